@@ -1,0 +1,231 @@
+/*
+ * igan_hip.h -- C ABI of libigan_hip.so: the MI355X (gfx950) kernels behind the
+ * InclusiveGAN G/D forward+backward hot path.
+ *
+ * This is the drop-in boundary for the reference's two native plugin mechanisms:
+ *   (1) the TF custom ops loaded by dnnlib/tflib/custom_ops.py:87-167
+ *       (UpFirDn2D  -> dnnlib/tflib/ops/upfirdn_2d.cu:310-324,
+ *        FusedBiasAct -> dnnlib/tflib/ops/fused_bias_act.cu:174-186), and
+ *   (2) the convolution / matmul / reduction / optimizer arithmetic the reference
+ *       obtains from TensorFlow+cuDNN (networks_stylegan2.py:46,60,120,
+ *       upfirdn_2d.py:291,332, optimizer.py:318-332) and the nearest-neighbour
+ *       search it obtains from dci_code (dci.h:76-89).
+ *
+ * Conventions (same contract as the reference ops):
+ *   - plain pointers and sizes only; no torch / TF types;
+ *   - the CALLER owns every buffer (inputs, outputs, workspaces); nothing is
+ *     allocated, retained or freed by the library;
+ *   - every entry point enqueues work on the given hipStream_t and returns
+ *     without synchronising (graph-capturable, re-entrant);
+ *   - return value 0 == IGAN_OK; on failure a thread-local message is available
+ *     from igan_last_error() (invalid arguments mirror the reference's
+ *     OP_REQUIRES checks, e.g. upfirdn_2d.cu:228-229,241-244,252,256,266);
+ *   - element counts are limited to int32 like the reference (upfirdn_2d.cu:243).
+ *   - all activation tensors are fp32, channel-minor ("NHWC"): [N, H, W, C].
+ */
+#ifndef IGAN_HIP_H
+#define IGAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IGAN_ABI_VERSION 1
+
+typedef void* igan_stream_t; /* hipStream_t */
+
+enum igan_status {
+    IGAN_OK = 0,
+    IGAN_ERR_INVALID_ARGUMENT = 1, /* reference: errors::InvalidArgument */
+    IGAN_ERR_HIP = 2,              /* reference: errors::Internal(cudaGetErrorName) */
+    IGAN_ERR_UNSUPPORTED = 3
+};
+
+int igan_abi_version(void);
+const char* igan_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * upfirdn2d: pad -> zero-insert upsample -> FIR -> decimate.
+ * Replaces UpFirDn2DOp<T>::Compute + UpFirDn2DKernel_{small,large}
+ * (dnnlib/tflib/ops/upfirdn_2d.cu:33-59,64-207,232-307).
+ *   y[m,oy,ox,c] = sum_{ky,kx} xup_pad[m, oy*downy+ky, ox*downx+kx, c] * k[kH-1-ky, kW-1-kx]
+ * outW/outH are derived exactly as upfirdn_2d.cu:254-255 and must match.
+ * `k` is a HOST pointer (<= 64 taps; the reference wrapper always builds the
+ * filter from a NumPy constant, upfirdn_2d.py:123-124); it is copied into the
+ * kernel arguments, so the call stays graph-capturable.
+ */
+typedef struct igan_upfirdn2d_params {
+    const float* x; /* [majorDim, inH, inW, minorDim] device */
+    const float* k; /* [kernelH, kernelW] HOST */
+    float* y;       /* [majorDim, outH, outW, minorDim] device */
+    int upx, upy, downx, downy;
+    int padx0, padx1, pady0, pady1;
+    int majorDim, inH, inW, minorDim;
+    int kernelH, kernelW;
+    int outH, outW;
+} igan_upfirdn2d_params;
+
+int igan_upfirdn2d(igan_stream_t stream, const igan_upfirdn2d_params* p);
+
+/* ------------------------------------------------------------------------
+ * fused_bias_act: y = act(x + b[(i / stepB) % sizeB]) * gain  (grad == 0) and its
+ * first / second derivative forms (grad == 1, 2) selected by act*10+grad.
+ * Replaces FusedBiasActOp<T>::Compute + FusedBiasActKernel
+ * (dnnlib/tflib/ops/fused_bias_act.cu:22-40,42-116,139-171).
+ * act index follows fused_bias_act.py:20-30 (1 linear, 2 relu, 3 lrelu, 4 tanh,
+ * 5 sigmoid, 6 elu, 7 selu, 8 softplus, 9 swish).
+ */
+typedef struct igan_fused_bias_act_params {
+    const float* x;   /* [sizeX] */
+    const float* b;   /* [sizeB] or NULL */
+    const float* ref; /* [sizeX] or NULL (required iff grad != 0) */
+    float* y;         /* [sizeX] */
+    int grad;
+    int act;
+    float alpha;
+    float gain;
+    int sizeX;
+    int sizeB;
+    int stepB;
+} igan_fused_bias_act_params;
+
+int igan_fused_bias_act(igan_stream_t stream, const igan_fused_bias_act_params* p);
+
+/* Bias gradient: db[c] = sum over all i with (i / stepB) % sizeB == c of dx[i].
+ * Replaces the TF reduce_sum pair of fused_bias_act.py:137-146.
+ * Deterministic (fixed reduction order). `partial` is a caller-owned workspace of
+ * igan_bias_grad_workspace_floats(sizeX, sizeB, stepB) floats. */
+size_t igan_bias_grad_workspace_floats(int sizeX, int sizeB, int stepB);
+int igan_bias_grad(igan_stream_t stream, const float* dx, float* db, float* partial,
+                   int sizeX, int sizeB, int stepB);
+
+/* ------------------------------------------------------------------------
+ * conv2d (implicit GEMM on f32 MFMA, exact fp32 accumulate).
+ * One entry point covers what the reference gets from tf.nn.conv2d (SAME stride 1,
+ * networks_stylegan2.py:60,120; VALID stride 2, upfirdn_2d.py:332),
+ * tf.nn.conv2d_transpose (VALID stride 2, upfirdn_2d.py:291), tf.matmul
+ * (networks_stylegan2.py:46, as a 1x1 conv on [N,1,1,C]) and their input
+ * gradients:
+ *
+ *   y[n,oy,ox,co] = out_scale[n,co] * sum_{ky,kx,ci}
+ *        xup[n, oy*stride + ky - pad_y, ox*stride + kx - pad_x, ci] * in_scale[n,ci] * W(ky,kx,ci,co)
+ *   xup[n,v,u,ci] = x[n, v/up, u/up, ci] if v%up==0 && u%up==0 && in range else 0
+ *
+ * (cross-correlation, like tf.nn.conv2d).  w_transposed == 0: W(ky,kx,ci,co) =
+ * w[ky][kx][ci][co] (HWIO, networks_stylegan2.py:23).  w_transposed == 1: the
+ * buffer is the FORWARD layer's HWIO weight [KH][KW][Cout][Cin] and
+ * W(ky,kx,ci,co) = w[KH-1-ky][KW-1-kx][co][ci] (spatial flip + channel swap) --
+ * i.e. the data-gradient of a forward conv with (stride,up,pad) is this same entry
+ * point called with (stride'=up, up'=stride, pad'=K-1-pad, w_transposed=1).
+ * At most one of stride, up may exceed 1.  in_scale / out_scale (optional)
+ * implement StyleGAN2 modulation / demodulation in the non-fused form of
+ * networks_stylegan2.py:112,126.
+ *
+ * Split-K: when splits > 1 the reduction axis (taps x Cin) is cut into `splits`
+ * slices whose partial tiles go to `workspace` ([splits][N*OH*OW][Cout] floats)
+ * and are summed in fixed order by a second kernel (bit-reproducible).
+ * igan_conv2d_plan() suggests `splits` and the workspace size for a shape.
+ */
+typedef struct igan_conv2d_params {
+    const float* x;         /* [N, H, W, Cin] */
+    const float* w;         /* see above */
+    float* y;               /* [N, OH, OW, Cout] */
+    const float* in_scale;  /* [N, Cin] or NULL */
+    const float* out_scale; /* [N, Cout] or NULL */
+    float* workspace;       /* NULL iff splits <= 1 */
+    size_t workspace_floats;
+    int N, H, W, Cin;
+    int OH, OW, Cout;
+    int KH, KW;
+    int stride, up;
+    int pad_y, pad_x;
+    int w_transposed;
+    int splits;
+} igan_conv2d_params;
+
+int igan_conv2d_plan(const igan_conv2d_params* p, int* splits, size_t* workspace_floats);
+int igan_conv2d(igan_stream_t stream, const igan_conv2d_params* p);
+
+/* Weight gradient of the op above (same geometry fields):
+ *   dw[ky,kx,ci,co] = sum_{n,oy,ox} xup[n, oy*stride+ky-pad_y, ox*stride+kx-pad_x, ci]
+ *                                   * in_scale[n,ci] * dy[n,oy,ox,co] * out_scale[n,co]
+ * written in HWIO [KH][KW][Cin][Cout].  The pixel axis is always reduced through
+ * the caller's workspace in fixed order (bit-reproducible);
+ * igan_conv2d_wgrad_plan() returns the split count and workspace size. */
+typedef struct igan_conv2d_wgrad_params {
+    const float* x;         /* [N, H, W, Cin] */
+    const float* dy;        /* [N, OH, OW, Cout] */
+    float* dw;              /* [KH, KW, Cin, Cout] */
+    const float* in_scale;  /* [N, Cin] or NULL */
+    const float* out_scale; /* [N, Cout] or NULL */
+    float* workspace;
+    size_t workspace_floats;
+    int N, H, W, Cin;
+    int OH, OW, Cout;
+    int KH, KW;
+    int stride, up;
+    int pad_y, pad_x;
+    int splits;
+} igan_conv2d_wgrad_params;
+
+int igan_conv2d_wgrad_plan(const igan_conv2d_wgrad_params* p, int* splits, size_t* workspace_floats);
+int igan_conv2d_wgrad(igan_stream_t stream, const igan_conv2d_wgrad_params* p);
+
+/* ------------------------------------------------------------------------
+ * minibatch_stddev_layer statistics (networks_stylegan2.py:132-144), NHWC input
+ * x[N, H, W, C], group size G (N % G == 0, M = N / G, num_new_features = 1):
+ *   stat[m] = mean_{c,h,w} sqrt( mean_g (x[g*M+m] - mean_g x)^2 + 1e-8 )
+ * fwd writes y[N, H, W, C+1] = concat(x, stat[n % M]) in one pass.
+ * bwd takes dy[N,H,W,C+1] and returns dx[N,H,W,C] (pass-through + statistic path).
+ */
+int igan_mbstd_fwd(igan_stream_t stream, const float* x, float* y, float* stat,
+                   int N, int H, int W, int C, int G);
+int igan_mbstd_bwd(igan_stream_t stream, const float* x, const float* dy, float* dx,
+                   int N, int H, int W, int C, int G);
+
+/* ------------------------------------------------------------------------
+ * Exact streaming 1-nearest-neighbour (replaces dci_add + dci_query as used at
+ * training/training_loop.py:367-368,398 with num_neighbours = 1).
+ *   best[q] = min over candidates c of pack(|query_q - cand_c|^2, idx_base + c)
+ * `best` holds one uint64 per query: high 32 bits = bit pattern of the (clamped
+ * >= 0) fp32 squared distance, low 32 bits = candidate index; initialise to
+ * 0xFFFFFFFFFFFFFFFF.  Candidates can be streamed batch after batch with
+ * increasing idx_base; the running minimum is order-independent and ties go to
+ * the lower index, so the result is deterministic.
+ * qnorm / cnorm are the squared row norms (igan_row_sqnorm, fp64 accumulate);
+ * the dot products run on the exact-fp32 MFMA and |q|^2 + |c|^2 - 2 q.c is combined
+ * in fp64 before rounding to fp32.  The caller takes sqrt (Euclidean distance,
+ * dci_code/src/util.c:62-69) when unpacking.
+ */
+int igan_row_sqnorm(igan_stream_t stream, const float* a, float* out, int rows, int dim);
+int igan_nn1_update(igan_stream_t stream, const float* query, const float* qnorm,
+                    const float* cand, const float* cnorm, unsigned long long* best,
+                    float* dots /* caller workspace, nq*nc floats */,
+                    int nq, int nc, int dim, int idx_base);
+
+/* ------------------------------------------------------------------------
+ * Flat-bucket optimizer step (dnnlib/tflib/optimizer.py:237-239,318-332):
+ *   flag[0] = all(isfinite(grad));  if flag: Adam update; else: skip.
+ *   m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g; w -= lr_t * m / (sqrt(v) + eps)
+ * lr_t = lr * sqrt(1 - b2pow') / (1 - b1pow') with b?pow' = b?pow * beta? read from
+ * the device-resident pow_state[2] = {b1pow, b2pow} (initialise to {1, 1}); the
+ * powers advance only when the step is applied, like TF's beta-power slots, and
+ * no host synchronisation is needed to learn whether it was.
+ * igan_finite_check ORs a non-zero into flag[0] when any element is non-finite
+ * (flag must be zeroed by the caller before the first check of a step).
+ * igan_ema: dst = src + (dst - src) * beta  (Network.setup_as_moving_average_of,
+ * dnnlib/tflib/network.py:341-351).
+ */
+int igan_finite_check(igan_stream_t stream, const float* g, int n, int* flag);
+int igan_adam_step(igan_stream_t stream, float* w, const float* g, float* m, float* v,
+                   int n, float lr, float beta1, float beta2, float eps,
+                   float* pow_state, const int* skip_flag);
+int igan_ema(igan_stream_t stream, float* dst, const float* src, int n, float beta);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IGAN_HIP_H */

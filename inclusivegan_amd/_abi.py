@@ -1,0 +1,139 @@
+"""ctypes binding of include/igan_hip.h (libigan_hip.so).
+
+This is the only place the product touches native code.  It plays the role of
+`dnnlib/tflib/custom_ops.py:87-167` (`get_plugin`) in the reference: locate the
+compiled plugin, load it once per process, hand out callables.  Unlike the
+reference there is no JIT: the library is built ahead of time for gfx950 by
+`__graft_entry__.build()` / `make -C inclusivegan_amd/csrc`.
+
+There is deliberately NO fallback: if the shared library is missing or a symbol
+is absent, importing a kernel raises.  The CPU oracle under `oracle/` is test
+infrastructure and is never imported from here.
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libigan_hip.so')
+
+IGAN_OK = 0
+IGAN_ERR_INVALID_ARGUMENT = 1
+IGAN_ERR_HIP = 2
+IGAN_ERR_UNSUPPORTED = 3
+
+c_float_p = ctypes.POINTER(ctypes.c_float)
+
+
+class UpFirDn2DParams(ctypes.Structure):
+    _fields_ = [
+        ('x', ctypes.c_void_p), ('k', ctypes.c_void_p), ('y', ctypes.c_void_p),
+        ('upx', ctypes.c_int), ('upy', ctypes.c_int), ('downx', ctypes.c_int), ('downy', ctypes.c_int),
+        ('padx0', ctypes.c_int), ('padx1', ctypes.c_int), ('pady0', ctypes.c_int), ('pady1', ctypes.c_int),
+        ('majorDim', ctypes.c_int), ('inH', ctypes.c_int), ('inW', ctypes.c_int), ('minorDim', ctypes.c_int),
+        ('kernelH', ctypes.c_int), ('kernelW', ctypes.c_int),
+        ('outH', ctypes.c_int), ('outW', ctypes.c_int),
+    ]
+
+
+class FusedBiasActParams(ctypes.Structure):
+    _fields_ = [
+        ('x', ctypes.c_void_p), ('b', ctypes.c_void_p), ('ref', ctypes.c_void_p), ('y', ctypes.c_void_p),
+        ('grad', ctypes.c_int), ('act', ctypes.c_int),
+        ('alpha', ctypes.c_float), ('gain', ctypes.c_float),
+        ('sizeX', ctypes.c_int), ('sizeB', ctypes.c_int), ('stepB', ctypes.c_int),
+    ]
+
+
+class Conv2DParams(ctypes.Structure):
+    _fields_ = [
+        ('x', ctypes.c_void_p), ('w', ctypes.c_void_p), ('y', ctypes.c_void_p),
+        ('in_scale', ctypes.c_void_p), ('out_scale', ctypes.c_void_p),
+        ('workspace', ctypes.c_void_p), ('workspace_floats', ctypes.c_size_t),
+        ('N', ctypes.c_int), ('H', ctypes.c_int), ('W', ctypes.c_int), ('Cin', ctypes.c_int),
+        ('OH', ctypes.c_int), ('OW', ctypes.c_int), ('Cout', ctypes.c_int),
+        ('KH', ctypes.c_int), ('KW', ctypes.c_int),
+        ('stride', ctypes.c_int), ('up', ctypes.c_int),
+        ('pad_y', ctypes.c_int), ('pad_x', ctypes.c_int),
+        ('w_transposed', ctypes.c_int), ('splits', ctypes.c_int),
+    ]
+
+
+class Conv2DWgradParams(ctypes.Structure):
+    _fields_ = [
+        ('x', ctypes.c_void_p), ('dy', ctypes.c_void_p), ('dw', ctypes.c_void_p),
+        ('in_scale', ctypes.c_void_p), ('out_scale', ctypes.c_void_p),
+        ('workspace', ctypes.c_void_p), ('workspace_floats', ctypes.c_size_t),
+        ('N', ctypes.c_int), ('H', ctypes.c_int), ('W', ctypes.c_int), ('Cin', ctypes.c_int),
+        ('OH', ctypes.c_int), ('OW', ctypes.c_int), ('Cout', ctypes.c_int),
+        ('KH', ctypes.c_int), ('KW', ctypes.c_int),
+        ('stride', ctypes.c_int), ('up', ctypes.c_int),
+        ('pad_y', ctypes.c_int), ('pad_x', ctypes.c_int),
+        ('splits', ctypes.c_int),
+    ]
+
+
+_I, _F, _P, _SZ = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+# name -> (restype, argtypes): every symbol include/igan_hip.h declares.
+SIGNATURES = {
+    'igan_abi_version': (_I, []),
+    'igan_last_error': (ctypes.c_char_p, []),
+    'igan_upfirdn2d': (_I, [_P, ctypes.POINTER(UpFirDn2DParams)]),
+    'igan_fused_bias_act': (_I, [_P, ctypes.POINTER(FusedBiasActParams)]),
+    'igan_bias_grad_workspace_floats': (_SZ, [_I, _I, _I]),
+    'igan_bias_grad': (_I, [_P, _P, _P, _P, _I, _I, _I]),
+    'igan_conv2d_plan': (_I, [ctypes.POINTER(Conv2DParams), ctypes.POINTER(_I), ctypes.POINTER(_SZ)]),
+    'igan_conv2d': (_I, [_P, ctypes.POINTER(Conv2DParams)]),
+    'igan_conv2d_wgrad_plan': (_I, [ctypes.POINTER(Conv2DWgradParams), ctypes.POINTER(_I), ctypes.POINTER(_SZ)]),
+    'igan_conv2d_wgrad': (_I, [_P, ctypes.POINTER(Conv2DWgradParams)]),
+    'igan_mbstd_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I]),
+    'igan_mbstd_bwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I]),
+    'igan_row_sqnorm': (_I, [_P, _P, _P, _I, _I]),
+    'igan_nn1_update': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I]),
+    'igan_finite_check': (_I, [_P, _P, _I, _P]),
+    'igan_adam_step': (_I, [_P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _P, _P]),
+    'igan_ema': (_I, [_P, _P, _P, _I, _F]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class IganError(RuntimeError):
+    """HIP-side failure (reference: errors::Internal -> tf.errors.InternalError)."""
+
+
+def get_plugin():
+    """Load libigan_hip.so once per process (reference: custom_ops.get_plugin)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.isfile(LIB_PATH):
+            raise ImportError(
+                'inclusivegan_amd: %s is missing. Build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                'or `make -C inclusivegan_amd/csrc`. There is no CPU fallback.' % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is absent
+            fn.restype = restype
+            fn.argtypes = argtypes
+        if lib.igan_abi_version() != 1:
+            raise ImportError('inclusivegan_amd: libigan_hip.so ABI version mismatch')
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    """Translate a status code into the exception the reference would surface."""
+    if rc == IGAN_OK:
+        return
+    msg = get_plugin().igan_last_error().decode('utf-8', 'replace')
+    if rc == IGAN_ERR_INVALID_ARGUMENT:
+        raise ValueError(msg)       # tf.errors.InvalidArgumentError
+    if rc == IGAN_ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise IganError(msg)            # tf.errors.InternalError

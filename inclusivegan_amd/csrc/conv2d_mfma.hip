@@ -1,0 +1,669 @@
+// conv2d / conv2d_transpose / matmul and their data- and weight-gradients for
+// gfx950, as ONE implicit-GEMM family on the exact-fp32 matrix instruction
+// v_mfma_f32_32x32x2_f32.
+//
+// Behavioural contract (what the reference gets from TensorFlow + cuDNN):
+//   tf.nn.conv2d SAME stride 1      training/networks_stylegan2.py:60,120
+//   tf.nn.conv2d VALID stride 2     dnnlib/tflib/ops/upfirdn_2d.py:332
+//   tf.nn.conv2d_transpose stride 2 dnnlib/tflib/ops/upfirdn_2d.py:286-291
+//   tf.matmul (dense_layer)         training/networks_stylegan2.py:41-46
+// and, through tf.gradients, their input and filter gradients (first and second
+// order -- the data gradient of one geometry is the forward op of the mirrored
+// geometry, see include/igan_hip.h).  fp32 in, fp32 accumulate, like the reference
+// (dtype='float32', networks_stylegan2.py:264,323,422).
+//
+// MI355X design (none of it is in the reference, which calls cuDNN):
+//  * activations are channel-minor [N,H,W,C]: an A-tile row (one output pixel, 32
+//    input channels of one tap) is a contiguous 128 B segment -> coalesced 16 B
+//    loads, no im2col buffer ever exists in HBM;
+//  * conv2d_transpose is NOT run as a zero-stuffed convolution: output pixels are
+//    partitioned into up*up parity classes, each class being a dense conv with
+//    the sub-lattice of taps that hits real samples (2.25 instead of 9 taps for
+//    3x3, up 2), one grid.z slice per class;
+//  * block tile BM x BN x 32, 4 wavefronts (one per SIMD), each owning TM x TN
+//    tiles of 32x32 accumulators (16 VGPRs each); the two 32-lane halves of a wave
+//    take k = 0..15 and 16..31 of the chunk (any bijection of k is legal for a
+//    reduction) so a lane's 16 A values are 64 contiguous bytes in LDS
+//    (4 x ds_read_b128, conflict-free with the 36-float row pitch);
+//  * register-staged double buffering: the global loads of chunk c+1 are issued
+//    before the 16*TM*TN MFMAs of chunk c and written to the other LDS buffer
+//    after them -- one barrier per chunk;
+//  * StyleGAN2 modulation / demodulation ride along as per-(sample,channel)
+//    scales on the A-operand load and in the epilogue (non-fused modconv form,
+//    networks_stylegan2.py:112,126), so x*s and y*d never round-trip HBM;
+//  * small-M layers (4x4 .. 16x16, dense) are split along the reduction axis
+//    across workgroups; partial tiles go to a caller-owned workspace and a second
+//    kernel adds them in fixed order (bit-reproducible, no float atomics).
+#include "igan_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;        // reduction chunk (floats)
+constexpr int LDK = BK + 4;   // row pitch of a [rows][k] LDS image (144 B: 16 B aligned, conflict-free b128 reads)
+
+struct ConvArgs {
+    const float* x;
+    const float* w;
+    float* y;          // final output (splits == 1) or workspace (splits > 1)
+    const float* in_scale;
+    const float* out_scale;
+    int N, H, W, Cin;
+    int OH, OW, Cout;
+    int KH, KW;
+    int stride, up_shift;   // up == 1 << up_shift
+    int pad_y, pad_x;
+    int splits;
+    int cpt;                // chunks per tap = ceil(Cin / 32)
+    int Mtot;               // N*OH*OW
+    int vecA, vecB, vecS;   // 16 B paths usable for x rows / w rows / in_scale rows
+};
+
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 f4mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+
+// Load 4 consecutive floats p[0..3] with element bound `left` (number of valid
+// elements starting at p; may be <= 0).  vec: pointer is 16 B aligned and the
+// four elements are all-in or all-out.
+__device__ __forceinline__ float4 load4(const float* p, int left, bool vec) {
+    if (vec) return (left > 0) ? *reinterpret_cast<const float4*>(p) : f4zero();
+    float4 r = f4zero();
+    if (left > 0) r.x = p[0];
+    if (left > 1) r.y = p[1];
+    if (left > 2) r.z = p[2];
+    if (left > 3) r.w = p[3];
+    return r;
+}
+
+// One chunk of MFMAs for this wave.  A image: [m][k] (A_KMAJOR = false, pitch LDK)
+// or [k][m] (A_KMAJOR = true, pitch LDA).  B image: [k][n] (B_KMAJOR = true, pitch
+// LDB) or [n][k] (B_KMAJOR = false, pitch LDK).
+template <int TM, int TN, bool A_KMAJOR, bool B_KMAJOR, int LDA, int LDB>
+__device__ __forceinline__ void mma_chunk(const float* __restrict__ As, const float* __restrict__ Bs,
+                                          f32x16 (&acc)[TM][TN], int am0, int bn0, int l31, int h) {
+    float af[TM][16];
+    float bf[TN][16];
+#pragma unroll
+    for (int tm = 0; tm < TM; tm++) {
+        if constexpr (!A_KMAJOR) {
+            const float4* pa = reinterpret_cast<const float4*>(As + (am0 + tm * 32 + l31) * LDK + 16 * h);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float4 v = pa[q];
+                af[tm][4 * q + 0] = v.x; af[tm][4 * q + 1] = v.y; af[tm][4 * q + 2] = v.z; af[tm][4 * q + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; j++) af[tm][j] = As[(16 * h + j) * LDA + am0 + tm * 32 + l31];
+        }
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; tn++) {
+        if constexpr (!B_KMAJOR) {
+            const float4* pb = reinterpret_cast<const float4*>(Bs + (bn0 + tn * 32 + l31) * LDK + 16 * h);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float4 v = pb[q];
+                bf[tn][4 * q + 0] = v.x; bf[tn][4 * q + 1] = v.y; bf[tn][4 * q + 2] = v.z; bf[tn][4 * q + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; j++) bf[tn][j] = Bs[(16 * h + j) * LDB + bn0 + tn * 32 + l31];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+#pragma unroll
+        for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+            for (int tn = 0; tn < TN; tn++)
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm][j], bf[tn][j], acc[tm][tn], 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------
+// Forward-type kernel (conv, transposed conv, dense, and all data gradients).
+// grid = (m tiles of the largest class, n tiles, classes * splits)
+template <int BM, int BN, int WM, int WN, bool WT>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
+    constexpr int TM = BM / WM / 32;
+    constexpr int TN = BN / WN / 32;
+    constexpr int LDB = WT ? LDK : BN + 4;
+    constexpr int A_ELEMS = BM * LDK;
+    constexpr int B_ELEMS = WT ? BN * LDK : BK * (BN + 4);
+    constexpr int AR = BM / 32;  // A rows per thread
+    constexpr int BR = BN / 32;  // B float4 per thread (both layouts)
+    static_assert(TM >= 1 && TN >= 1 && WM * WN == 4, "bad tile config");
+
+    __shared__ __attribute__((aligned(16))) float As[2 * A_ELEMS];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * B_ELEMS];
+    __shared__ int row_pix[BM];  // linear output pixel (n*OH+oy)*OW+ox, or -1
+    __shared__ int row_n[BM];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int up = 1 << a.up_shift;
+    const int cls = blockIdx.z / a.splits;
+    const int split = blockIdx.z - cls * a.splits;
+    const int py = cls >> a.up_shift, px = cls & (up - 1);
+    const int QH = (a.OH - py + up - 1) >> a.up_shift;
+    const int QW = (a.OW - px + up - 1) >> a.up_shift;
+    const int Mcls = a.N * QH * QW;
+    const int m0 = blockIdx.x * BM;
+    if (m0 >= Mcls) return;  // uniform: smaller classes have fewer tiles
+    const int n0 = blockIdx.y * BN;
+
+    // taps of this class: ky = ky0 + up*i  (all taps when up == 1)
+    int ky0 = (a.pad_y - py * a.stride) & (up - 1);
+    int kx0 = (a.pad_x - px * a.stride) & (up - 1);
+    const int nky = (ky0 < a.KH) ? ((a.KH - ky0 + up - 1) >> a.up_shift) : 0;
+    const int nkx = (kx0 < a.KW) ? ((a.KW - kx0 + up - 1) >> a.up_shift) : 0;
+    const int chunks = nky * nkx * a.cpt;
+    const int c_begin = (int)(((long long)split * chunks) / a.splits);
+    const int c_end = (int)(((long long)(split + 1) * chunks) / a.splits);
+
+    // ---- per-row bookkeeping ----
+    if (tid < BM) {
+        const int m = m0 + tid;
+        int pix = -1, nn = 0;
+        if (m < Mcls) {
+            nn = m / (QH * QW);
+            const int r = m - nn * (QH * QW);
+            const int qy = r / QW, qx = r - qy * QW;
+            pix = (nn * a.OH + (qy * up + py)) * a.OW + (qx * up + px);
+        }
+        row_pix[tid] = pix;
+        row_n[tid] = nn;
+    }
+    // loader rows (registers)
+    const int kvec = tid & 7;
+    const int arow0 = tid >> 3;
+    int rn[AR], rby[AR], rbx[AR];
+    bool rok[AR];
+#pragma unroll
+    for (int i = 0; i < AR; i++) {
+        const int m = m0 + arow0 + 32 * i;
+        rok[i] = m < Mcls;
+        const int mm = rok[i] ? m : 0;
+        const int nn = mm / (QH * QW);
+        const int r = mm - nn * (QH * QW);
+        const int qy = r / QW, qx = r - qy * QW;
+        rn[i] = nn;
+        rby[i] = (qy * up + py) * a.stride - a.pad_y;
+        rbx[i] = (qx * up + px) * a.stride - a.pad_x;
+    }
+    // B loader coordinates
+    constexpr int NV = BN / 4;            // float4 per B row (normal layout)
+    constexpr int KROWS = 256 / NV;       // k rows per pass (normal layout)
+    const int nvec = WT ? 0 : (tid % NV);
+    const int krow0 = WT ? 0 : (tid / NV);
+    const int brow0 = tid >> 3;           // transposed layout: n row
+
+    float4 ra[AR], rb[BR];
+
+    auto load_chunk = [&](int c) {
+        const int t = c / a.cpt;
+        const int ci0 = (c - t * a.cpt) * BK;
+        const int ta = t / nkx, tb = t - ta * nkx;
+        const int ky = ky0 + (ta << a.up_shift), kx = kx0 + (tb << a.up_shift);
+        const int ci = ci0 + 4 * kvec;
+#pragma unroll
+        for (int i = 0; i < AR; i++) {
+            const int vy = rby[i] + ky, vx = rbx[i] + kx;
+            const int iy = vy >> a.up_shift, ix = vx >> a.up_shift;
+            const bool ok = rok[i] & (vy >= 0) & (vx >= 0) & (iy < a.H) & (ix < a.W);
+            const float* p = a.x + ((rn[i] * a.H + iy) * a.W + ix) * a.Cin + ci;
+            float4 v = load4(p, ok ? (a.Cin - ci) : 0, a.vecA);
+            if (a.in_scale) v = f4mul(v, load4(a.in_scale + rn[i] * a.Cin + ci, ok ? (a.Cin - ci) : 0, a.vecS));
+            ra[i] = v;
+        }
+        if constexpr (!WT) {
+#pragma unroll
+            for (int i = 0; i < BR; i++) {
+                const int kr = krow0 + KROWS * i;
+                const int cik = ci0 + kr;
+                const int co = n0 + 4 * nvec;
+                const float* p = a.w + ((ky * a.KW + kx) * a.Cin + cik) * a.Cout + co;
+                rb[i] = load4(p, (cik < a.Cin) ? (a.Cout - co) : 0, a.vecB);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < BR; i++) {
+                const int co = n0 + brow0 + 32 * i;
+                const float* p = a.w + (((a.KH - 1 - ky) * a.KW + (a.KW - 1 - kx)) * a.Cout + co) * a.Cin + ci;
+                rb[i] = load4(p, (co < a.Cout) ? (a.Cin - ci) : 0, a.vecB);
+            }
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        float* A = As + buf * A_ELEMS;
+        float* B = Bs + buf * B_ELEMS;
+#pragma unroll
+        for (int i = 0; i < AR; i++) *reinterpret_cast<float4*>(A + (arow0 + 32 * i) * LDK + 4 * kvec) = ra[i];
+        if constexpr (!WT) {
+#pragma unroll
+            for (int i = 0; i < BR; i++) *reinterpret_cast<float4*>(B + (krow0 + KROWS * i) * LDB + 4 * nvec) = rb[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < BR; i++) *reinterpret_cast<float4*>(B + (brow0 + 32 * i) * LDK + 4 * kvec) = rb[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+        for (int tn = 0; tn < TN; tn++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[tm][tn][r] = 0.0f;
+
+    if (c_begin < c_end) {
+        load_chunk(c_begin);
+        store_chunk(0);
+    }
+    __syncthreads();
+    for (int c = c_begin; c < c_end; c++) {
+        const int cur = (c - c_begin) & 1;
+        const bool more = (c + 1 < c_end);
+        if (more) load_chunk(c + 1);
+        mma_chunk<TM, TN, false, !WT, LDK, LDB>(As + cur * A_ELEMS, Bs + cur * B_ELEMS, acc,
+                                                 wm * (BM / WM), wn * (BN / WN), l31, h);
+        if (more) store_chunk(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*h ----
+    float* out = a.y + (a.splits > 1 ? (size_t)split * a.Mtot * a.Cout : (size_t)0);
+    const bool scale = (a.out_scale != nullptr) && (a.splits == 1);
+#pragma unroll
+    for (int tm = 0; tm < TM; tm++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = wm * (BM / WM) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int pix = row_pix[row];
+            if (pix < 0) continue;
+            const int nn = row_n[row];
+#pragma unroll
+            for (int tn = 0; tn < TN; tn++) {
+                const int co = n0 + wn * (BN / WN) + tn * 32 + l31;
+                if (co < a.Cout) {
+                    float v = acc[tm][tn][r];
+                    if (scale) v *= a.out_scale[nn * a.Cout + co];
+                    out[(size_t)pix * a.Cout + co] = v;
+                }
+            }
+        }
+    }
+}
+
+// y[i] = out_scale * sum_s ws[s][i]   (fixed order)
+__global__ __launch_bounds__(256) void conv_reduce_kernel(const float* ws, float* y, const float* out_scale,
+                                                          int total, int splits, int Cout, int pix_per_n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < splits; k++) s += ws[(size_t)k * total + i];
+        if (out_scale) {
+            const int pix = i / Cout;
+            const int co = i - pix * Cout;
+            s *= out_scale[(pix / pix_per_n) * Cout + co];
+        }
+        y[i] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------
+// Weight-gradient kernel: dw[tap][ci][co] = sum_pixels xs[pixel(tap)][ci] * dys[pixel][co].
+// GEMM view: M = Cin tile, N = Cout tile, K = pixels of the tap's parity class.
+// grid = (ci tiles, co tiles, taps * splits)
+struct WgradArgs {
+    const float* x;
+    const float* dy;
+    float* out;  // dw (splits == 1) or workspace [splits][KH*KW*Cin*Cout]
+    const float* in_scale;
+    const float* out_scale;
+    int N, H, W, Cin;
+    int OH, OW, Cout;
+    int KH, KW;
+    int stride, up_shift;
+    int pad_y, pad_x;
+    int splits;
+    int vecA, vecB, vecSA, vecSB;
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+    constexpr int TM = BM / WM / 32;
+    constexpr int TN = BN / WN / 32;
+    constexpr int LDA = BM + 4;
+    constexpr int LDB = BN + 4;
+    constexpr int A_ELEMS = BK * LDA;
+    constexpr int B_ELEMS = BK * LDB;
+    constexpr int MV = BM / 4, NV = BN / 4;
+    constexpr int AROWS = 256 / MV, BROWS = 256 / NV;  // pixel rows per pass
+    constexpr int AR = BK / AROWS, BR = BK / BROWS;    // float4 per thread
+    static_assert(AR >= 1 && BR >= 1, "tile too wide");
+
+    __shared__ __attribute__((aligned(16))) float As[2 * A_ELEMS];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * B_ELEMS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int up = 1 << a.up_shift;
+    const int tap = blockIdx.z / a.splits;
+    const int split = blockIdx.z - tap * a.splits;
+    const int ky = tap / a.KW, kx = tap - ky * a.KW;
+    const int py = (a.pad_y - ky) & (up - 1);  // stride == 1 whenever up > 1
+    const int px = (a.pad_x - kx) & (up - 1);
+    const int QH = (a.OH - py + up - 1) >> a.up_shift;
+    const int QW = (a.OW - px + up - 1) >> a.up_shift;
+    const int Kpix = (QH > 0 && QW > 0) ? a.N * QH * QW : 0;
+    const int chunks = (Kpix + BK - 1) / BK;
+    const int c_begin = (int)(((long long)split * chunks) / a.splits);
+    const int c_end = (int)(((long long)(split + 1) * chunks) / a.splits);
+    const int m0 = blockIdx.x * BM;  // ci
+    const int n0 = blockIdx.y * BN;  // co
+
+    const int amv = tid % MV, aprow0 = tid / MV;
+    const int bnv = tid % NV, bprow0 = tid / NV;
+
+    float4 ra[AR], rb[BR];
+
+    auto decode = [&](int kp, int& nn, int& oy, int& ox) {
+        nn = kp / (QH * QW);
+        const int r = kp - nn * (QH * QW);
+        const int qy = r / QW, qx = r - qy * QW;
+        oy = qy * up + py;
+        ox = qx * up + px;
+    };
+    auto load_chunk = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < AR; i++) {
+            const int kp = c * BK + aprow0 + AROWS * i;
+            int nn = 0, oy = 0, ox = 0;
+            const bool in = kp < Kpix;
+            if (in) decode(kp, nn, oy, ox);
+            const int vy = oy * a.stride + ky - a.pad_y, vx = ox * a.stride + kx - a.pad_x;
+            const int iy = vy >> a.up_shift, ix = vx >> a.up_shift;
+            const bool ok = in & (vy >= 0) & (vx >= 0) & (iy < a.H) & (ix < a.W);
+            const int ci = m0 + 4 * amv;
+            const float* p = a.x + ((nn * a.H + iy) * a.W + ix) * a.Cin + ci;
+            float4 v = load4(p, ok ? (a.Cin - ci) : 0, a.vecA);
+            if (a.in_scale) v = f4mul(v, load4(a.in_scale + nn * a.Cin + ci, ok ? (a.Cin - ci) : 0, a.vecSA));
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < BR; i++) {
+            const int kp = c * BK + bprow0 + BROWS * i;
+            int nn = 0, oy = 0, ox = 0;
+            const bool in = kp < Kpix;
+            if (in) decode(kp, nn, oy, ox);
+            const int co = n0 + 4 * bnv;
+            const float* p = a.dy + ((nn * a.OH + oy) * a.OW + ox) * a.Cout + co;
+            float4 v = load4(p, in ? (a.Cout - co) : 0, a.vecB);
+            if (a.out_scale) v = f4mul(v, load4(a.out_scale + nn * a.Cout + co, in ? (a.Cout - co) : 0, a.vecSB));
+            rb[i] = v;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        float* A = As + buf * A_ELEMS;
+        float* B = Bs + buf * B_ELEMS;
+#pragma unroll
+        for (int i = 0; i < AR; i++) *reinterpret_cast<float4*>(A + (aprow0 + AROWS * i) * LDA + 4 * amv) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BR; i++) *reinterpret_cast<float4*>(B + (bprow0 + BROWS * i) * LDB + 4 * bnv) = rb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+        for (int tn = 0; tn < TN; tn++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[tm][tn][r] = 0.0f;
+
+    if (c_begin < c_end) {
+        load_chunk(c_begin);
+        store_chunk(0);
+    }
+    __syncthreads();
+    for (int c = c_begin; c < c_end; c++) {
+        const int cur = (c - c_begin) & 1;
+        const bool more = (c + 1 < c_end);
+        if (more) load_chunk(c + 1);
+        mma_chunk<TM, TN, true, true, LDA, LDB>(As + cur * A_ELEMS, Bs + cur * B_ELEMS, acc,
+                                                 wm * (BM / WM), wn * (BN / WN), l31, h);
+        if (more) store_chunk(cur ^ 1);
+        __syncthreads();
+    }
+
+    const size_t wsize = (size_t)a.KH * a.KW * a.Cin * a.Cout;
+    float* out = a.out + (a.splits > 1 ? (size_t)split * wsize : (size_t)0) + (size_t)tap * a.Cin * a.Cout;
+#pragma unroll
+    for (int tm = 0; tm < TM; tm++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int ci = m0 + wm * (BM / WM) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (ci >= a.Cin) continue;
+#pragma unroll
+            for (int tn = 0; tn < TN; tn++) {
+                const int co = n0 + wn * (BN / WN) + tn * 32 + l31;
+                if (co < a.Cout) out[(size_t)ci * a.Cout + co] = acc[tm][tn][r];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void plain_reduce_kernel(const float* ws, float* y, int total, int splits) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < splits; k++) s += ws[(size_t)k * total + i];
+        y[i] = s;
+    }
+}
+
+// ---- host-side planning --------------------------------------------------------
+struct FwdTile { int BM, BN; };
+
+FwdTile pick_fwd_tile(int Mmax, int Cout) {
+    FwdTile t;
+    t.BN = (Cout > 64) ? 128 : (Cout > 32 ? 64 : 32);
+    t.BM = (Mmax <= 32 && t.BN == 128) ? 32 : 128;
+    return t;
+}
+
+int fwd_geometry_check(const igan_conv2d_params* p) {
+    IGAN_REQUIRE(p->x && p->w && p->y, "conv2d: null buffer");
+    IGAN_REQUIRE(p->N >= 1 && p->H >= 1 && p->W >= 1 && p->Cin >= 1, "conv2d: input dims must be positive");
+    IGAN_REQUIRE(p->OH >= 1 && p->OW >= 1 && p->Cout >= 1, "conv2d: output dims must be positive");
+    IGAN_REQUIRE(p->KH >= 1 && p->KW >= 1, "conv2d: kernel must be at least 1x1");
+    IGAN_REQUIRE(p->stride >= 1 && p->up >= 1, "conv2d: stride and up must be at least 1");
+    IGAN_REQUIRE(p->stride == 1 || p->up == 1, "conv2d: at most one of stride, up may exceed 1");
+    if (!(p->up == 1 || p->up == 2)) return igan::fail(IGAN_ERR_UNSUPPORTED, "conv2d: up must be 1 or 2 (got %d)", p->up);
+    IGAN_REQUIRE((long long)p->N * p->H * p->W * p->Cin <= INT32_MAX, "conv2d: input too large");
+    IGAN_REQUIRE((long long)p->N * p->OH * p->OW * p->Cout <= INT32_MAX, "conv2d: output too large");
+    IGAN_REQUIRE((long long)p->KH * p->KW * p->Cin * p->Cout <= INT32_MAX, "conv2d: filter too large");
+    return IGAN_OK;
+}
+
+void fwd_counts(const igan_conv2d_params* p, int& Mmax, int& chunks_max, int& nclass) {
+    const int up = p->up;
+    nclass = up * up;
+    const int QH = (p->OH + up - 1) / up, QW = (p->OW + up - 1) / up;
+    Mmax = p->N * QH * QW;
+    const int cpt = (p->Cin + BK - 1) / BK;
+    // largest class tap count: ceil(KH/up)*ceil(KW/up)
+    chunks_max = ((p->KH + up - 1) / up) * ((p->KW + up - 1) / up) * cpt;
+}
+
+template <int BM, int BN, int WM, int WN>
+void launch_fwd(hipStream_t stream, const ConvArgs& a, dim3 grid, bool wt) {
+    if (wt) hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, true>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, false>), grid, dim3(256), 0, stream, a);
+}
+
+}  // namespace
+
+extern "C" int igan_conv2d_plan(const igan_conv2d_params* p, int* splits, size_t* workspace_floats) {
+    IGAN_REQUIRE(p && splits && workspace_floats, "conv2d_plan: null argument");
+    if (int rc = fwd_geometry_check(p)) return rc;
+    int Mmax, chunks_max, nclass;
+    fwd_counts(p, Mmax, chunks_max, nclass);
+    const FwdTile t = pick_fwd_tile(Mmax, p->Cout);
+    const long long blocks = (long long)igan::ceil_div(Mmax, t.BM) * igan::ceil_div(p->Cout, t.BN) * nclass;
+    int s = 1;
+    if (blocks < 256) {
+        s = (int)((512 + blocks - 1) / blocks);
+        s = std::min(s, std::max(1, chunks_max / 2));
+        s = std::min(s, 64);
+        s = std::max(s, 1);
+    }
+    *splits = s;
+    *workspace_floats = (s > 1) ? (size_t)s * p->N * p->OH * p->OW * p->Cout : 0;
+    return IGAN_OK;
+}
+
+extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
+    using namespace igan;
+    hipStream_t stream = (hipStream_t)stream_;
+    IGAN_REQUIRE(p != nullptr, "conv2d: null params");
+    if (int rc = fwd_geometry_check(p)) return rc;
+    const int splits = std::max(1, p->splits);
+    const size_t out_elems = (size_t)p->N * p->OH * p->OW * p->Cout;
+    if (splits > 1) {
+        IGAN_REQUIRE(p->workspace != nullptr, "conv2d: splits > 1 needs a workspace");
+        IGAN_REQUIRE(p->workspace_floats >= (size_t)splits * out_elems, "conv2d: workspace too small");
+        IGAN_REQUIRE((long long)splits * (long long)out_elems <= INT32_MAX, "conv2d: split workspace too large");
+    }
+    int Mmax, chunks_max, nclass;
+    fwd_counts(p, Mmax, chunks_max, nclass);
+    const FwdTile t = pick_fwd_tile(Mmax, p->Cout);
+
+    ConvArgs a;
+    a.x = p->x; a.w = p->w;
+    a.y = (splits > 1) ? p->workspace : p->y;
+    a.in_scale = p->in_scale; a.out_scale = p->out_scale;
+    a.N = p->N; a.H = p->H; a.W = p->W; a.Cin = p->Cin;
+    a.OH = p->OH; a.OW = p->OW; a.Cout = p->Cout;
+    a.KH = p->KH; a.KW = p->KW;
+    a.stride = p->stride; a.up_shift = (p->up == 2) ? 1 : 0;
+    a.pad_y = p->pad_y; a.pad_x = p->pad_x;
+    a.splits = splits;
+    a.cpt = ceil_div(p->Cin, BK);
+    a.Mtot = p->N * p->OH * p->OW;
+    a.vecA = (p->Cin % 4 == 0) && (((uintptr_t)p->x & 15) == 0);
+    a.vecS = (p->Cin % 4 == 0) && (((uintptr_t)p->in_scale & 15) == 0);
+    if (p->w_transposed) a.vecB = (p->Cin % 4 == 0) && (((uintptr_t)p->w & 15) == 0);
+    else a.vecB = (p->Cout % 4 == 0) && (((uintptr_t)p->w & 15) == 0);
+
+    dim3 grid(ceil_div(Mmax, t.BM), ceil_div(p->Cout, t.BN), nclass * splits);
+    const bool wt = p->w_transposed != 0;
+    if (t.BM == 128 && t.BN == 128) launch_fwd<128, 128, 2, 2>(stream, a, grid, wt);
+    else if (t.BM == 128 && t.BN == 64) launch_fwd<128, 64, 2, 2>(stream, a, grid, wt);
+    else if (t.BM == 128 && t.BN == 32) launch_fwd<128, 32, 4, 1>(stream, a, grid, wt);
+    else launch_fwd<32, 128, 1, 4>(stream, a, grid, wt);
+    IGAN_LAUNCH_CHECK("conv2d launch");
+
+    if (splits > 1) {
+        const int total = (int)out_elems;
+        const int rg = std::min(ceil_div(total, 256), 2048);
+        hipLaunchKernelGGL(conv_reduce_kernel, dim3(rg), dim3(256), 0, stream,
+                           (const float*)p->workspace, p->y, p->out_scale, total, splits, p->Cout, p->OH * p->OW);
+        IGAN_LAUNCH_CHECK("conv2d reduce launch");
+    }
+    return IGAN_OK;
+}
+
+namespace {
+
+int wgrad_geometry_check(const igan_conv2d_wgrad_params* p) {
+    IGAN_REQUIRE(p->x && p->dy && p->dw, "conv2d_wgrad: null buffer");
+    IGAN_REQUIRE(p->N >= 1 && p->H >= 1 && p->W >= 1 && p->Cin >= 1, "conv2d_wgrad: input dims must be positive");
+    IGAN_REQUIRE(p->OH >= 1 && p->OW >= 1 && p->Cout >= 1, "conv2d_wgrad: output dims must be positive");
+    IGAN_REQUIRE(p->KH >= 1 && p->KW >= 1, "conv2d_wgrad: kernel must be at least 1x1");
+    IGAN_REQUIRE(p->stride >= 1 && p->up >= 1, "conv2d_wgrad: stride and up must be at least 1");
+    IGAN_REQUIRE(p->stride == 1 || p->up == 1, "conv2d_wgrad: at most one of stride, up may exceed 1");
+    if (!(p->up == 1 || p->up == 2)) return igan::fail(IGAN_ERR_UNSUPPORTED, "conv2d_wgrad: up must be 1 or 2 (got %d)", p->up);
+    IGAN_REQUIRE((long long)p->N * p->H * p->W * p->Cin <= INT32_MAX, "conv2d_wgrad: input too large");
+    IGAN_REQUIRE((long long)p->N * p->OH * p->OW * p->Cout <= INT32_MAX, "conv2d_wgrad: output too large");
+    IGAN_REQUIRE((long long)p->KH * p->KW * p->Cin * p->Cout <= INT32_MAX, "conv2d_wgrad: filter too large");
+    return IGAN_OK;
+}
+
+struct WgTile { int BM, BN; };
+WgTile pick_wg_tile(int Cin, int Cout) {
+    WgTile t;
+    t.BM = (Cin > 32) ? 128 : 32;
+    t.BN = (Cout > 32) ? 128 : 32;
+    if (t.BM == 32 && t.BN == 32) t.BN = 128;  // only three instantiations exist
+    return t;
+}
+
+int wgrad_splits(const igan_conv2d_wgrad_params* p) {
+    const WgTile t = pick_wg_tile(p->Cin, p->Cout);
+    const long long tiles = (long long)igan::ceil_div(p->Cin, t.BM) * igan::ceil_div(p->Cout, t.BN) * p->KH * p->KW;
+    const int up = p->up;
+    const long long kpix = (long long)p->N * ((p->OH + up - 1) / up) * ((p->OW + up - 1) / up);
+    const int chunks = (int)((kpix + BK - 1) / BK);
+    int s = (int)((768 + tiles - 1) / tiles);
+    s = std::min(s, std::max(1, chunks / 4));
+    s = std::min(s, 256);
+    return std::max(s, 1);
+}
+
+}  // namespace
+
+extern "C" int igan_conv2d_wgrad_plan(const igan_conv2d_wgrad_params* p, int* splits, size_t* workspace_floats) {
+    IGAN_REQUIRE(p && splits && workspace_floats, "conv2d_wgrad_plan: null argument");
+    if (int rc = wgrad_geometry_check(p)) return rc;
+    const int s = wgrad_splits(p);
+    *splits = s;
+    *workspace_floats = (s > 1) ? (size_t)s * p->KH * p->KW * p->Cin * p->Cout : 0;
+    return IGAN_OK;
+}
+
+extern "C" int igan_conv2d_wgrad(igan_stream_t stream_, const igan_conv2d_wgrad_params* p) {
+    using namespace igan;
+    hipStream_t stream = (hipStream_t)stream_;
+    IGAN_REQUIRE(p != nullptr, "conv2d_wgrad: null params");
+    if (int rc = wgrad_geometry_check(p)) return rc;
+    const int splits = std::max(1, p->splits);
+    const size_t wsize = (size_t)p->KH * p->KW * p->Cin * p->Cout;
+    if (splits > 1) {
+        IGAN_REQUIRE(p->workspace != nullptr, "conv2d_wgrad: splits > 1 needs a workspace");
+        IGAN_REQUIRE(p->workspace_floats >= (size_t)splits * wsize, "conv2d_wgrad: workspace too small");
+    }
+    WgradArgs a;
+    a.x = p->x; a.dy = p->dy;
+    a.out = (splits > 1) ? p->workspace : p->dw;
+    a.in_scale = p->in_scale; a.out_scale = p->out_scale;
+    a.N = p->N; a.H = p->H; a.W = p->W; a.Cin = p->Cin;
+    a.OH = p->OH; a.OW = p->OW; a.Cout = p->Cout;
+    a.KH = p->KH; a.KW = p->KW;
+    a.stride = p->stride; a.up_shift = (p->up == 2) ? 1 : 0;
+    a.pad_y = p->pad_y; a.pad_x = p->pad_x;
+    a.splits = splits;
+    a.vecA = (p->Cin % 4 == 0) && (((uintptr_t)p->x & 15) == 0);
+    a.vecB = (p->Cout % 4 == 0) && (((uintptr_t)p->dy & 15) == 0);
+    a.vecSA = (p->Cin % 4 == 0) && (((uintptr_t)p->in_scale & 15) == 0);
+    a.vecSB = (p->Cout % 4 == 0) && (((uintptr_t)p->out_scale & 15) == 0);
+
+    const WgTile t = pick_wg_tile(p->Cin, p->Cout);
+    dim3 grid(ceil_div(p->Cin, t.BM), ceil_div(p->Cout, t.BN), p->KH * p->KW * splits);
+    if (t.BM == 128 && t.BN == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2>), grid, dim3(256), 0, stream, a);
+    else if (t.BM == 128 && t.BN == 32) hipLaunchKernelGGL((conv_wgrad_kernel<128, 32, 4, 1>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 4>), grid, dim3(256), 0, stream, a);
+    IGAN_LAUNCH_CHECK("conv2d_wgrad launch");
+    if (splits > 1) {
+        const int total = (int)wsize;
+        const int rg = std::min(ceil_div(total, 256), 2048);
+        hipLaunchKernelGGL(plain_reduce_kernel, dim3(rg), dim3(256), 0, stream, (const float*)p->workspace, p->dw, total, splits);
+        IGAN_LAUNCH_CHECK("conv2d_wgrad reduce launch");
+    }
+    return IGAN_OK;
+}

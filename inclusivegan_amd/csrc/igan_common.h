@@ -1,0 +1,35 @@
+// Shared host-side helpers for libigan_hip.so (error reporting, launch checks).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdint>
+#include "../../include/igan_hip.h"
+
+namespace igan {
+
+// Thread-local message buffer behind igan_last_error(); the reference surfaces the
+// same information through tensorflow::Status (upfirdn_2d.cu:20,228-229).
+char* error_buffer();
+int fail(int code, const char* fmt, ...);
+
+inline int check_hip(hipError_t e, const char* what) {
+    if (e == hipSuccess) return IGAN_OK;
+    return fail(IGAN_ERR_HIP, "%s: %s", what, hipGetErrorName(e));
+}
+
+#define IGAN_REQUIRE(cond, ...)                                   \
+    do {                                                          \
+        if (!(cond)) return ::igan::fail(IGAN_ERR_INVALID_ARGUMENT, __VA_ARGS__); \
+    } while (0)
+
+#define IGAN_LAUNCH_CHECK(what)                                   \
+    do {                                                          \
+        hipError_t e__ = hipGetLastError();                       \
+        if (e__ != hipSuccess) return ::igan::check_hip(e__, what); \
+    } while (0)
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+inline long long ceil_div_ll(long long a, long long b) { return (a + b - 1) / b; }
+
+}  // namespace igan

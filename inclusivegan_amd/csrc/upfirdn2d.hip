@@ -1,0 +1,198 @@
+// upfirdn2d for gfx950: pad -> zero-insert upsample -> FIR -> decimate on
+// channel-minor tensors [majorDim, inH, inW, minorDim].
+//
+// Behavioural contract: dnnlib/tflib/ops/upfirdn_2d.cu:64-117 (index math of the
+// general kernel) and :232-307 (argument checks, output size).  The design is not
+// the reference's: the reference runs with minorDim == 1 (NCHW reshaped to
+// [N*C,H,W,1], upfirdn_2d.py:357-361) and stages one channel plane per block in
+// shared memory.  Here the channel axis is minor and contiguous, so the hot case
+// (up = down = 1, <= 4x4 taps: every conv pre/post filter of G and D and their
+// gradients) is a pure HBM stream: each lane owns a float4 of channels and a
+// vertical strip of TY output rows, keeps the TY partial sums in registers and
+// reads each input row of its column window exactly once (4 x 16 B loads per row,
+// horizontally adjacent lanes share them through L1).  A wave covers 64
+// consecutive float4 = 1 KiB of one or more adjacent pixels, so global loads and
+// stores are fully coalesced.
+#include "igan_common.h"
+
+namespace {
+
+struct FirTaps {
+    float k[64];  // flipped taps, row-major [kernelH][kernelW] (or 4x4 zero-extended)
+};
+
+struct UpfirdnArgs {
+    const float* x;
+    float* y;
+    int upx, upy, downx, downy;
+    int padx0, pady0;
+    int majorDim, inH, inW, minorDim;
+    int kernelH, kernelW;
+    int outH, outW;
+};
+
+__host__ __device__ __forceinline__ int floor_div(int a, int b) {
+    int c = a / b;
+    if (c * b > a) c--;
+    return c;
+}
+
+// General path: one thread per output element, channel index fastest.
+// Same receptive-field arithmetic as upfirdn_2d.cu:76-90.
+__global__ __launch_bounds__(256) void upfirdn2d_generic_kernel(UpfirdnArgs a, FirTaps taps) {
+    const long long total = (long long)a.majorDim * a.outH * a.outW * a.minorDim;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        long long t = idx;
+        const int c = (int)(t % a.minorDim); t /= a.minorDim;
+        const int ox = (int)(t % a.outW);    t /= a.outW;
+        const int oy = (int)(t % a.outH);    t /= a.outH;
+        const int m = (int)t;
+
+        const int midY = oy * a.downy + a.upy - 1 - a.pady0;
+        const int inY = min(max(floor_div(midY, a.upy), 0), a.inH);
+        const int h = min(max(floor_div(midY + a.kernelH, a.upy), 0), a.inH) - inY;
+        const int kernelY = midY + a.kernelH - (inY + 1) * a.upy;
+
+        const int midX = ox * a.downx + a.upx - 1 - a.padx0;
+        const int inX = min(max(floor_div(midX, a.upx), 0), a.inW);
+        const int w = min(max(floor_div(midX + a.kernelW, a.upx), 0), a.inW) - inX;
+        const int kernelX = midX + a.kernelW - (inX + 1) * a.upx;
+
+        // taps.k holds the FLIPPED filter; the reference walks the unflipped one
+        // backwards (kp += -upx), i.e. k[kernelY - y*upy][kernelX - x*upx].
+        float v = 0.0f;
+        for (int yy = 0; yy < h; yy++) {
+            const int ky = kernelY - yy * a.upy;  // index into the unflipped filter
+            const float* xrow = a.x + (((long long)m * a.inH + inY + yy) * a.inW + inX) * a.minorDim + c;
+            for (int xx = 0; xx < w; xx++) {
+                const int kx = kernelX - xx * a.upx;
+                const float kv = taps.k[(a.kernelH - 1 - ky) * a.kernelW + (a.kernelW - 1 - kx)];
+                v += xrow[(long long)xx * a.minorDim] * kv;
+            }
+        }
+        a.y[idx] = v;
+    }
+}
+
+// Fast path: up = down = 1, taps zero-extended to 4x4, minorDim % 4 == 0.
+//   y[m,oy,ox,c] = sum_{ky,kx<4} x[m, oy+ky-pady0, ox+kx-padx0, c] * kf[ky][kx]
+template <int TY>
+__global__ __launch_bounds__(256) void upfirdn2d_fir4_kernel(UpfirdnArgs a, FirTaps taps) {
+    const int cvecs = a.minorDim >> 2;
+    const int strips = (a.outH + TY - 1) / TY;
+    const long long total = (long long)a.majorDim * strips * a.outW * cvecs;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    long long t = idx;
+    const int cv = (int)(t % cvecs); t /= cvecs;
+    const int ox = (int)(t % a.outW); t /= a.outW;
+    const int strip = (int)(t % strips); t /= strips;
+    const int m = (int)t;
+    const int oy0 = strip * TY;
+
+    float4 acc[TY];
+#pragma unroll
+    for (int i = 0; i < TY; i++) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const int ix0 = ox - a.padx0;
+    const float4* xbase = reinterpret_cast<const float4*>(a.x) + (long long)m * a.inH * a.inW * cvecs + cv;
+
+#pragma unroll
+    for (int r = 0; r < TY + 3; r++) {
+        const int iy = oy0 + r - a.pady0;
+        float4 v[4];
+        const bool rowok = (iy >= 0) & (iy < a.inH);
+#pragma unroll
+        for (int kx = 0; kx < 4; kx++) {
+            const int ix = ix0 + kx;
+            const bool ok = rowok & (ix >= 0) & (ix < a.inW);
+            v[kx] = ok ? xbase[((long long)iy * a.inW + ix) * cvecs] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int ky = 0; ky < 4; ky++) {
+            const int o = r - ky;  // output row (relative) fed by this input row via tap ky
+            if (o >= 0 && o < TY) {
+#pragma unroll
+                for (int kx = 0; kx < 4; kx++) {
+                    const float kv = taps.k[ky * 4 + kx];
+                    acc[o].x += v[kx].x * kv;
+                    acc[o].y += v[kx].y * kv;
+                    acc[o].z += v[kx].z * kv;
+                    acc[o].w += v[kx].w * kv;
+                }
+            }
+        }
+    }
+
+    float4* ybase = reinterpret_cast<float4*>(a.y) + (long long)m * a.outH * a.outW * cvecs + cv;
+#pragma unroll
+    for (int i = 0; i < TY; i++) {
+        const int oy = oy0 + i;
+        if (oy < a.outH) ybase[((long long)oy * a.outW + ox) * cvecs] = acc[i];
+    }
+}
+
+}  // namespace
+
+extern "C" int igan_upfirdn2d(igan_stream_t stream_, const igan_upfirdn2d_params* p) {
+    using namespace igan;
+    hipStream_t stream = (hipStream_t)stream_;
+    IGAN_REQUIRE(p != nullptr, "upfirdn2d: null params");
+    IGAN_REQUIRE(p->x && p->k && p->y, "upfirdn2d: null buffer");
+    // upfirdn_2d.cu:228-229
+    IGAN_REQUIRE(p->upx >= 1 && p->upy >= 1, "upx and upy must be at least 1x1");
+    IGAN_REQUIRE(p->downx >= 1 && p->downy >= 1, "downx and downy must be at least 1x1");
+    // upfirdn_2d.cu:252
+    IGAN_REQUIRE(p->kernelW >= 1 && p->kernelH >= 1, "kernel must be at least 1x1");
+    IGAN_REQUIRE(p->kernelW * p->kernelH <= 64, "kernel too large (max 64 taps)");
+    IGAN_REQUIRE(p->majorDim >= 1 && p->inH >= 1 && p->inW >= 1 && p->minorDim >= 1, "input must have rank 4 with positive dims");
+    // upfirdn_2d.cu:254-256
+    const int outW = (p->inW * p->upx + p->padx0 + p->padx1 - p->kernelW + p->downx) / p->downx;
+    const int outH = (p->inH * p->upy + p->pady0 + p->pady1 - p->kernelH + p->downy) / p->downy;
+    IGAN_REQUIRE(outW >= 1 && outH >= 1, "output must be at least 1x1");
+    IGAN_REQUIRE(outW == p->outW && outH == p->outH, "upfirdn2d: outH/outW (%d,%d) do not match derived (%d,%d)", p->outH, p->outW, outH, outW);
+    // upfirdn_2d.cu:243,266
+    const long long in_elems = (long long)p->majorDim * p->inH * p->inW * p->minorDim;
+    const long long out_elems = (long long)p->majorDim * outH * outW * p->minorDim;
+    IGAN_REQUIRE(in_elems <= INT32_MAX, "input too large");
+    IGAN_REQUIRE(out_elems <= INT32_MAX, "output too large");
+
+    UpfirdnArgs a;
+    a.x = p->x; a.y = p->y;
+    a.upx = p->upx; a.upy = p->upy; a.downx = p->downx; a.downy = p->downy;
+    a.padx0 = p->padx0; a.pady0 = p->pady0;
+    a.majorDim = p->majorDim; a.inH = p->inH; a.inW = p->inW; a.minorDim = p->minorDim;
+    a.kernelH = p->kernelH; a.kernelW = p->kernelW;
+    a.outH = outH; a.outW = outW;
+
+    const bool aligned = (((uintptr_t)p->x | (uintptr_t)p->y) & 15) == 0;
+    const bool fast = p->upx == 1 && p->upy == 1 && p->downx == 1 && p->downy == 1 &&
+                      p->kernelH <= 4 && p->kernelW <= 4 && (p->minorDim % 4) == 0 && aligned;
+    FirTaps taps;
+    for (int i = 0; i < 64; i++) taps.k[i] = 0.0f;
+    if (fast) {
+        // flipped taps, zero-extended to 4x4 (extra taps read padding-or-data times 0)
+        for (int ky = 0; ky < p->kernelH; ky++)
+            for (int kx = 0; kx < p->kernelW; kx++)
+                taps.k[ky * 4 + kx] = p->k[(p->kernelH - 1 - ky) * p->kernelW + (p->kernelW - 1 - kx)];
+        const int cvecs = p->minorDim / 4;
+        if (outH >= 8) {
+            const long long total = (long long)p->majorDim * ceil_div(outH, 8) * outW * cvecs;
+            const int grid = (int)ceil_div_ll(total, 256);
+            hipLaunchKernelGGL(upfirdn2d_fir4_kernel<8>, dim3(grid), dim3(256), 0, stream, a, taps);
+        } else {
+            const long long total = (long long)p->majorDim * ceil_div(outH, 2) * outW * cvecs;
+            const int grid = (int)ceil_div_ll(total, 256);
+            hipLaunchKernelGGL(upfirdn2d_fir4_kernel<2>, dim3(grid), dim3(256), 0, stream, a, taps);
+        }
+    } else {
+        for (int ky = 0; ky < p->kernelH; ky++)
+            for (int kx = 0; kx < p->kernelW; kx++)
+                taps.k[ky * p->kernelW + kx] = p->k[(p->kernelH - 1 - ky) * p->kernelW + (p->kernelW - 1 - kx)];
+        const int grid = (int)std::min<long long>(ceil_div_ll(out_elems, 256), 256 * 32);
+        hipLaunchKernelGGL(upfirdn2d_generic_kernel, dim3(grid), dim3(256), 0, stream, a, taps);
+    }
+    IGAN_LAUNCH_CHECK("upfirdn2d launch");
+    return IGAN_OK;
+}

@@ -1,0 +1,139 @@
+"""`DCI`: the nearest-neighbour index surface the training loop uses
+(`from dci import DCI`, training/training_loop.py:21-23,197,367-368,398), backed by the exact
+on-GPU streaming 1-NN instead of the reference's CPU Prioritized-DCI index.
+
+Kept from the reference's `dci_code/src/dci.py:61-340`:
+  * `DCI(dim, num_comp_indices, num_simp_indices)`; `add(data, ...)` (one array only, :261-262),
+    `query(query, num_neighbours, ...)` returning `(list of int32 index arrays, list of float64
+    distance arrays)` per query (:316-330), `reset()`, `clear()`, `num_points`, `dim`;
+  * distances are Euclidean (sqrt) like `compute_dist` (dci_code/src/util.c:62-69);
+  * NumPy input must be float64, C-contiguous, of the declared dimension (:113-121).
+The indexing hyper-parameters (num_levels, field_of_view, prop_to_retrieve, blind, ...) are accepted
+and ignored: the search is exact, so every reference setting maps to the same (best possible)
+answer.  Extension: `add` / `query` also accept device tensors, so candidates generated on the GPU
+never visit the host (the reference materialises a 118 GB fp64 array, training_loop.py:358).
+
+Only `num_neighbours == 1` (the default, non-exclusive IMLE assignment, training_loop.py:398) is
+built on the HIP path.
+"""
+import numpy as np
+import torch
+
+from .. import hip_ops
+
+
+class DCI(object):
+    def __init__(self, dim, num_comp_indices=2, num_simp_indices=7, device=None):
+        self._dim = int(dim)
+        self._num_comp_indices = num_comp_indices
+        self._num_simp_indices = num_simp_indices
+        if device is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError('inclusivegan_amd DCI needs a ROCm device; there is no CPU path')
+            device = torch.device('cuda', torch.cuda.current_device())
+        self.device = torch.device(device)
+        self._data = None
+        self._norms = None
+        self.cand_chunk = 8192      # candidates folded per kernel pass
+        self.query_chunk = 4096     # queries per kernel pass
+
+    @property
+    def dim(self):
+        return self._dim
+
+    @property
+    def num_comp_indices(self):
+        return self._num_comp_indices
+
+    @property
+    def num_simp_indices(self):
+        return self._num_simp_indices
+
+    @property
+    def num_points(self):
+        return 0 if self._data is None else int(self._data.shape[0])
+
+    @property
+    def num_levels(self):
+        return 0 if self._data is None else 1
+
+    def _check_numpy(self, arr):
+        if arr.ndim != 2 or arr.shape[1] != self.dim:
+            raise ValueError('mismatch between array dimension (%s) and the declared dimension of this DCI instance (%d)' % (arr.shape[1:] , self.dim))
+        if arr.dtype != np.float64:
+            raise TypeError('array must consist of double-precision floats')
+        if not arr.flags.c_contiguous:
+            raise ValueError('the memory layout of array must be in row-major (C-order)')
+
+    def _to_device(self, arr, check):
+        if torch.is_tensor(arr):
+            if arr.dim() != 2 or arr.shape[1] != self.dim:
+                raise ValueError('mismatch between array dimension (%s) and the declared dimension of this DCI instance (%d)' % (tuple(arr.shape[1:]), self.dim))
+            return arr.to(self.device, torch.float32).contiguous()
+        arr = np.asarray(arr)
+        if check:
+            self._check_numpy(arr)
+        elif arr.ndim != 2 or arr.shape[1] != self.dim:
+            raise ValueError('mismatch between array dimension (%s) and the declared dimension of this DCI instance (%d)' % (arr.shape[1:], self.dim))
+        out = torch.empty((arr.shape[0], self.dim), device=self.device, dtype=torch.float32)
+        step = max(1, (64 << 20) // (8 * self.dim))
+        for i in range(0, arr.shape[0], step):
+            out[i:i + step] = torch.from_numpy(np.ascontiguousarray(arr[i:i + step], dtype=np.float32)).to(self.device)
+        return out
+
+    def add(self, data, indices=None, num_levels=2, field_of_view=10, blind=False, num_to_visit=-1, num_to_retrieve=-1,
+            prop_to_visit=-1.0, prop_to_retrieve=-1.0):
+        if self.num_points > 0:
+            raise RuntimeError('DCI class does not support insertion of more than one array. Must combine all arrays into one array before inserting')
+        if indices is not None:
+            raise NotImplementedError('DCI.add(indices=...) is not built on the hip path')
+        self._data = self._to_device(data, check=True)
+        self._norms = hip_ops.row_sqnorm_raw(self._data)
+
+    def query(self, query, num_neighbours=-1, field_of_view=100, blind=False, num_to_visit=-1, num_to_retrieve=-1,
+              prop_to_visit=-1.0, prop_to_retrieve=-1.0):
+        if self._data is None:
+            raise RuntimeError('DCI.query() on an empty database')
+        if num_neighbours < 0:
+            num_neighbours = self.num_points
+        if num_neighbours != 1:
+            raise NotImplementedError('only num_neighbours=1 is built on the hip path (got %d)' % num_neighbours)
+        idx, dist = self.query_device(self._to_device(query, check=False))
+        idx = idx.cpu().numpy().astype(np.int32)
+        dist = dist.cpu().numpy().astype(np.float64)
+        return [idx[i:i + 1] for i in range(idx.shape[0])], [dist[i:i + 1] for i in range(dist.shape[0])]
+
+    def query_device(self, q):
+        """q: device fp32 [nq, dim] -> (int64 idx [nq], fp32 Euclidean dist [nq]) on the device."""
+        nq = int(q.shape[0])
+        best = torch.full((nq,), -1, device=self.device, dtype=torch.int64)   # 0xFFFF... as uint64
+        n = self.num_points
+        for q0 in range(0, nq, self.query_chunk):
+            qs = q[q0:q0 + self.query_chunk]
+            qn = hip_ops.row_sqnorm_raw(qs)
+            bs = best[q0:q0 + self.query_chunk]
+            for c0 in range(0, n, self.cand_chunk):
+                hip_ops.nn1_update_raw(qs, qn, self._data[c0:c0 + self.cand_chunk], self._norms[c0:c0 + self.cand_chunk], bs, c0)
+        return unpack_best(best)
+
+    def clear(self):
+        self._data = None
+        self._norms = None
+
+    def reset(self):
+        # The reference also re-draws its random projection directions here (dci.c:859-863); an exact
+        # search has none.
+        self.clear()
+
+
+def unpack_best(best):
+    """packed uint64 (as int64) -> (idx int64, Euclidean distance fp32)."""
+    idx = best & 0xFFFFFFFF
+    bits = (best >> 32) & 0xFFFFFFFF
+    d2 = _bits_to_float(bits)
+    return idx, torch.sqrt(d2)
+
+
+def _bits_to_float(bits):
+    # bits < 2^31 for non-negative floats, so the int64 -> int32 narrowing is exact
+    return bits.to(torch.int32).view(torch.float32)

@@ -1,0 +1,38 @@
+"""Running means of training scalars, standing in for `dnnlib/tflib/autosummary.py:45-74`
+(`autosummary(name, value)` accumulates [count, sum] and ignores non-finite values, :64).
+Accumulation happens on the device without host synchronisation; `flush()` (called once per tick,
+training_loop.py:523) reads the means back and resets."""
+from collections import OrderedDict
+
+import torch
+
+_acc = OrderedDict()   # name -> tensor [count, sum] (float64 on the value's device)
+
+
+def autosummary(name, value):
+    """Record `value` (python scalar or tensor of any shape) and pass it through."""
+    if torch.is_tensor(value):
+        v = value.detach().to(torch.float64).reshape(-1)
+        ok = torch.isfinite(v)
+        cnt = ok.sum().to(torch.float64)
+        tot = torch.where(ok, v, torch.zeros_like(v)).sum()
+        upd = torch.stack([cnt, tot])
+        if name in _acc and _acc[name].device == upd.device:
+            _acc[name] += upd
+        else:
+            _acc[name] = upd
+    else:
+        v = float(value)
+        upd = torch.tensor([1.0, v], dtype=torch.float64)
+        _acc[name] = _acc[name] + upd if name in _acc and _acc[name].device == upd.device else upd
+    return value
+
+
+def flush():
+    """-> OrderedDict name -> mean; resets the accumulators."""
+    out = OrderedDict()
+    for name, t in _acc.items():
+        c, s = t.cpu().tolist()
+        out[name] = s / c if c > 0 else float('nan')
+    _acc.clear()
+    return out

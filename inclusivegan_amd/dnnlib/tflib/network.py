@@ -1,0 +1,290 @@
+"""`Network`: the object model the reference's training code programs against
+(dnnlib/tflib/network.py:35-590), restated for eager PyTorch-ROCm.
+
+Kept semantics (the parts the hot path touches):
+  * construction from a build function given by object or dotted name (`func_name`), static kwargs
+    remembered and merged with per-call dynamic kwargs (network.py:84-123,199-232);
+  * `vars` / `trainables`: ordered dicts keyed by the reference's *local variable names*
+    (e.g. 'G_synthesis/64x64/Conv0_up/mod_weight', network.py:181-185) in creation order;
+  * sub-networks created inside a build function become `components` whose variables appear in the
+    parent under '<component name>/...' (network.py:125-185);
+  * `get_output_for`, `clone`, `copy_vars_from`, `setup_as_moving_average_of`, `run`,
+    `input_shapes` / `output_shapes`.
+Dropped: TF graph/session mechanics, pickling of build-module source, weight histograms.
+
+MI355X-specific design: all trainables of a top-level network are views into ONE contiguous fp32
+bucket (`flat_params`, every tensor 16-byte aligned) with a matching gradient bucket
+(`flat_grads`), so that the data-parallel exchange is a single RCCL all-reduce and Adam / EMA /
+finite-check are single streaming kernels (optimizer.py) instead of the reference's one NCCL call
+and one Adam chain per variable (dnnlib/tflib/optimizer.py:193-201,237-239).
+"""
+import inspect
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from .. import util
+from ..util import EasyDict
+from . import tfutil
+from ... import hip_ops
+
+_ALIGN = 4  # floats (16 bytes)
+
+
+def _resolve(func_name):
+    if callable(func_name):
+        return func_name
+    return util.get_obj_by_name(func_name)
+
+
+class Network:
+    def __init__(self, name=None, func_name=None, device=None, seed=0, **static_kwargs):
+        assert isinstance(name, str) or name is None
+        assert func_name is not None
+        self.name = name or 'net'
+        self.static_kwargs = EasyDict(static_kwargs)
+        self._build_func = _resolve(func_name)
+        self._build_func_name = func_name if isinstance(func_name, str) else getattr(func_name, '__name__', str(func_name))
+        self.components = EasyDict()
+        self.seed = seed
+
+        # Nested construction (inside a parent's build function) => component of that parent.
+        parent = tfutil._stack().store
+        if parent is not None:
+            self._root = parent._root
+            self._prefix = parent._prefix + self.name + '/'
+            self.device = self._root.device
+        else:
+            self._root = self
+            self._prefix = ''
+            if device is None:
+                if not torch.cuda.is_available():
+                    raise RuntimeError('inclusivegan_amd.Network needs a ROCm device (or device="meta"/"cpu" for shape-only / host-side use)')
+                device = torch.device('cuda', torch.cuda.current_device())
+            self.device = torch.device(device)
+            self._specs = OrderedDict()   # full name -> (shape, initializer, trainable)
+            self._store = OrderedDict()   # full name -> tensor (after materialisation)
+            self._templating = True
+            self.flat_params = None
+            self.flat_grads = None
+
+        # Template pass on the meta device: creates variable specs, infers shapes.
+        self.input_names = [p.name for p in inspect.signature(self._build_func).parameters.values()
+                            if p.kind == p.POSITIONAL_OR_KEYWORD and p.default is p.empty]
+        templ = [torch.empty(self._template_shape(n), device='meta') for n in self.input_names]
+        was_templating = self._root._templating
+        self._root._templating = True
+        with tfutil.variable_store(self), torch.no_grad():
+            out = self._build_func(*templ, is_template_graph=True, components=self.components, **self.static_kwargs)
+        self._root._templating = was_templating if parent is not None else False
+        outs = list(out) if isinstance(out, (tuple, list)) else [out]
+        self.input_shapes = [[None] + list(t.shape[1:]) for t in templ]
+        self.output_shapes = [([None] + list(t.shape[1:])) if t is not None else None for t in outs]
+        self.input_shape = self.input_shapes[0]
+        self.output_shape = self.output_shapes[0]
+        self.num_inputs = len(self.input_shapes)
+        self.num_outputs = len(self.output_shapes)
+
+        if parent is None:
+            self._materialize()
+
+    # ------------------------------------------------------------------
+    def _template_shape(self, arg_name):
+        kw = self.static_kwargs
+        if arg_name == 'latents_in':
+            return (1, kw.get('latent_size', 512))
+        if arg_name == 'labels_in':
+            return (1, kw.get('label_size', 0))
+        if arg_name == 'images_in':
+            r = kw.get('resolution', 1024)
+            return (1, kw.get('num_channels', 3), r, r)
+        if arg_name == 'dlatents_in':
+            r = kw.get('resolution', 1024)
+            return (1, int(np.log2(r)) * 2 - 2, kw.get('dlatent_size', 512))
+        if arg_name in ('images_a', 'images_b'):
+            r = kw.get('resolution', 64)
+            return (1, 3, r, r)
+        raise ValueError('Network: do not know the template shape of input %r' % arg_name)
+
+    # variable access (called through tfutil.get_variable) -----------------
+    def _get_variable(self, local_name, shape, initializer, trainable):
+        root = self._root
+        full = self._prefix + local_name
+        if full in root._specs:
+            if root._templating or root._store.get(full) is None:
+                return torch.empty(root._specs[full][0], device='meta')
+            return root._store[full]
+        if not root._templating:
+            raise KeyError('variable %r does not exist in network %r' % (full, root.name))
+        shape = tuple(int(s) for s in (shape if shape is not None else ()))
+        root._specs[full] = (shape, initializer or ('zeros',), bool(trainable))
+        return torch.empty(shape, device='meta')
+
+    def _materialize(self):
+        """Allocate the flat buckets and initialise every variable (seeded NumPy stream, so all
+        ranks / devices start bit-identical, like the reference's towers: optimizer.py:204-239)."""
+        dev = self.device
+        offsets = OrderedDict()
+        total = 0
+        for name, (shape, init, trainable) in self._specs.items():
+            if trainable:
+                n = int(np.prod(shape)) if len(shape) else 1
+                offsets[name] = (total, n)
+                total += (n + _ALIGN - 1) // _ALIGN * _ALIGN
+        self._offsets = offsets
+        self._flat_size = total
+        if dev.type == 'meta':
+            self.flat_params = torch.empty((total,), device='meta')
+            self.flat_grads = torch.empty((total,), device='meta')
+            for name, (shape, init, trainable) in self._specs.items():
+                self._store[name] = torch.empty(shape, device='meta')
+            self._index()
+            return
+        rng = np.random.RandomState(self.seed)
+        flat = np.zeros((total,), dtype=np.float32)
+        others = OrderedDict()
+        for name, (shape, init, trainable) in self._specs.items():
+            kind = init[0]
+            if kind == 'zeros':
+                val = np.zeros(shape, dtype=np.float32)
+            elif kind == 'normal':
+                val = (rng.standard_normal(shape) * init[1]).astype(np.float32)
+            elif kind == 'const':
+                val = np.full(shape, init[1], dtype=np.float32)
+            else:
+                raise ValueError('unknown initializer %r' % (init,))
+            if trainable:
+                off, n = offsets[name]
+                flat[off:off + n] = val.reshape(-1)
+            else:
+                others[name] = val
+        self.flat_params = torch.from_numpy(flat).to(dev)
+        self.flat_grads = torch.zeros_like(self.flat_params)
+        for name, (shape, init, trainable) in self._specs.items():
+            if trainable:
+                off, n = offsets[name]
+                p = self.flat_params[off:off + n].view(shape)
+                p.requires_grad_(True)
+                p.grad = self.flat_grads[off:off + n].view(shape)
+                self._store[name] = p
+            else:
+                self._store[name] = torch.from_numpy(others[name]).to(dev)
+        self._index()
+
+    def _index(self):
+        self.vars = OrderedDict(self._store)
+        self.trainables = OrderedDict((n, v) for n, v in self._store.items() if self._specs[n][2])
+        self._index_components(self)
+
+    def _index_components(self, net):
+        for comp in net.components.values():
+            if isinstance(comp, Network):
+                pre = comp._prefix
+                comp.vars = OrderedDict((n[len(pre):], v) for n, v in self._store.items() if n.startswith(pre))
+                comp.trainables = OrderedDict((n[len(pre):], v) for n, v in self._store.items()
+                                              if n.startswith(pre) and self._specs[n][2])
+                self._index_components(comp)
+
+    # ------------------------------------------------------------------
+    def get_output_for(self, *in_expr, return_as_list=False, **dynamic_kwargs):
+        """Run the build function on the given tensors (network.py:199-232)."""
+        assert len(in_expr) == self.num_inputs
+        build_kwargs = dict(self.static_kwargs)
+        build_kwargs.update(dynamic_kwargs)
+        build_kwargs['is_template_graph'] = False
+        build_kwargs['components'] = self.components
+        with tfutil.variable_store(self):
+            out = self._build_func(*in_expr, **build_kwargs)
+        if isinstance(out, (tuple, list)):
+            return list(out) if return_as_list else tuple(out)
+        return [out] if return_as_list else out
+
+    def requires_grad_(self, flag):
+        """Freeze / unfreeze every trainable (the reference gets the same effect by registering
+        gradients only w.r.t. one network's trainables, training_loop.py:288-291)."""
+        assert self._root is self
+        for v in self.trainables.values():
+            v.requires_grad_(flag)
+        return self
+
+    def get_var(self, name):
+        return self.vars[name]
+
+    def num_params(self):
+        return sum(int(np.prod(v.shape)) if v.dim() else 1 for v in self.trainables.values())
+
+    def zero_grad(self):
+        self.flat_grads.zero_()
+
+    def copy_vars_from(self, src):
+        assert self._root is self and src._root is src
+        same = list(self._offsets.items()) == list(src._offsets.items())
+        with torch.no_grad():
+            if same:
+                self.flat_params.copy_(src.flat_params)
+            for name, var in self.vars.items():
+                if name in src.vars and (not same or not self._specs[name][2]):
+                    var.copy_(src.vars[name])
+
+    def clone(self, name=None, **new_static_kwargs):
+        """network.py:301-314: same build function, same variable values."""
+        static_kwargs = dict(self.static_kwargs)
+        static_kwargs.update(new_static_kwargs)
+        net = Network(name=name or self.name, func_name=self._build_func, device=self.device, seed=self.seed, **static_kwargs)
+        net.copy_vars_from(self)
+        return net
+
+    def setup_as_moving_average_of(self, src_net, beta=0.99, beta_nontrainable=0.0):
+        """Returns a callable that moves this network's variables towards `src_net`'s:
+        var <- lerp(src, var, beta) for trainables, beta_nontrainable otherwise (network.py:341-351).
+        `beta` may be a float or a zero-arg callable evaluated at each call."""
+        assert self._root is self and src_net._root is src_net
+        assert list(self._offsets) == list(src_net._offsets)
+
+        def update_op():
+            b = beta() if callable(beta) else beta
+            with torch.no_grad():
+                hip_ops.ema_raw(self.flat_params, src_net.flat_params, b)
+                for name, var in self.vars.items():
+                    if name in src_net.vars and not self._specs[name][2]:
+                        if beta_nontrainable == 0.0:
+                            var.copy_(src_net.vars[name])
+                        else:
+                            var.copy_(tfutil.lerp(src_net.vars[name], var, beta_nontrainable))
+        return update_op
+
+    def run(self, *in_arrays, minibatch_size=None, num_gpus=1, return_as_list=False, **dynamic_kwargs):
+        """NumPy in, NumPy out, evaluated in minibatches without gradients (network.py:353-453)."""
+        assert len(in_arrays) == self.num_inputs
+        num_items = in_arrays[0].shape[0]
+        if minibatch_size is None:
+            minibatch_size = num_items
+        outs = None
+        with torch.no_grad():
+            for begin in range(0, num_items, minibatch_size):
+                end = min(begin + minibatch_size, num_items)
+                ins = [torch.as_tensor(np.asarray(a[begin:end], dtype=np.float32)).to(self.device) for a in in_arrays]
+                mb = self.get_output_for(*ins, return_as_list=True, **dynamic_kwargs)
+                mb = [t.contiguous().cpu().numpy() for t in mb]
+                if outs is None:
+                    outs = [np.empty([num_items] + list(o.shape[1:]), dtype=o.dtype) for o in mb]
+                for dst, o in zip(outs, mb):
+                    dst[begin:end] = o
+        if not return_as_list:
+            outs = outs[0] if len(outs) == 1 else tuple(outs)
+        return outs
+
+    def print_layers(self, title=None):
+        rows = [[title or self.name, 'Params', 'Shape']]
+        total = 0
+        for name, v in self.trainables.items():
+            n = int(np.prod(v.shape)) if v.dim() else 1
+            total += n
+            rows.append([name, str(n), str(tuple(v.shape))])
+        rows.append(['Total', str(total), ''])
+        widths = [max(len(r[i]) for r in rows) for i in range(3)]
+        print()
+        for r in rows:
+            print('  '.join(c + ' ' * (w - len(c)) for c, w in zip(r, widths)))
+        print()

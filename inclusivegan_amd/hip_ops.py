@@ -1,0 +1,558 @@
+"""Tensor-level entry to the C ABI plus the autograd closures around it.
+
+Two layers:
+
+* ``*_raw`` functions: take torch (ROCm) tensors, allocate outputs / workspaces
+  from torch's caching allocator, pass raw pointers + the current HIP stream to
+  ``libigan_hip.so``.  No autograd, no host synchronisation (graph-capturable).
+* ``torch.autograd.Function`` closures with the same differentiation structure as
+  the reference's ``tf.custom_gradient`` closures:
+    - upfirdn_2d: backward is the same op with (up<->down), flipped taps and
+      ``gpad*`` (dnnlib/tflib/ops/upfirdn_2d.py:123-139) -> closed under
+      differentiation, arbitrary order;
+    - fused_bias_act: ``grad=1`` kernel with ``ref`` + bias reduction, second
+      order through the same ``grad=1`` kernel for piecewise-linear activations
+      (dnnlib/tflib/ops/fused_bias_act.py:126-172);
+    - conv2d / its data gradient / its weight gradient form a closed triple
+      (conv is bilinear), which is what ``tf.gradients`` of ``tf.nn.conv2d`` /
+      ``conv2d_transpose`` gives the reference for R1 and path-length
+      regularisation (training/loss.py:64-66,107-111).
+
+All activations are fp32.  4-D activations are logical NCHW with
+``torch.channels_last`` strides, i.e. physically [N, H, W, C].
+"""
+import ctypes
+from collections import namedtuple
+
+import numpy as np
+import torch
+
+from . import _abi
+
+CL = torch.channels_last
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _require_cuda_f32(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError('inclusivegan_amd kernels need tensors on a ROCm device (got %s); there is no CPU path' % t.device)
+        if t.dtype != torch.float32:
+            raise TypeError('inclusivegan_amd kernels are fp32 (got %s)' % t.dtype)
+
+
+def _is_meta(t):
+    """Shape-only dry runs (Network template pass) use the meta device and never reach a kernel."""
+    return t.device.type == 'meta'
+
+
+def nhwc(x):
+    """Logical NCHW tensor -> same tensor, physically [N,H,W,C] dense."""
+    return x.contiguous(memory_format=CL)
+
+
+def empty_nchw(n, c, h, w, like):
+    return torch.empty((n, c, h, w), device=like.device, dtype=torch.float32, memory_format=CL)
+
+
+# ----------------------------------------------------------------------------
+# upfirdn2d
+
+def upfirdn2d_raw(x, k, upx, upy, downx, downy, padx0, padx1, pady0, pady1):
+    """x: [majorDim, inH, inW, minorDim] dense.  k: host float32 [kH, kW]."""
+    k = np.ascontiguousarray(k, dtype=np.float32)
+    if k.ndim != 2:
+        raise ValueError('kernel must have rank 2')
+    if x.dim() != 4:
+        raise ValueError('input must have rank 4')
+    major, in_h, in_w, minor = x.shape
+    kh, kw = k.shape
+    out_w = (in_w * upx + padx0 + padx1 - kw + downx) // downx
+    out_h = (in_h * upy + pady0 + pady1 - kh + downy) // downy
+    if out_w < 1 or out_h < 1:
+        raise ValueError('output must be at least 1x1')
+    if _is_meta(x):
+        return torch.empty((major, out_h, out_w, minor), device='meta')
+    lib = _abi.get_plugin()
+    _require_cuda_f32(x)
+    x = x.contiguous()
+    y = torch.empty((major, out_h, out_w, minor), device=x.device, dtype=torch.float32)
+    p = _abi.UpFirDn2DParams(
+        x=x.data_ptr(), k=k.ctypes.data, y=y.data_ptr(),
+        upx=upx, upy=upy, downx=downx, downy=downy,
+        padx0=padx0, padx1=padx1, pady0=pady0, pady1=pady1,
+        majorDim=major, inH=in_h, inW=in_w, minorDim=minor,
+        kernelH=kh, kernelW=kw, outH=out_h, outW=out_w)
+    _abi.check(lib.igan_upfirdn2d(_stream(), ctypes.byref(p)))
+    return y
+
+
+class UpFirDn2dFn(torch.autograd.Function):
+    """upfirdn_2d.py:130-140: y = op(x; k, up, down, pad); grad = op(dy; flip(k), down, up, gpad)."""
+
+    @staticmethod
+    def forward(ctx, x, k, upx, upy, downx, downy, padx0, padx1, pady0, pady1):
+        k = np.asarray(k, dtype=np.float32)
+        in_h, in_w = x.shape[1], x.shape[2]
+        y = upfirdn2d_raw(x, k, upx, upy, downx, downy, padx0, padx1, pady0, pady1)
+        out_h, out_w = y.shape[1], y.shape[2]
+        kh, kw = k.shape
+        # upfirdn_2d.py:125-128
+        gpadx0 = kw - padx0 - 1
+        gpady0 = kh - pady0 - 1
+        gpadx1 = in_w * upx - out_w * downx + padx0 - upx + 1
+        gpady1 = in_h * upy - out_h * downy + pady0 - upy + 1
+        ctx.gargs = (np.ascontiguousarray(k[::-1, ::-1]), downx, downy, upx, upy, gpadx0, gpadx1, gpady0, gpady1)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx = UpFirDn2dFn.apply(dy, *ctx.gargs)
+        return (dx,) + (None,) * 9
+
+
+# ----------------------------------------------------------------------------
+# fused_bias_act
+
+def _bias_layout(x, axis):
+    """Returns (x_dense, sizeB, stepB) for a bias along `axis` given x's physical layout."""
+    if x.dim() == 4 and axis == 1 and x.is_contiguous(memory_format=CL):
+        return x, x.shape[1], 1
+    xc = x.contiguous()
+    step = 1
+    for d in xc.shape[axis + 1:]:
+        step *= int(d)
+    return xc, int(xc.shape[axis]), step
+
+
+def fused_bias_act_raw(x, b, ref, grad, act_idx, alpha, gain, size_b, step_b):
+    """x (and ref) dense in the layout described by (size_b, step_b); returns empty_like(x)."""
+    if _is_meta(x):
+        return torch.empty_like(x)
+    lib = _abi.get_plugin()
+    _require_cuda_f32(x, b, ref)
+    y = torch.empty_like(x)
+    p = _abi.FusedBiasActParams(
+        x=x.data_ptr(), b=(b.data_ptr() if b is not None else None),
+        ref=(ref.data_ptr() if ref is not None else None), y=y.data_ptr(),
+        grad=grad, act=act_idx, alpha=float(alpha), gain=float(gain),
+        sizeX=x.numel(), sizeB=size_b, stepB=step_b)
+    _abi.check(lib.igan_fused_bias_act(_stream(), ctypes.byref(p)))
+    return y
+
+
+def bias_grad_raw(dx, size_b, step_b):
+    lib = _abi.get_plugin()
+    _require_cuda_f32(dx)
+    n = dx.numel()
+    ws_floats = lib.igan_bias_grad_workspace_floats(n, size_b, step_b)
+    ws = torch.empty((max(int(ws_floats), 1),), device=dx.device, dtype=torch.float32)
+    db = torch.empty((size_b,), device=dx.device, dtype=torch.float32)
+    _abi.check(lib.igan_bias_grad(_stream(), _ptr(dx), _ptr(db), _ptr(ws), n, size_b, step_b))
+    return db
+
+
+def _match_layout(t, ref):
+    """t with exactly ref's (dense) physical layout."""
+    if t.shape == ref.shape and t.stride() == ref.stride():
+        return t
+    out = torch.empty_like(ref)
+    out.copy_(t)
+    return out
+
+
+class _FbaGradFn(torch.autograd.Function):
+    """dx = kernel(grad=1)(dy [+ d_db], ref).  Closed under differentiation for activations
+    with zero second derivative (fused_bias_act.py:161-172)."""
+
+    @staticmethod
+    def forward(ctx, dy, bias_term, ref, axis, act_idx, alpha, gain, size_b, step_b, zero_2nd):
+        ctx.save_for_backward(ref)
+        ctx.cfg = (axis, act_idx, alpha, gain, size_b, step_b, zero_2nd)
+        ctx.has_bias_term = bias_term is not None
+        return fused_bias_act_raw(_match_layout(dy, ref), bias_term, ref, 1, act_idx, alpha, gain, size_b, step_b)
+
+    @staticmethod
+    def backward(ctx, d_dx):
+        (ref,) = ctx.saved_tensors
+        axis, act_idx, alpha, gain, size_b, step_b, zero_2nd = ctx.cfg
+        if not zero_2nd:
+            raise NotImplementedError('fused_bias_act: second-order gradients of this activation are not supported on the hip path')
+        d_dy = _FbaGradFn.apply(d_dx, None, ref, axis, act_idx, alpha, gain, size_b, step_b, zero_2nd)
+        d_bias_term = None
+        if ctx.has_bias_term:
+            d_bias_term = _BiasGradFn.apply(d_dy, axis, size_b, step_b)
+        return (d_dy, d_bias_term) + (None,) * 8
+
+
+class _BiasGradFn(torch.autograd.Function):
+    """db = reduce_sum(dx) over all axes but the bias axis (fused_bias_act.py:137-146)."""
+
+    @staticmethod
+    def forward(ctx, dx, axis, size_b, step_b):
+        ctx.shape = dx.shape
+        ctx.axis = axis
+        return bias_grad_raw(dx, size_b, step_b)
+
+    @staticmethod
+    def backward(ctx, d_db):
+        view = [1] * len(ctx.shape)
+        view[ctx.axis] = -1
+        return d_db.view(*view).expand(ctx.shape), None, None, None
+
+
+class FusedBiasActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, b, axis, act_idx, alpha, gain, ref_kind, zero_2nd):
+        xd, size_b, step_b = _bias_layout(x, axis)
+        y = fused_bias_act_raw(xd, b, None, 0, act_idx, alpha, gain, size_b, step_b)
+        ctx.save_for_backward(xd if ref_kind == 'x' else y)
+        ctx.cfg = (axis, act_idx, alpha, gain, size_b, step_b, zero_2nd)
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (ref,) = ctx.saved_tensors
+        axis, act_idx, alpha, gain, size_b, step_b, zero_2nd = ctx.cfg
+        dx = _FbaGradFn.apply(dy, None, ref, axis, act_idx, alpha, gain, size_b, step_b, zero_2nd)
+        db = _BiasGradFn.apply(dx, axis, size_b, step_b) if ctx.has_b else None
+        return (dx, db) + (None,) * 6
+
+
+# ----------------------------------------------------------------------------
+# conv2d family
+
+# Geometry of y = conv(x, w): see include/igan_hip.h (igan_conv2d_params).
+ConvGeom = namedtuple('ConvGeom', 'kh kw stride up pad_y pad_x')
+
+_plan_cache = {}
+_wplan_cache = {}
+
+
+def conv2d_raw(x, w, geom, out_hw, cout, w_transposed=False, in_scale=None, out_scale=None):
+    """x: logical [N,Cin,H,W] (channels_last).  w: HWIO [KH,KW,Cin,Cout] (or the forward layer's
+    [KH,KW,Cout,Cin] when w_transposed).  Returns logical [N,Cout,OH,OW] channels_last."""
+    if _is_meta(x):
+        return torch.empty((x.shape[0], cout, out_hw[0], out_hw[1]), device='meta')
+    lib = _abi.get_plugin()
+    _require_cuda_f32(x, w, in_scale, out_scale)
+    x = nhwc(x)
+    w = w.contiguous()
+    n, cin, h, wd = x.shape
+    oh, ow = out_hw
+    y = empty_nchw(n, cout, oh, ow, x)
+    if in_scale is not None:
+        in_scale = in_scale.contiguous()
+    if out_scale is not None:
+        out_scale = out_scale.contiguous()
+    p = _abi.Conv2DParams(
+        x=x.data_ptr(), w=w.data_ptr(), y=y.data_ptr(),
+        in_scale=(in_scale.data_ptr() if in_scale is not None else None),
+        out_scale=(out_scale.data_ptr() if out_scale is not None else None),
+        workspace=None, workspace_floats=0,
+        N=n, H=h, W=wd, Cin=cin, OH=oh, OW=ow, Cout=cout,
+        KH=geom.kh, KW=geom.kw, stride=geom.stride, up=geom.up,
+        pad_y=geom.pad_y, pad_x=geom.pad_x,
+        w_transposed=1 if w_transposed else 0, splits=1)
+    key = (n, h, wd, cin, oh, ow, cout, geom)
+    plan = _plan_cache.get(key)
+    if plan is None:
+        splits = ctypes.c_int(1)
+        wsf = ctypes.c_size_t(0)
+        _abi.check(lib.igan_conv2d_plan(ctypes.byref(p), ctypes.byref(splits), ctypes.byref(wsf)))
+        plan = (splits.value, wsf.value)
+        _plan_cache[key] = plan
+    ws = None
+    if plan[0] > 1:
+        ws = torch.empty((plan[1],), device=x.device, dtype=torch.float32)
+        p.workspace = ws.data_ptr()
+        p.workspace_floats = plan[1]
+        p.splits = plan[0]
+    _abi.check(lib.igan_conv2d(_stream(), ctypes.byref(p)))
+    return y
+
+
+def conv2d_wgrad_raw(x, dy, geom, in_scale=None, out_scale=None):
+    """dw[KH,KW,Cin,Cout] for y = conv(x, w) with geometry `geom`."""
+    lib = _abi.get_plugin()
+    _require_cuda_f32(x, dy, in_scale, out_scale)
+    x = nhwc(x)
+    dy = nhwc(dy)
+    n, cin, h, wd = x.shape
+    n2, cout, oh, ow = dy.shape
+    if n2 != n:
+        raise ValueError('conv2d_wgrad: batch mismatch')
+    dw = torch.empty((geom.kh, geom.kw, cin, cout), device=x.device, dtype=torch.float32)
+    if in_scale is not None:
+        in_scale = in_scale.contiguous()
+    if out_scale is not None:
+        out_scale = out_scale.contiguous()
+    p = _abi.Conv2DWgradParams(
+        x=x.data_ptr(), dy=dy.data_ptr(), dw=dw.data_ptr(),
+        in_scale=(in_scale.data_ptr() if in_scale is not None else None),
+        out_scale=(out_scale.data_ptr() if out_scale is not None else None),
+        workspace=None, workspace_floats=0,
+        N=n, H=h, W=wd, Cin=cin, OH=oh, OW=ow, Cout=cout,
+        KH=geom.kh, KW=geom.kw, stride=geom.stride, up=geom.up,
+        pad_y=geom.pad_y, pad_x=geom.pad_x, splits=1)
+    key = (n, h, wd, cin, oh, ow, cout, geom)
+    plan = _wplan_cache.get(key)
+    if plan is None:
+        splits = ctypes.c_int(1)
+        wsf = ctypes.c_size_t(0)
+        _abi.check(lib.igan_conv2d_wgrad_plan(ctypes.byref(p), ctypes.byref(splits), ctypes.byref(wsf)))
+        plan = (splits.value, wsf.value)
+        _wplan_cache[key] = plan
+    ws = None
+    if plan[0] > 1:
+        ws = torch.empty((plan[1],), device=x.device, dtype=torch.float32)
+        p.workspace = ws.data_ptr()
+        p.workspace_floats = plan[1]
+        p.splits = plan[0]
+    _abi.check(lib.igan_conv2d_wgrad(_stream(), ctypes.byref(p)))
+    return dw
+
+
+def dgrad_geom(g):
+    """Data-gradient geometry of a forward geometry (include/igan_hip.h)."""
+    return ConvGeom(g.kh, g.kw, g.up, g.stride, g.kh - 1 - g.pad_y, g.kw - 1 - g.pad_x)
+
+
+class Conv2dFn(torch.autograd.Function):
+    """y = conv(x, w; geom).  x: [N,Cin,H,W], w: HWIO."""
+
+    @staticmethod
+    def forward(ctx, x, w, geom, out_hw):
+        ctx.save_for_backward(x, w)
+        ctx.geom = geom
+        ctx.in_hw = (x.shape[2], x.shape[3])
+        return conv2d_raw(x, w, geom, out_hw, w.shape[3])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = ConvDgradFn.apply(dy, w, ctx.geom, ctx.in_hw)
+        if ctx.needs_input_grad[1]:
+            dw = ConvWgradFn.apply(x, dy, ctx.geom)
+        return dx, dw, None, None
+
+
+class ConvDgradFn(torch.autograd.Function):
+    """dx = conv(dy, flip/transpose(w); mirrored geom): the data gradient of Conv2dFn."""
+
+    @staticmethod
+    def forward(ctx, dy, w, geom, in_hw):
+        ctx.save_for_backward(dy, w)
+        ctx.geom = geom
+        ctx.out_hw = (dy.shape[2], dy.shape[3])
+        return conv2d_raw(dy, w, dgrad_geom(geom), in_hw, w.shape[2], w_transposed=True)
+
+    @staticmethod
+    def backward(ctx, ddx):
+        dy, w = ctx.saved_tensors
+        d_dy = d_w = None
+        if ctx.needs_input_grad[0]:
+            d_dy = Conv2dFn.apply(ddx, w, ctx.geom, ctx.out_hw)
+        if ctx.needs_input_grad[1]:
+            d_w = ConvWgradFn.apply(ddx, dy, ctx.geom)
+        return d_dy, d_w, None, None
+
+
+class ConvWgradFn(torch.autograd.Function):
+    """dw = wgrad(x, dy; geom): the filter gradient of Conv2dFn."""
+
+    @staticmethod
+    def forward(ctx, x, dy, geom):
+        ctx.save_for_backward(x, dy)
+        ctx.geom = geom
+        return conv2d_wgrad_raw(x, dy, geom)
+
+    @staticmethod
+    def backward(ctx, ddw):
+        x, dy = ctx.saved_tensors
+        d_x = d_dy = None
+        if ctx.needs_input_grad[0]:
+            d_x = ConvDgradFn.apply(dy, ddw, ctx.geom, (x.shape[2], x.shape[3]))
+        if ctx.needs_input_grad[1]:
+            d_dy = Conv2dFn.apply(x, ddw, ctx.geom, (dy.shape[2], dy.shape[3]))
+        return d_x, d_dy, None
+
+
+def conv2d(x, w, geom, out_hw):
+    return Conv2dFn.apply(x, w, geom, out_hw)
+
+
+def matmul(x, w):
+    """tf.matmul(x[N,in], w[in,out]) (networks_stylegan2.py:46) as a 1x1 conv on [N,in,1,1]."""
+    n, cin = x.shape
+    y = Conv2dFn.apply(x.reshape(n, cin, 1, 1), w.reshape(1, 1, cin, w.shape[1]), ConvGeom(1, 1, 1, 1, 0, 0), (1, 1))
+    return y.reshape(n, w.shape[1])
+
+
+# ----------------------------------------------------------------------------
+# modulated conv (fused scales on the first-order path)
+
+class ModConv2dFn(torch.autograd.Function):
+    """y = d * conv(x * s, w): modulated_conv2d_layer in its non-fused form
+    (networks_stylegan2.py:112,126) with the two scalings folded into the MFMA kernel's operand
+    load / epilogue.  d may be None (demodulate=False, ToRGB).
+
+    First-order backward uses the same fused kernels.  When the backward itself has to be
+    differentiated (create_graph=True: path-length regulariser, loss.py:64-66) it is re-expressed
+    through the closed Conv2dFn / ConvDgradFn / ConvWgradFn triple and differentiable elementwise
+    ops, so gradients of any order are exact."""
+
+    @staticmethod
+    def forward(ctx, x, w, s, d, geom, out_hw):
+        y = conv2d_raw(x, w, geom, out_hw, w.shape[3], in_scale=s, out_scale=d)
+        ctx.save_for_backward(x, w, s, d, y)
+        ctx.geom = geom
+        ctx.out_hw = out_hw
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, s, d, y = ctx.saved_tensors
+        geom = ctx.geom
+        if torch.is_grad_enabled():
+            with torch.enable_grad():
+                y2 = modconv_composite(x, w, s, d, geom, ctx.out_hw)
+                ins = [t for t, need in zip((x, w, s, d), ctx.needs_input_grad[:4]) if need and t is not None]
+                gs = torch.autograd.grad(y2, ins, dy, create_graph=True, allow_unused=True)
+            it = iter(gs)
+            outs = [next(it) if (need and t is not None) else None for t, need in zip((x, w, s, d), ctx.needs_input_grad[:4])]
+            return tuple(outs) + (None, None)
+        in_hw = (x.shape[2], x.shape[3])
+        dx = dw = ds = dd = None
+        dy = nhwc(dy)
+        need_x, need_w, need_s, need_d = ctx.needs_input_grad[:4]
+        if need_x or need_s:
+            # dxs = dgrad(dy * d, w)   (un-modulated input gradient)
+            dxs = conv2d_raw(dy, w, dgrad_geom(geom), in_hw, w.shape[2], w_transposed=True, in_scale=d)
+            if need_s:
+                ds = (x * dxs).sum(dim=(2, 3))
+            if need_x:
+                dx = dxs * s[:, :, None, None]
+        if need_w:
+            dw = conv2d_wgrad_raw(x, dy, geom, in_scale=s, out_scale=d)
+        if need_d and d is not None:
+            dd = (dy * y).sum(dim=(2, 3)) / d
+        return dx, dw, ds, dd, None, None
+
+
+def modconv_composite(x, w, s, d, geom, out_hw):
+    y = Conv2dFn.apply(x * s[:, :, None, None], w, geom, out_hw)
+    if d is not None:
+        y = y * d[:, :, None, None]
+    return y
+
+
+# ----------------------------------------------------------------------------
+# minibatch stddev
+
+def mbstd_composite(x, group_size):
+    """networks_stylegan2.py:132-144 with torch ops (used only to differentiate the backward)."""
+    n, c, h, w = x.shape
+    g = min(group_size, n)
+    y = x.reshape(g, -1, 1, c, h, w)
+    y = y - y.mean(dim=0, keepdim=True)
+    y = (y * y).mean(dim=0)
+    y = torch.sqrt(y + 1e-8)
+    y = y.mean(dim=(2, 3, 4), keepdim=True)
+    y = y.mean(dim=2)
+    y = y.repeat(g, 1, h, w)
+    return torch.cat([x, y], dim=1)
+
+
+def mbstd_fwd_raw(x, g):
+    if _is_meta(x):
+        return torch.empty((x.shape[0], x.shape[1] + 1, x.shape[2], x.shape[3]), device='meta')
+    lib = _abi.get_plugin()
+    _require_cuda_f32(x)
+    x = nhwc(x)
+    n, c, h, w = x.shape
+    y = empty_nchw(n, c + 1, h, w, x)
+    stat = torch.empty((n // g,), device=x.device, dtype=torch.float32)
+    _abi.check(lib.igan_mbstd_fwd(_stream(), _ptr(x), _ptr(y), _ptr(stat), n, h, w, c, g))
+    return y
+
+
+def mbstd_bwd_raw(x, dy, g):
+    lib = _abi.get_plugin()
+    _require_cuda_f32(x, dy)
+    x = nhwc(x)
+    dy = nhwc(dy)
+    n, c, h, w = x.shape
+    dx = empty_nchw(n, c, h, w, x)
+    _abi.check(lib.igan_mbstd_bwd(_stream(), _ptr(x), _ptr(dy), _ptr(dx), n, h, w, c, g))
+    return dx
+
+
+class MbStdFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, group_size):
+        g = min(group_size, x.shape[0])
+        ctx.save_for_backward(x)
+        ctx.g = g
+        return mbstd_fwd_raw(x, g)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        if torch.is_grad_enabled():
+            with torch.enable_grad():
+                y2 = mbstd_composite(x, ctx.g)
+                (dx,) = torch.autograd.grad(y2, [x], dy, create_graph=True)
+            return dx, None
+        return mbstd_bwd_raw(x, dy, ctx.g), None
+
+
+# ----------------------------------------------------------------------------
+# nearest neighbour, optimizer
+
+def row_sqnorm_raw(a):
+    lib = _abi.get_plugin()
+    _require_cuda_f32(a)
+    a = a.contiguous()
+    out = torch.empty((a.shape[0],), device=a.device, dtype=torch.float32)
+    _abi.check(lib.igan_row_sqnorm(_stream(), _ptr(a), _ptr(out), a.shape[0], a.shape[1]))
+    return out
+
+
+def nn1_update_raw(query, qnorm, cand, cnorm, best, idx_base):
+    """Fold one candidate batch into the running packed (dist2, idx) minimum `best` (int64 view of uint64)."""
+    lib = _abi.get_plugin()
+    _require_cuda_f32(query, qnorm, cand, cnorm)
+    nq, dim = query.shape
+    nc = cand.shape[0]
+    dots = torch.empty((nq, nc), device=query.device, dtype=torch.float32)
+    _abi.check(lib.igan_nn1_update(_stream(), _ptr(query), _ptr(qnorm), _ptr(cand), _ptr(cnorm), _ptr(best), _ptr(dots),
+                                   nq, nc, dim, idx_base))
+
+
+def finite_check_raw(g, flag):
+    lib = _abi.get_plugin()
+    _abi.check(lib.igan_finite_check(_stream(), _ptr(g), g.numel(), _ptr(flag)))
+
+
+def adam_step_raw(w, g, m, v, lr, beta1, beta2, eps, pow_state, skip_flag):
+    lib = _abi.get_plugin()
+    _abi.check(lib.igan_adam_step(_stream(), _ptr(w), _ptr(g), _ptr(m), _ptr(v), w.numel(),
+                                  float(lr), float(beta1), float(beta2), float(eps), _ptr(pow_state), _ptr(skip_flag)))
+
+
+def ema_raw(dst, src, beta):
+    lib = _abi.get_plugin()
+    _abi.check(lib.igan_ema(_stream(), _ptr(dst), _ptr(src), dst.numel(), float(beta)))

@@ -1,0 +1,148 @@
+"""Loss functions on the HIP path: same names, arguments and `(loss, reg)` return arity as the
+reference's `training/loss.py` (G_logistic_ns_rec_interp_arb_pathreg :19-91, D_logistic_r1 :93-113).
+
+The reference builds one graph holding both terms and lets TensorFlow prune whichever the
+executed op does not need (G_train_op vs G_reg_op, training_loop.py:474-479).  Eager code has no
+pruning, so both functions take an extra keyword `phase` in {'both','loss','reg'}: 'both'
+evaluates everything like the reference graph; 'loss' / 'reg' return `None` for the other term.
+
+Random draws (interp factors :36, latents :46,59,98, path-length noise :64) go through
+tflib.tfutil's injectable source.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from ..dnnlib import tflib
+from ..dnnlib.tflib import tfutil
+from ..dnnlib.tflib.autosummary import autosummary
+from ..metrics import lpips as lpips_mod
+
+#----------------------------------------------------------------------------
+
+def _lpips_pair(lpips, a, b):
+    return lpips.get_output_for(a, b)
+
+def G_logistic_ns_rec_interp_arb_pathreg(G, D, lpips, training_set, minibatch_size, reals_rec_1, labels_rec_1, latents_rec_1, reals_rec_2, labels_rec_2, latents_rec_2,
+    NN_rec_lpips_weight,
+    pl_minibatch_shrink=2, pl_decay=0.01, pl_weight=2.0, phase='both'):
+    assert phase in ('both', 'loss', 'reg')
+    dev = latents_rec_1.device
+    latent_shape = G.input_shapes[0][1:]
+    loss = None
+    reg = None
+
+    if phase in ('both', 'loss'):
+        if NN_rec_lpips_weight != 0:
+            # loss.py:25-33
+            rec_images_1_out = G.get_output_for(latents_rec_1, labels_rec_1, is_training=True)
+            rec_images_2_out = G.get_output_for(latents_rec_2, labels_rec_2, is_training=True)
+            rec_images_1_out = (rec_images_1_out + 1) * (255 / 2)
+            rec_images_2_out = (rec_images_2_out + 1) * (255 / 2)
+            reals_1 = (reals_rec_1 + 1) * (255 / 2)
+            reals_2 = (reals_rec_2 + 1) * (255 / 2)
+
+            # loss.py:36-40
+            interp_factors = tfutil.random_uniform([minibatch_size, 1], dev, 0.0, 1.0)
+            interp_latents = tflib.slerp(latents_rec_2, latents_rec_1, interp_factors)
+            interp_labels = tflib.lerp(labels_rec_2, labels_rec_1, interp_factors)
+            interp_images_out = G.get_output_for(interp_latents, interp_labels, is_training=True)
+            interp_images_out = (interp_images_out + 1) * (255 / 2)
+
+            # VGG features once per image batch (the reference graph evaluates reals and the interpolated
+            # image twice, :31,41 -- same values).
+            with torch.no_grad():
+                f_real_1 = lpips_mod.features_of(lpips, reals_1)
+                f_real_2 = lpips_mod.features_of(lpips, reals_2)
+            f_rec_1 = lpips_mod.features_of(lpips, rec_images_1_out)
+            f_rec_2 = lpips_mod.features_of(lpips, rec_images_2_out)
+            f_interp = lpips_mod.features_of(lpips, interp_images_out)
+
+            loss_NN_rec_lpips = (lpips_mod.distance_of(lpips, f_rec_1, f_real_1) + lpips_mod.distance_of(lpips, f_rec_2, f_real_2)) * 0.5
+            loss_NN_rec_lpips = loss_NN_rec_lpips * NN_rec_lpips_weight
+            loss_NN_rec_lpips = autosummary('Loss/loss_NN_rec_lpips', loss_NN_rec_lpips)
+            loss = loss_addup(loss, loss_NN_rec_lpips)
+
+            loss_NN_interp_lpips = tflib.lerp(lpips_mod.distance_of(lpips, f_interp, f_real_2), lpips_mod.distance_of(lpips, f_interp, f_real_1), interp_factors.squeeze(1))
+            loss_NN_interp_lpips = loss_NN_interp_lpips * (NN_rec_lpips_weight * 0.4)
+            loss_NN_interp_lpips = autosummary('Loss/loss_NN_interp_lpips', loss_NN_interp_lpips)
+            loss = loss_addup(loss, loss_NN_interp_lpips)
+
+        # loss.py:46-52
+        latents_random = tfutil.random_normal([minibatch_size] + latent_shape, dev)
+        labels_random = training_set.get_random_labels_tf(minibatch_size)
+        arb_images_out = G.get_output_for(latents_random, labels_random, is_training=True)
+        arb_scores_out, _ = D.get_output_for(arb_images_out, labels_random, is_training=True)
+        loss_G_arb = F.softplus(-arb_scores_out)
+        loss_G_arb = autosummary('Loss/loss_G_arb', loss_G_arb)
+        loss = loss_addup(loss, loss_G_arb)
+
+    # Path length regularization (loss.py:55-89).
+    if phase in ('both', 'reg'):
+        pl_minibatch = minibatch_size // pl_minibatch_shrink
+        pl_latents = tfutil.random_normal([pl_minibatch] + latent_shape, dev)
+        pl_labels = training_set.get_random_labels_tf(pl_minibatch)
+        fake_images_out, fake_dlatents_out = G.get_output_for(pl_latents, pl_labels, is_training=True, return_dlatents=True)
+
+        # Compute |J*y|.
+        pl_noise = tfutil.random_normal(fake_images_out.shape, dev) / np.sqrt(np.prod(G.output_shape[2:]))
+        pl_grads = torch.autograd.grad(torch.sum(fake_images_out * pl_noise), [fake_dlatents_out], create_graph=True)[0]
+        pl_lengths = torch.sqrt(torch.mean(torch.sum(pl_grads * pl_grads, dim=2), dim=1))
+
+        # Track exponential moving average of |J*y| (per replica, like the per-tower variable :70).
+        if not hasattr(G, 'pl_mean_var'):
+            G.pl_mean_var = torch.zeros((), device=dev, dtype=torch.float32)
+        pl_mean_old = G.pl_mean_var.clone()
+        pl_mean = pl_mean_old + pl_decay * (torch.mean(pl_lengths) - pl_mean_old)   # differentiable, like :71
+        G.pl_mean_var.copy_(pl_mean.detach())                                        # tf.assign (:72)
+
+        # Calculate (|J*y|-a)^2.
+        pl_penalty = (pl_lengths - pl_mean) ** 2
+        reg = pl_penalty * pl_weight
+        reg = autosummary('Loss/pl_penalty', reg)
+
+    return loss, reg
+
+def D_logistic_r1(G, D, training_set, minibatch_size, reals, labels,
+    gamma=10.0, phase='both'):
+    assert phase in ('both', 'loss', 'reg')
+    dev = reals.device
+    latent_shape = G.input_shapes[0][1:]
+    loss = None
+    reg = None
+
+    need_reg = phase in ('both', 'reg')
+    if need_reg:
+        reals = reals.detach().requires_grad_(True)
+
+    if phase in ('both', 'loss'):
+        # loss.py:98-105
+        latents_random = tfutil.random_normal([minibatch_size * 2] + latent_shape, dev)
+        labels_random = training_set.get_random_labels_tf(minibatch_size * 2)
+        with torch.no_grad():   # only D's trainables are differentiated in this step (training_loop.py:291)
+            arb_images_out = G.get_output_for(latents_random, labels_random, is_training=True)
+        arb_scores_out, _ = D.get_output_for(arb_images_out, labels_random, is_training=True)
+        real_scores_out, _ = D.get_output_for(reals, labels, is_training=True)
+        loss_D = F.softplus(arb_scores_out) + F.softplus(-real_scores_out)
+        loss_D = autosummary('Loss/loss_D', loss_D)
+        loss = loss_addup(loss, loss_D)
+    else:
+        real_scores_out, _ = D.get_output_for(reals, labels, is_training=True)
+
+    if need_reg:
+        # loss.py:107-111
+        real_grads = torch.autograd.grad(torch.sum(real_scores_out), [reals], create_graph=True)[0]
+        gradient_penalty = torch.sum(real_grads * real_grads, dim=[1, 2, 3])
+        reg = gradient_penalty * (gamma * 0.5)
+        reg = autosummary('Loss/gradient_penalty_D', reg)
+
+    return loss, reg
+
+#----------------------------------------------------------------------------
+
+def loss_addup(loss, loss_):
+    if loss is None:
+        L = loss_
+    else:
+        L = loss + loss_
+    return L

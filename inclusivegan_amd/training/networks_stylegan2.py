@@ -1,0 +1,451 @@
+"""StyleGAN2 generator / discriminator on the HIP path.
+
+Same build-function names, kwargs and return arity as the reference's
+`training/networks_stylegan2.py` (G_main :151-245, G_mapping :252-304, G_synthesis_stylegan2
+:311-401, D_stylegan2_feature :408-507 and the layer helpers :22-144), so a config dict can point
+`func_name` at `inclusivegan_amd.training.networks_stylegan2.<name>`; variable names and HWIO weight
+layouts match the reference's (checkpoint interchange).
+
+What is different by design (MI355X-first):
+  * tensors are torch/ROCm, activations channels_last (physically NHWC);
+  * `modulated_conv2d_layer` always evaluates the mathematically identical *non-fused* form
+    (networks_stylegan2.py:112,126): one shared-weight implicit GEMM with M = N*H*W on the f32
+    MFMA, modulation folded into the operand load and demodulation into the epilogue, instead of
+    the reference's per-sample grouped convolution (:108-110).  The demodulation coefficients
+    d[b,o] = rsqrt(sum_i (sum_k w[k,i,o]^2) s[b,i]^2 + 1e-8) are a tiny [N,Cin]x[Cin,Cout] product;
+  * dense layers run on the same GEMM kernel as 1x1 convolutions;
+  * random draws (noise, style mixing) go through tflib.tfutil's injectable source.
+"""
+import numpy as np
+import torch
+
+from .. import hip_ops
+from ..dnnlib.util import EasyDict
+from ..dnnlib import tflib
+from ..dnnlib.tflib import tfutil
+from ..dnnlib.tflib.tfutil import variable_scope, get_variable
+from ..dnnlib.tflib.ops.upfirdn_2d import upsample_2d, downsample_2d, upsample_conv_2d, conv_downsample_2d
+from ..dnnlib.tflib.ops.fused_bias_act import fused_bias_act
+
+#----------------------------------------------------------------------------
+# Get/create weight tensor for a convolution or fully-connected layer (:22-36).
+
+def get_weight(shape, gain=1, use_wscale=True, lrmul=1, weight_var='weight', init_mul=1.0):
+    fan_in = np.prod(shape[:-1]) # [kernel, kernel, fmaps_in, fmaps_out] or [in, out]
+    he_std = gain / np.sqrt(fan_in) # He init
+    if use_wscale:
+        init_std = 1.0 / lrmul
+        runtime_coef = he_std * lrmul
+    else:
+        init_std = he_std / lrmul
+        runtime_coef = lrmul
+    w = get_variable(weight_var, shape=shape, initializer=('normal', init_std * init_mul))
+    return w * float(runtime_coef)
+
+#----------------------------------------------------------------------------
+# Fully-connected layer (:41-46).
+
+def dense_layer(x, fmaps, gain=1, use_wscale=True, lrmul=1, weight_var='weight', init_mul=1.0):
+    if x.dim() > 2:
+        x = x.reshape(x.shape[0], -1)   # logical NCHW flatten order, like tf.reshape on NCHW
+    w = get_weight([int(x.shape[1]), fmaps], gain=gain, use_wscale=use_wscale, lrmul=lrmul, weight_var=weight_var, init_mul=init_mul)
+    return hip_ops.matmul(x, w)
+
+#----------------------------------------------------------------------------
+# Convolution layer with optional upsampling or downsampling (:51-61).
+
+def conv2d_layer(x, fmaps, kernel, up=False, down=False, resample_kernel=None, gain=1, use_wscale=True, lrmul=1, weight_var='weight', init_mul=1.0):
+    assert not (up and down)
+    assert kernel >= 1 and kernel % 2 == 1
+    w = get_weight([kernel, kernel, int(x.shape[1]), fmaps], gain=gain, use_wscale=use_wscale, lrmul=lrmul, weight_var=weight_var, init_mul=init_mul)
+    if up:
+        x = upsample_conv_2d(x, w, data_format='NCHW', k=resample_kernel)
+    elif down:
+        x = conv_downsample_2d(x, w, data_format='NCHW', k=resample_kernel)
+    else:
+        p = (kernel - 1) // 2   # SAME, stride 1, odd kernel
+        x = hip_ops.conv2d(x, w, hip_ops.ConvGeom(kernel, kernel, 1, 1, p, p), (int(x.shape[2]), int(x.shape[3])))
+    return x
+
+#----------------------------------------------------------------------------
+# Apply bias and activation func (:66-68).
+
+def apply_bias_act(x, act='linear', alpha=None, gain=None, lrmul=1, bias_var='bias'):
+    b = get_variable(bias_var, shape=[int(x.shape[1])], initializer=('zeros',)) * float(lrmul)
+    return fused_bias_act(x, b=b, act=act, alpha=alpha, gain=gain)
+
+#----------------------------------------------------------------------------
+# Modulated convolution layer (:89-127).
+
+def modulated_conv2d_layer(x, y, fmaps, kernel, up=False, down=False, demodulate=True, resample_kernel=None, gain=1, use_wscale=True, lrmul=1, fused_modconv=True, weight_var='weight', mod_weight_var='mod_weight', mod_bias_var='mod_bias', init_mul=1.0):
+    assert not (up and down)
+    assert kernel >= 1 and kernel % 2 == 1
+    del fused_modconv  # both settings are the same function; this path always runs the non-fused algebra
+
+    # Get weight.
+    cin = int(x.shape[1])
+    w = get_weight([kernel, kernel, cin, fmaps], gain=gain, use_wscale=use_wscale, lrmul=lrmul, weight_var=weight_var, init_mul=init_mul)
+
+    # Modulate.
+    s = dense_layer(y, fmaps=cin, weight_var=mod_weight_var, init_mul=init_mul) # [BI] Transform incoming W to style.
+    s = apply_bias_act(s, bias_var=mod_bias_var) + 1 # [BI] Add bias (initially 1).
+
+    # Demodulate: d[b,o] = rsqrt(sum_{k,k,i} (w*s)^2 + 1e-8) = rsqrt((s^2) @ (sum_kk w^2) + 1e-8).
+    d = None
+    if demodulate:
+        wsq = (w * w).sum(dim=(0, 1))                    # [I,O]
+        d = torch.rsqrt(hip_ops.matmul(s * s, wsq) + 1e-8) # [BO]
+
+    # Convolution with optional up/downsampling; scales folded into the kernel.
+    H, W = int(x.shape[2]), int(x.shape[3])
+    if up:
+        geom = hip_ops.ConvGeom(kernel, kernel, 1, 2, kernel - 1, kernel - 1)
+        out_hw = ((H - 1) * 2 + kernel, (W - 1) * 2 + kernel)
+        x = hip_ops.ModConv2dFn.apply(x, w, s, d, geom, out_hw)
+        # FIR after the transposed conv (upfirdn_2d.py:272-273,292)
+        from ..dnnlib.tflib.ops.upfirdn_2d import _setup_kernel, _simple_upfirdn_2d
+        k = _setup_kernel(resample_kernel if resample_kernel is not None else [1, 1]) * 4.0
+        p = (k.shape[0] - 2) - (kernel - 1)
+        x = _simple_upfirdn_2d(x, k, pad0=(p+1)//2+2-1, pad1=p//2+1, data_format='NCHW')
+    elif down:
+        from ..dnnlib.tflib.ops.upfirdn_2d import _setup_kernel, _simple_upfirdn_2d
+        k = _setup_kernel(resample_kernel if resample_kernel is not None else [1, 1])
+        p = (k.shape[0] - 2) + (kernel - 1)
+        # the FIR commutes with the per-channel input scale, so modulation stays inside the conv
+        x = _simple_upfirdn_2d(x, k, pad0=(p+1)//2, pad1=p//2, data_format='NCHW')
+        H, W = int(x.shape[2]), int(x.shape[3])
+        geom = hip_ops.ConvGeom(kernel, kernel, 2, 1, 0, 0)
+        x = hip_ops.ModConv2dFn.apply(x, w, s, d, geom, ((H - kernel) // 2 + 1, (W - kernel) // 2 + 1))
+    else:
+        p = (kernel - 1) // 2
+        x = hip_ops.ModConv2dFn.apply(x, w, s, d, hip_ops.ConvGeom(kernel, kernel, 1, 1, p, p), (H, W))
+    return x
+
+#----------------------------------------------------------------------------
+# Minibatch standard deviation layer (:132-144).
+
+def minibatch_stddev_layer(x, group_size=6, num_new_features=1):
+    if num_new_features != 1:
+        raise NotImplementedError('minibatch_stddev_layer: only num_new_features=1 is built (the only value the configs use)')
+    n = int(x.shape[0])
+    g = min(group_size, n)
+    if n % g != 0:
+        raise ValueError('minibatch must be divisible by (or smaller than) group_size')
+    return hip_ops.MbStdFn.apply(x, g)
+
+#----------------------------------------------------------------------------
+# Main generator network (:151-245).
+
+def G_main(
+    latents_in,                                         # First input: Latent vectors (Z) [minibatch, latent_size].
+    labels_in,                                          # Second input: Conditioning labels [minibatch, label_size].
+    truncation_psi          = 0.6,
+    truncation_cutoff       = None,
+    truncation_psi_val      = None,
+    truncation_cutoff_val   = None,
+    dlatent_avg_beta        = 0.995,
+    style_mixing_prob       = 0.9,
+    is_training             = False,
+    is_validation           = False,
+    return_dlatents         = False,
+    is_template_graph       = False,
+    components              = None,
+    mapping_func            = 'G_mapping',
+    synthesis_func          = 'G_synthesis_stylegan2',
+    init_mul                = 1.0,
+    **kwargs):
+
+    # Validate arguments (:171-183).
+    assert not is_training or not is_validation
+    if components is None:
+        components = EasyDict()
+    if is_validation:
+        truncation_psi = truncation_psi_val
+        truncation_cutoff = truncation_cutoff_val
+    if is_training or (truncation_psi is not None and truncation_psi == 1):
+        truncation_psi = None
+    if is_training:
+        truncation_cutoff = None
+    if not is_training or (dlatent_avg_beta is not None and dlatent_avg_beta == 1):
+        dlatent_avg_beta = None
+    if not is_training or (style_mixing_prob is not None and style_mixing_prob <= 0):
+        style_mixing_prob = None
+
+    # Setup components (:186-191).
+    if 'synthesis' not in components:
+        components.synthesis = tflib.Network('G_synthesis', func_name=globals()[synthesis_func], init_mul=init_mul, **kwargs)
+    num_layers = components.synthesis.input_shape[1]
+    dlatent_size = components.synthesis.input_shape[2]
+    if 'mapping' not in components:
+        components.mapping = tflib.Network('G_mapping', func_name=globals()[mapping_func], dlatent_broadcast=num_layers, init_mul=init_mul, **kwargs)
+
+    # Setup variables (:194-195).
+    lod_in = get_variable('lod', shape=[], initializer=('zeros',), trainable=False)
+    dlatent_avg = get_variable('dlatent_avg', shape=[dlatent_size], initializer=('zeros',), trainable=False)
+    dev = latents_in.device
+
+    # Evaluate mapping network.
+    dlatents = components.mapping.get_output_for(latents_in, labels_in, is_training=is_training, **kwargs)
+
+    # Update moving average of W (:202-207).
+    if dlatent_avg_beta is not None and not is_template_graph:
+        with torch.no_grad():
+            batch_avg = dlatents[:, 0].mean(dim=0)
+            dlatent_avg.copy_(tfutil.lerp(batch_avg, dlatent_avg, dlatent_avg_beta))
+
+    # Perform style mixing regularization (:210-221).
+    if style_mixing_prob is not None:
+        latents2 = tfutil.random_normal(latents_in.shape, dev)
+        dlatents2 = components.mapping.get_output_for(latents2, labels_in, is_training=is_training, **kwargs)
+        layer_idx = torch.arange(num_layers, device=dev)[None, :, None]
+        cur_layers = num_layers   # lod is always 0 on this path (no progressive growing, training_loop.py:93-94)
+        u = tfutil.random_uniform((), dev, 0.0, 1.0)
+        r = tfutil.random_int(1, cur_layers, dev)
+        mixing_cutoff = torch.where(u < style_mixing_prob, r, torch.full_like(r, cur_layers))
+        dlatents = torch.where(layer_idx < mixing_cutoff, dlatents, dlatents2)
+
+    # Apply truncation trick (:224-232).
+    if truncation_psi is not None:
+        layer_idx = np.arange(num_layers)[np.newaxis, :, np.newaxis]
+        layer_psi = np.ones(layer_idx.shape, dtype=np.float32)
+        if truncation_cutoff is None:
+            layer_psi *= truncation_psi
+        else:
+            layer_psi = np.where(layer_idx < truncation_cutoff, layer_psi * truncation_psi, layer_psi)
+        dlatents = tfutil.lerp(dlatent_avg, dlatents, torch.as_tensor(layer_psi, device=dev))
+
+    # Evaluate synthesis network.
+    images_out = components.synthesis.get_output_for(dlatents, is_training=is_training, force_clean_graph=is_template_graph, **kwargs)
+
+    if return_dlatents:
+        return images_out, dlatents
+    return images_out
+
+#----------------------------------------------------------------------------
+# Mapping network (:252-304).
+
+def G_mapping(
+    latents_in,
+    labels_in,
+    latent_size             = 512,
+    label_size              = 0,
+    dlatent_size            = 512,
+    dlatent_broadcast       = None,
+    mapping_layers          = 8,
+    mapping_fmaps           = 512,
+    mapping_lrmul           = 0.01,
+    mapping_nonlinearity    = 'lrelu',
+    normalize_latents       = True,
+    dtype                   = 'float32',
+    init_mul                = 1.0,
+    **_kwargs):
+
+    act = mapping_nonlinearity
+    assert dtype == 'float32'
+    assert latents_in.shape[1] == latent_size
+    x = latents_in.to(torch.float32)
+    # (label conditioning is commented out in the reference, :278-284: labels are ignored.)
+
+    # Normalize latents (:289).
+    if normalize_latents:
+        x = x * torch.rsqrt(torch.mean(x * x, dim=1, keepdim=True) + 1e-8)
+
+    # Mapping layers (:292-295).
+    for layer_idx in range(mapping_layers):
+        with variable_scope('Dense%d' % layer_idx):
+            fmaps = dlatent_size if layer_idx == mapping_layers - 1 else mapping_fmaps
+            x = apply_bias_act(dense_layer(x, fmaps=fmaps, lrmul=mapping_lrmul, init_mul=init_mul), act=act, lrmul=mapping_lrmul)
+
+    # Broadcast (:298-300).
+    if dlatent_broadcast is not None:
+        x = x[:, None, :].expand(-1, dlatent_broadcast, -1)
+    return x
+
+#----------------------------------------------------------------------------
+# StyleGAN2 synthesis network (:311-401).
+
+def G_synthesis_stylegan2(
+    dlatents_in,
+    dlatent_size        = 512,
+    num_channels        = 3,
+    resolution          = 1024,
+    fmap_base           = 16 << 10,
+    fmap_decay          = 1.0,
+    fmap_min            = 1,
+    fmap_max            = 512,
+    randomize_noise     = True,
+    architecture        = 'skip',
+    nonlinearity        = 'lrelu',
+    dtype               = 'float32',
+    resample_kernel     = [1,3,3,1],
+    fused_modconv       = True,
+    init_mul            = 1.0,
+    **_kwargs):
+
+    resolution_log2 = int(np.log2(resolution))
+    assert resolution == 2**resolution_log2 and resolution >= 4
+    def nf(stage): return int(np.clip(int(fmap_base / (2.0 ** (stage * fmap_decay))), fmap_min, fmap_max))
+    assert architecture in ['orig', 'skip', 'resnet']
+    assert dtype == 'float32'
+    act = nonlinearity
+    num_layers = resolution_log2 * 2 - 2
+    images_out = None
+    assert tuple(dlatents_in.shape[1:]) == (num_layers, dlatent_size)
+    dev = dlatents_in.device
+    batch = int(dlatents_in.shape[0])
+
+    # Noise inputs (:342-346).
+    noise_inputs = []
+    for layer_idx in range(num_layers - 1):
+        res = (layer_idx + 5) // 2
+        shape = [1, 1, 2**res, 2**res]
+        noise_inputs.append(get_variable('noise%d' % layer_idx, shape=shape, initializer=('normal', 1.0), trainable=False))
+
+    # Single convolution layer with all the bells and whistles (:349-357).
+    def layer(x, layer_idx, fmaps, kernel, up=False):
+        x = modulated_conv2d_layer(x, dlatents_in[:, layer_idx], fmaps=fmaps, kernel=kernel, up=up, resample_kernel=resample_kernel, fused_modconv=fused_modconv, init_mul=init_mul)
+        if randomize_noise:
+            noise = tfutil.random_normal([batch, 1, int(x.shape[2]), int(x.shape[3])], dev)
+        else:
+            noise = noise_inputs[layer_idx]
+        noise_strength = get_variable('noise_strength', shape=[], initializer=('zeros',))
+        x = x + noise * noise_strength
+        return apply_bias_act(x, act=act)
+
+    # Building blocks for main layers (:360-377).
+    def block(x, res): # res = 3..resolution_log2
+        t = x
+        with variable_scope('Conv0_up'):
+            x = layer(x, layer_idx=res*2-5, fmaps=nf(res-1), kernel=3, up=True)
+        with variable_scope('Conv1'):
+            x = layer(x, layer_idx=res*2-4, fmaps=nf(res-1), kernel=3)
+        if architecture == 'resnet':
+            with variable_scope('Skip'):
+                t = conv2d_layer(t, fmaps=nf(res-1), kernel=1, up=True, resample_kernel=resample_kernel, init_mul=init_mul)
+                x = (x + t) * (1 / np.sqrt(2))
+        return x
+    def upsample(y):
+        with variable_scope('Upsample'):
+            return upsample_2d(y, k=resample_kernel)
+    def torgb(x, y, res): # res = 2..resolution_log2
+        with variable_scope('ToRGB'):
+            t = apply_bias_act(modulated_conv2d_layer(x, dlatents_in[:, res*2-3], fmaps=num_channels, kernel=1, demodulate=False, fused_modconv=fused_modconv, init_mul=init_mul))
+            return t if y is None else y + t
+
+    # Early layers (:380-388).
+    y = None
+    with variable_scope('4x4'):
+        with variable_scope('Const'):
+            x = get_variable('const', shape=[1, nf(1), 4, 4], initializer=('normal', 1.0))
+            x = x.expand(batch, -1, -1, -1)
+        with variable_scope('Conv'):
+            x = layer(x, layer_idx=0, fmaps=nf(1), kernel=3)
+        if architecture == 'skip':
+            y = torgb(x, y, 2)
+
+    # Main layers (:391-398).
+    for res in range(3, resolution_log2 + 1):
+        with variable_scope('%dx%d' % (2**res, 2**res)):
+            x = block(x, res)
+            if architecture == 'skip':
+                y = upsample(y)
+            if architecture == 'skip' or res == resolution_log2:
+                y = torgb(x, y, res)
+    images_out = y
+    return images_out
+
+#----------------------------------------------------------------------------
+# StyleGAN2 discriminator returning (scores, features) (:408-507).
+
+def D_stylegan2_feature(
+    images_in,
+    labels_in,
+    num_channels        = 3,
+    resolution          = 1024,
+    label_size          = 0,
+    fmap_base           = 16 << 10,
+    fmap_decay          = 1.0,
+    fmap_min            = 1,
+    fmap_max            = 512,
+    architecture        = 'resnet',
+    nonlinearity        = 'lrelu',
+    mbstd_group_size    = 6,
+    mbstd_num_features  = 1,
+    dtype               = 'float32',
+    resample_kernel     = [1,3,3,1],
+    return_features     = False,        # extension: the losses discard features_out (loss.py:49,101-102), so the
+                                        # concat is only materialised on request; the 2-tuple return is kept.
+    **_kwargs):
+
+    resolution_log2 = int(np.log2(resolution))
+    assert resolution == 2**resolution_log2 and resolution >= 4
+    def nf(stage): return int(np.clip(int(fmap_base / (2.0 ** (stage * fmap_decay))), fmap_min, fmap_max))
+    assert architecture in ['orig', 'skip', 'resnet']
+    assert dtype == 'float32'
+    act = nonlinearity
+    assert tuple(images_in.shape[1:]) == (num_channels, resolution, resolution)
+    images_in = images_in.to(torch.float32)
+
+    # Building blocks for main layers (:438-455).
+    def fromrgb(x, y, res): # res = 2..resolution_log2
+        with variable_scope('FromRGB'):
+            t = apply_bias_act(conv2d_layer(y, fmaps=nf(res-1), kernel=1), act=act)
+            return t if x is None else x + t
+    def block(x, res): # res = 2..resolution_log2
+        t = x
+        with variable_scope('Conv0'):
+            x = apply_bias_act(conv2d_layer(x, fmaps=nf(res-1), kernel=3), act=act)
+        with variable_scope('Conv1_down'):
+            x = apply_bias_act(conv2d_layer(x, fmaps=nf(res-2), kernel=3, down=True, resample_kernel=resample_kernel), act=act)
+        if architecture == 'resnet':
+            with variable_scope('Skip'):
+                t = conv2d_layer(t, fmaps=nf(res-2), kernel=1, down=True, resample_kernel=resample_kernel)
+                x = (x + t) * (1 / np.sqrt(2))
+        return x
+    def downsample(y):
+        with variable_scope('Downsample'):
+            return downsample_2d(y, k=resample_kernel)
+
+    feats = []
+    def feature_concat(x): # :457-461
+        if return_features:
+            length = int(np.prod(x.shape[1:]))
+            feats.append((x / np.sqrt(np.float32(length))).reshape(-1, length))
+
+    # Main layers (:463-476).
+    x = None
+    y = images_in
+    feature_concat(y)
+    for res in range(resolution_log2, 2, -1):
+        with variable_scope('%dx%d' % (2**res, 2**res)):
+            if architecture == 'skip' or res == resolution_log2:
+                x = fromrgb(x, y, res)
+                feature_concat(x)
+            x = block(x, res)
+            feature_concat(x)
+            if architecture == 'skip':
+                y = downsample(y)
+
+    # Final layers (:479-490).
+    with variable_scope('4x4'):
+        if architecture == 'skip':
+            x = fromrgb(x, y, 2)
+        if mbstd_group_size > 1:
+            with variable_scope('MinibatchStddev'):
+                x = minibatch_stddev_layer(x, mbstd_group_size, mbstd_num_features)
+        with variable_scope('Conv'):
+            x = apply_bias_act(conv2d_layer(x, fmaps=nf(1), kernel=3), act=act)
+            feature_concat(x)
+        with variable_scope('Dense0'):
+            x = apply_bias_act(dense_layer(x, fmaps=nf(0)), act=act)
+            feature_concat(x)
+
+    # Output layer (:493-496).
+    with variable_scope('Output'):
+        x = apply_bias_act(dense_layer(x, fmaps=1))
+        feature_concat(x)
+    scores_out = x.squeeze(1)
+    features_out = torch.cat(feats, dim=1) if return_features else None
+    return scores_out, features_out
+
+#----------------------------------------------------------------------------

@@ -1,0 +1,447 @@
+"""Main training loop on the HIP path.  `training_loop(**kwargs)` accepts the kwargs of the
+reference's `training/training_loop.py:123-160` (as assembled by run_training.py:36-165) and runs
+the same host loop (:332-482):
+
+    every data_size*init_staleness images: IMLE refresh (generate candidates with G, assign every
+        real its nearest candidate) (:353-406)
+    assemble 2*minibatch (real, label, matched latent) triples in dataset order, optional attribute
+        AND-mask, slerp-perturb the latents, split in halves, shuffle each (:409-464)
+    G step; G reg every G_reg_interval; D step + Gs EMA; D reg every D_reg_interval (:466-479)
+    cur_nimg += 2*minibatch (:481)
+
+MI355X execution model (instead of one process building an in-graph tower per GPU, :257-291):
+one process per GPU (`num_gpus` = torch.distributed world size), every rank runs the same host
+logic from the same NumPy seed (run_training.py:61 `rnd.np_random_seed`) and takes its slice of
+the global minibatch (tf.split, :231-239); gradients are averaged with one RCCL all-reduce per
+step over the flat bucket (tflib/optimizer.py); the IMLE candidates are sharded over ranks and the
+per-real minima are combined with one all-reduce(min) of packed (distance, index) words.
+
+Out of scope here: run-dir / snapshot / metric maintenance (:485-531).
+A `hooks` dict lets a driver (bench.py, tests) observe iterations and stop early.
+"""
+import time
+
+import numpy as np
+import torch
+
+from .. import dnnlib
+from ..dnnlib import tflib
+from ..dnnlib.tflib import tfutil
+from ..dnnlib.tflib.autosummary import autosummary
+from ..dnnlib.tflib import autosummary as autosummary_mod
+from . import dataset
+from . import misc
+from ..dci_code.dci import DCI, unpack_best
+from .. import hip_ops
+
+#----------------------------------------------------------------------------
+# Function to determine the dimension of random projection (:28-35).
+
+def func_proj_dim(init_proj_dim, data_size, num_samples_factor, G):
+    if init_proj_dim is None:
+        proj_dim = int(np.prod(G.output_shape[1:]))
+    elif init_proj_dim == 0:
+        # sklearn.random_projection.johnson_lindenstrauss_min_dim(n_samples, eps=0.1)
+        n, eps = data_size * num_samples_factor, 0.1
+        proj_dim = int(4 * np.log(n) / ((eps ** 2 / 2) - (eps ** 3 / 3)))
+    else:
+        proj_dim = init_proj_dim
+    return proj_dim
+
+#----------------------------------------------------------------------------
+# Just-in-time processing of training images before feeding them to the networks (:40-60).
+
+def process_reals(x, labels, lod, mirror_augment, drange_data, drange_net):
+    x = x.to(torch.float32)
+    x = misc.adjust_dynamic_range(x, drange_data, drange_net)
+    if mirror_augment:
+        flip = tfutil.random_uniform([x.shape[0]], x.device) >= 0.5
+        x = torch.where(flip[:, None, None, None], x.flip(3), x)
+    # FadeLOD / UpscaleLOD are the identity at lod == 0, the only value config-e produces (:93-94).
+    assert lod == 0
+    return x.contiguous(memory_format=torch.channels_last), labels
+
+#----------------------------------------------------------------------------
+# Evaluate time-varying training parameters (:65-118).
+
+def training_schedule(
+    cur_nimg,
+    training_set,
+    lod_initial_resolution  = None,
+    lod_training_kimg       = 600,
+    lod_transition_kimg     = 600,
+    minibatch_size_base     = 64,
+    minibatch_size_dict     = {},
+    minibatch_gpu_base      = 32,
+    minibatch_gpu_dict      = {},
+    G_lrate_base            = 0.002,
+    G_lrate_dict            = {},
+    D_lrate_base            = 0.002,
+    D_lrate_dict            = {},
+    lrate_rampup_kimg       = 0,
+    tick_kimg_base          = 1,
+    tick_kimg_dict          = {}):
+
+    s = dnnlib.EasyDict()
+    s.kimg = cur_nimg / 1000.0
+    if lod_initial_resolution is not None:
+        raise NotImplementedError('progressive growing (configs a-d) is not on the hot path')
+    s.lod = 0.0
+    s.resolution = 2 ** training_set.resolution_log2
+    s.minibatch_size = minibatch_size_dict.get(s.resolution, minibatch_size_base)
+    s.minibatch_gpu = minibatch_gpu_dict.get(s.resolution, minibatch_gpu_base)
+    s.G_lrate = G_lrate_dict.get(s.resolution, G_lrate_base)
+    s.D_lrate = D_lrate_dict.get(s.resolution, D_lrate_base)
+    if lrate_rampup_kimg > 0:
+        rampup = min(s.kimg / lrate_rampup_kimg, 1.0)
+        s.G_lrate *= rampup
+        s.D_lrate *= rampup
+    s.tick_kimg = tick_kimg_dict.get(s.resolution, tick_kimg_base)
+    return s
+
+#----------------------------------------------------------------------------
+
+def _dist_info():
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        return torch.distributed.get_rank(), torch.distributed.get_world_size()
+    return 0, 1
+
+
+def imle_refresh(G, training_set_rec, latent_candidates, data_size, minibatch_size, candidate_batch_size,
+                 drange_net, device, rank=0, world=1, query_chunk=4096):
+    """IMLE assignment (:357-406, non-exclusive, no projection): every real image (dataset order,
+    [-1,1] range, flattened CHW) gets the index of its nearest generated candidate and the Euclidean
+    distance.  Candidates are generated batch by batch with G (training weights, validation mode,
+    random noise -- `G.run(..., is_validation=True)`, :361) and folded into a running per-real
+    minimum; rank r handles candidate batches r, r+world, ... and the minima are combined with one
+    all-reduce(min).  Returns (nearest_indices int64 [data_size], dists float64 [data_size]) as NumPy."""
+    num_cand = latent_candidates.shape[0]
+    dim = int(np.prod(training_set_rec.shape))
+    # Reals resident on the device in fp32 (30 000 x 49 152 x 4 B = 5.9 GB for CelebA-128).
+    reals = torch.empty((data_size, dim), device=device, dtype=torch.float32)
+    step = max(1, (256 << 20) // (4 * dim))
+    for i in range(0, data_size, step):
+        r, _ = training_set_rec.get_minibatch_np(min(step, data_size - i))
+        r = torch.from_numpy(r).to(device).to(torch.float32)
+        reals[i:i + r.shape[0]] = misc.adjust_dynamic_range(r, training_set_rec.dynamic_range, drange_net).reshape(r.shape[0], -1)
+    rnorm = hip_ops.row_sqnorm_raw(reals)
+    best = torch.full((data_size,), -1, device=device, dtype=torch.int64)
+    nbatches = (num_cand + candidate_batch_size - 1) // candidate_batch_size
+    label_size = training_set_rec.label_size
+    with torch.no_grad():
+        for b in range(rank, nbatches, world):
+            c0 = b * candidate_batch_size
+            z = torch.from_numpy(latent_candidates[c0:c0 + candidate_batch_size]).to(device)
+            lab = torch.zeros((z.shape[0], label_size), device=device)
+            imgs = []
+            for j in range(0, z.shape[0], minibatch_size):
+                imgs.append(G.get_output_for(z[j:j + minibatch_size], lab[j:j + minibatch_size], is_validation=True))
+            cand = torch.cat(imgs, dim=0).contiguous().reshape(z.shape[0], -1)   # logical NCHW flatten (:363)
+            cnorm = hip_ops.row_sqnorm_raw(cand)
+            for q0 in range(0, data_size, query_chunk):
+                hip_ops.nn1_update_raw(reals[q0:q0 + query_chunk], rnorm[q0:q0 + query_chunk], cand, cnorm,
+                                       best[q0:q0 + query_chunk], c0)
+    if world > 1:
+        torch.distributed.all_reduce(best, op=torch.distributed.ReduceOp.MIN)
+    idx, dist = unpack_best(best)
+    return idx.cpu().numpy(), dist.cpu().numpy().astype(np.float64)
+
+#----------------------------------------------------------------------------
+# Main training script.
+
+def training_loop(
+    G_args                  = {},
+    D_args                  = {},
+    G_opt_args              = {},
+    D_opt_args              = {},
+    G_loss_args             = {},
+    D_loss_args             = {},
+    dataset_args            = {},
+    sched_args              = {},
+    grid_args               = {},
+    metric_arg_list         = [],
+    tf_config               = {},
+    data_dir                = None,
+    G_smoothing_kimg        = 10.0,
+    minibatch_repeats       = 4,
+    lazy_regularization     = True,
+    G_reg_interval          = 4,
+    D_reg_interval          = 16,
+    reset_opt_for_new_lod   = True,
+    total_kimg              = 25000,
+    mirror_augment          = False,
+    drange_net              = [-1,1],
+    save_tf_graph           = False,
+    save_weight_histograms  = False,
+    resume_pkl              = None,
+
+    data_size               = 3000,
+    num_epochs              = 10000,
+
+    init_proj_dim           = None,
+    init_staleness          = 10,
+    num_samples_factor      = 25,
+    knn_perturb_factor      = 0.1,
+    candidate_batch_size    = 256,
+    exclusive_retrieved_code = 0,
+    dist_thres_percentile   = 100.0,
+    attr_interesting        = None,
+
+    # --- extensions (not in the reference) ---
+    attr_names              = None,     # list of attribute names (reference reads celeba/Anno/list_attr_celeba.txt, :174-180)
+    lpips_func_name         = 'inclusivegan_amd.metrics.lpips.vgg16_zhang_perceptual',
+    hooks                   = None,     # {'on_iteration': f(state) -> bool stop, 'on_refresh': f(seconds)}
+    submit_config           = None,
+    ):
+
+    hooks = hooks or {}
+    if resume_pkl is not None:
+        raise NotImplementedError('resume_pkl: checkpoint interchange is a later row (SURVEY.md section 8f)')
+    if init_proj_dim is not None:
+        raise NotImplementedError('random projection before NN search is not built (default is no projection)')
+    if exclusive_retrieved_code:
+        raise NotImplementedError('exclusive_retrieved_code needs k-NN with k>1; only the default 1-NN path is built')
+
+    # Initialize (tflib.init_tf: rnd.np_random_seed, tfutil.py:122-147).
+    rank, world = _dist_info()
+    num_gpus = world
+    np_seed = tf_config.get('rnd.np_random_seed', 1000) if tf_config else 1000
+    np.random.seed(np_seed)                 # identical host-side stream on every rank
+    device = torch.device('cuda', torch.cuda.current_device())
+    torch.manual_seed(np_seed * 7919 + rank)   # per-rank device stream (latents, noise)
+
+    # Load training set (:169-170).
+    ds_args = dict(dataset_args)
+    ds_args.setdefault('data_size', data_size)
+    training_set = dataset.load_dataset(data_dir=data_dir, verbose=(rank == 0), device=device, rank=rank, world_size=world, **ds_args)
+    training_set_rec = dataset.load_dataset(data_dir=data_dir, verbose=False, device=device, rank=0, world_size=1, **ds_args)
+
+    if attr_interesting is not None:
+        assert attr_names is not None, 'attr_interesting needs attr_names (celeba/Anno/list_attr_celeba.txt is not shipped)'
+
+    # Construct networks (:188-197).  Same seed on every rank => bit-identical replicas.
+    G_args = dict(G_args); D_args = dict(D_args)
+    G_args['func_name'] = _retarget(G_args.get('func_name', 'training.networks_stylegan2.G_main'))
+    D_args['func_name'] = _retarget(D_args.get('func_name', 'training.networks_stylegan2.D_stylegan2_feature'))
+    G = tflib.Network('G', num_channels=training_set.shape[0], resolution=training_set.shape[1], label_size=training_set.label_size, device=device, seed=np_seed + 1, **G_args)
+    D = tflib.Network('D', num_channels=training_set.shape[0], resolution=training_set.shape[1], label_size=training_set.label_size, device=device, seed=np_seed + 2, **D_args)
+    Gs = G.clone('Gs')
+    lpips = tflib.Network('lpips', func_name=lpips_func_name, resolution=training_set.shape[1], device=device, seed=np_seed + 3)
+    proj_dim = func_proj_dim(init_proj_dim, data_size, num_samples_factor, G)
+
+    if rank == 0:
+        G.print_layers(); D.print_layers()
+    sched = training_schedule(cur_nimg=0, training_set=training_set, **sched_args)
+
+    # Setup optimizers (:242-255).
+    cur_lrate = [sched.G_lrate]
+    G_opt_args = dict(G_opt_args)
+    D_opt_args = dict(D_opt_args)
+    ratios = {}
+    for key, args, reg_interval in [('G', G_opt_args, G_reg_interval), ('D', D_opt_args, D_reg_interval)]:
+        mb_ratio = reg_interval / (reg_interval + 1) if lazy_regularization else 1.0
+        ratios[key] = mb_ratio
+        if lazy_regularization:
+            if 'beta1' in args: args['beta1'] **= mb_ratio
+            if 'beta2' in args: args['beta2'] **= mb_ratio
+    G_lr = lambda: cur_lrate[0] * ratios['G']
+    D_lr = lambda: cur_lrate[0] * ratios['D']      # both optimizers are fed sched.G_lrate (:218,246,347)
+    G_opt = tflib.Optimizer(name='TrainG', learning_rate=G_lr, **G_opt_args)
+    D_opt = tflib.Optimizer(name='TrainD', learning_rate=D_lr, **D_opt_args)
+    G_reg_opt = tflib.Optimizer(name='RegG', share=G_opt, learning_rate=G_lr, **G_opt_args)
+    D_reg_opt = tflib.Optimizer(name='RegD', share=D_opt, learning_rate=D_lr, **D_opt_args)
+
+    G_loss_args = dict(G_loss_args); D_loss_args = dict(D_loss_args)
+    G_loss_fn = dnnlib.util.get_obj_by_name(_retarget(G_loss_args.pop('func_name')))
+    D_loss_fn = dnnlib.util.get_obj_by_name(_retarget(D_loss_args.pop('func_name')))
+
+    minibatch_size_holder = [sched.minibatch_size]
+    Gs_beta = (lambda: 0.5 ** (minibatch_size_holder[0] / (G_smoothing_kimg * 1000.0))) if G_smoothing_kimg > 0.0 else 0.0  # :222
+    Gs_update_op = Gs.setup_as_moving_average_of(G, beta=Gs_beta)
+
+    # ---- the four training ops (:278-297) ------------------------------------------
+    def G_train_op(feed):
+        D.requires_grad_(False)
+        reals_1, labels_1 = process_reals(feed['reals_rec_1'], feed['labels_rec_1'], 0, mirror_augment, training_set.dynamic_range, drange_net)
+        reals_2, labels_2 = process_reals(feed['reals_rec_2'], feed['labels_rec_2'], 0, mirror_augment, training_set.dynamic_range, drange_net)
+        loss, _ = G_loss_fn(G=G, D=D, lpips=lpips, training_set=training_set, minibatch_size=feed['minibatch_gpu'],
+                            reals_rec_1=reals_1, labels_rec_1=labels_1, latents_rec_1=feed['latents_rec_1'],
+                            reals_rec_2=reals_2, labels_rec_2=labels_2, latents_rec_2=feed['latents_rec_2'], phase='loss', **G_loss_args)
+        G_opt.register_gradients(torch.mean(loss), G)
+        D.requires_grad_(True)
+        G_opt.apply_updates()
+        return loss
+
+    def G_reg_op(feed):
+        D.requires_grad_(False)
+        _, reg = G_loss_fn(G=G, D=D, lpips=lpips, training_set=training_set, minibatch_size=feed['minibatch_gpu'],
+                           reals_rec_1=None, labels_rec_1=None, latents_rec_1=feed['latents_rec_1'],
+                           reals_rec_2=None, labels_rec_2=None, latents_rec_2=feed['latents_rec_2'], phase='reg', **G_loss_args)
+        D.requires_grad_(True)
+        if reg is not None:
+            G_reg_opt.register_gradients(torch.mean(reg * G_reg_interval), G)
+        G_reg_opt.apply_updates(allow_no_op=True)
+
+    def next_reals():
+        # `training_set.get_minibatch_tf()` is an iterator op: every session.run that consumes it
+        # (D_train_op and, separately, D_reg_op -- :231,477,479) pulls the next minibatch.
+        reals, labels = training_set.get_minibatch_tf()
+        return process_reals(reals, labels, 0, mirror_augment, training_set.dynamic_range, drange_net)
+
+    def D_train_op(feed):
+        reals, labels = next_reals()
+        G.requires_grad_(False)
+        loss, _ = D_loss_fn(G=G, D=D, training_set=training_set, minibatch_size=feed['minibatch_gpu'], reals=reals, labels=labels, phase='loss', **D_loss_args)
+        G.requires_grad_(True)
+        D_opt.register_gradients(torch.mean(loss), D)
+        D_opt.apply_updates()
+        return loss
+
+    def D_reg_op(feed):
+        reals, labels = next_reals()
+        G.requires_grad_(False)
+        _, reg = D_loss_fn(G=G, D=D, training_set=training_set, minibatch_size=feed['minibatch_gpu'], reals=reals, labels=labels, phase='reg', **D_loss_args)
+        G.requires_grad_(True)
+        if reg is not None:
+            D_reg_opt.register_gradients(torch.mean(reg * D_reg_interval), D)
+        D_reg_opt.apply_updates(allow_no_op=True)
+
+    if rank == 0:
+        print('Training for %d kimg...\n' % total_kimg)
+    cur_nimg = 0
+    cur_tick = -1
+    tick_start_nimg = cur_nimg
+    tick_start_time = time.time()
+    start_time = tick_start_time
+    running_mb_counter = 0
+    cursor = 0
+    latent_candidates = np.random.randn(data_size * num_samples_factor, *G.input_shapes[0][1:]).astype(np.float32)  # :325
+
+    selected_latents = None
+    remained = None          # (reals, labels, latents) carried over between iterations (:328-330)
+    stop = False
+    while cur_nimg < total_kimg * 1000 and not stop:
+        # Choose training parameters (:336-340).
+        sched = training_schedule(cur_nimg=cur_nimg, training_set=training_set, **sched_args)
+        assert sched.minibatch_size % (sched.minibatch_gpu * num_gpus) == 0
+        assert sched.minibatch_size // (sched.minibatch_gpu * num_gpus) == 1   # "fast path without gradient accumulation" (:467)
+        assert data_size % (sched.minibatch_size * 2) == 0
+        training_set.configure(sched.minibatch_size * 2, sched.lod)
+        training_set_rec.configure(sched.minibatch_size * 2, sched.lod)
+        cur_lrate[0] = sched.G_lrate
+        minibatch_size_holder[0] = sched.minibatch_size
+        mb = sched.minibatch_size
+
+        for _repeat in range(minibatch_repeats):
+            run_G_reg = (lazy_regularization and running_mb_counter % G_reg_interval == 0)
+            run_D_reg = (lazy_regularization and running_mb_counter % D_reg_interval == 0)
+
+            # IMLE refresh (:354-406).
+            if selected_latents is None or cur_nimg // (data_size * init_staleness) != (cur_nimg - mb * 2) // (data_size * init_staleness):
+                if selected_latents is not None:
+                    init_staleness *= 2
+                t0 = time.time()
+                nearest_indices, selected_dists = imle_refresh(
+                    G, training_set_rec, latent_candidates, data_size, sched.minibatch_gpu, candidate_batch_size,
+                    drange_net, device, rank=rank, world=world)
+                cursor += data_size     # the reference's query loop walks the whole set once (:403)
+                selected_latents = latent_candidates[nearest_indices]
+                dist_thres = np.percentile(selected_dists, dist_thres_percentile)
+                torch.cuda.synchronize()
+                if 'on_refresh' in hooks:
+                    hooks['on_refresh'](time.time() - t0)
+
+            # Sync IMLE loss with G training loss (:409-441).
+            if remained is None or cursor % data_size == 0:
+                cur = None
+            else:
+                cur = [np.array(a) for a in remained]
+            while cur is None or cur[0].shape[0] < mb * 2:
+                reals_t, labels_t = training_set_rec.get_minibatch_np(mb * 2)
+                reals_t = reals_t.astype(np.float32)
+                pos = cursor % data_size
+                latents_t = selected_latents[pos:pos + mb * 2]
+                if attr_interesting is None:
+                    selected_idx = selected_dists[pos:pos + mb * 2] <= dist_thres
+                else:
+                    active = np.ones(labels_t.shape[0])
+                    for attr in attr_interesting.split(','):
+                        active *= labels_t[:, attr_names.index(attr)]
+                    selected_idx = active == 1
+                sel = [reals_t[selected_idx], labels_t[selected_idx], latents_t[selected_idx]]
+                if cur is None or cursor % data_size == 0:
+                    cur = [np.array(a) for a in sel]
+                else:
+                    cur = [np.concatenate((a, b), axis=0) for a, b in zip(cur, sel)]
+                if cur[0].shape[0] > mb * 2:
+                    remained = [np.array(a[mb * 2:]) for a in cur]
+                    cur = [np.array(a[:mb * 2]) for a in cur]
+                else:
+                    remained = None
+                cursor += mb * 2
+
+            cur_reals, cur_labels, cur_latents = cur
+            cur_latents = misc.slerp(cur_latents, np.random.randn(*cur_latents.shape).astype(np.float32), knn_perturb_factor)  # :447
+            halves = []
+            for h in range(2):
+                order = np.arange(mb)
+                np.random.shuffle(order)                                         # :456-464
+                sl = slice(h * mb, (h + 1) * mb)
+                halves.append((cur_reals[sl][order], cur_labels[sl][order], cur_latents[sl][order]))
+
+            # This rank's slice of the global minibatch (tf.split, :231-239).
+            B = sched.minibatch_gpu
+            rs = slice(rank * B, (rank + 1) * B)
+            feed = {'minibatch_gpu': B}
+            for h, (r_, l_, z_) in enumerate(halves):
+                feed['reals_rec_%d' % (h + 1)] = torch.from_numpy(np.ascontiguousarray(r_[rs])).to(device)
+                feed['labels_rec_%d' % (h + 1)] = torch.from_numpy(np.ascontiguousarray(l_[rs])).to(device)
+                feed['latents_rec_%d' % (h + 1)] = torch.from_numpy(np.ascontiguousarray(z_[rs]).astype(np.float32)).to(device)
+
+            # Run training ops (:474-479).
+            G_train_op(feed)
+            if run_G_reg:
+                G_reg_op(feed)
+            D_train_op(feed)
+            Gs_update_op()
+            if run_D_reg:
+                D_reg_op(feed)
+
+            cur_nimg += mb * 2
+            running_mb_counter += 1
+            if 'on_iteration' in hooks:
+                if hooks['on_iteration'](dict(cur_nimg=cur_nimg, iteration=running_mb_counter, G=G, D=D, Gs=Gs)):
+                    stop = True
+                    break
+
+        # Per-tick progress line (:485-505); snapshots / metrics are out of scope.
+        done = (cur_nimg >= total_kimg * 1000) or stop
+        if cur_tick < 0 or cur_nimg >= tick_start_nimg + sched.tick_kimg * 1000 or done:
+            cur_tick += 1
+            torch.cuda.synchronize()
+            now = time.time()
+            tick_kimg = max((cur_nimg - tick_start_nimg) / 1000.0, 1e-9)
+            tick_time = now - tick_start_time
+            sums = autosummary_mod.flush()
+            if rank == 0:
+                print('tick %-5d kimg %-8.1f lod %-5.2f minibatch %-4d time %-12s sec/tick %-7.1f sec/kimg %-7.2f gpumem %.1f' % (
+                    cur_tick, cur_nimg / 1000.0, sched.lod, sched.minibatch_size, dnnlib.util.format_time(now - start_time),
+                    tick_time, tick_time / tick_kimg, torch.cuda.max_memory_allocated() / 2**30))
+                for k, v in sums.items():
+                    print('    %-32s %g' % (k, v))
+            tick_start_nimg = cur_nimg
+            tick_start_time = now
+
+    training_set.close()
+    training_set_rec.close()
+    return dict(G=G, D=D, Gs=Gs, cur_nimg=cur_nimg)
+
+
+def _retarget(func_name):
+    """A reference config names 'training.loss.X' / 'training.networks_stylegan2.X'
+    (run_training.py:52-57); resolve those dotted names inside this package."""
+    if func_name.startswith('training.') or func_name.startswith('metrics.'):
+        return 'inclusivegan_amd.' + func_name
+    return func_name
+
+#----------------------------------------------------------------------------
