@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Throughput benchmark of the hot path: training img/s of StyleGAN2+IMLE (config-e-Gskip-Dresnet)
+on synthetic CelebA-shaped 128x128 batches, one process per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one iteration of the reference's host loop (training/training_loop.py:466-482): G step,
+G path-length reg every 4th, D step + Gs EMA, D R1 reg every 16th; it advances the image counter by
+2*minibatch_size (:481), which is what "img" means in img/s.  The IMLE refresh (candidate generation
++ nearest-neighbour assignment, :353-406) runs once before the timed region and is reported
+separately (`imle_refresh_s`), as BASELINE.md prescribes.
+
+Prints ONE JSON line on rank 0.  Besides the contract fields it carries
+  roofline      the dominant kernel (f32-MFMA conv2d forward, 128x128 Conv1 shape) timed with HIP
+                events in this process: algorithmic FLOPs / launch time vs the 157.3 TFLOP/s f32
+                matrix peak of MI355X;
+  cpu_baseline  the CPU oracle (oracle/, PyTorch-CPU fp32) timed on this box's host cores on a
+                bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+F32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=32)
+    p.add_argument('--warmup', type=int, default=4)
+    p.add_argument('--resolution', type=int, default=128)
+    p.add_argument('--minibatch-gpu', type=int, default=6)
+    p.add_argument('--data-size', type=int, default=1152)
+    p.add_argument('--num-samples-factor', type=int, default=10)
+    p.add_argument('--lpips-weight', type=float, default=2.5)
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--no-roofline', action='store_true')
+    return p.parse_args()
+
+
+def conv_roofline(device, batch, reps=20):
+    """Dominant kernel: conv_fwd_kernel<128,128,2,2> on the 128x128 Conv1 shape
+    (GEMM M = batch*128*128, N = 128, K = 1152)."""
+    import torch
+    from inclusivegan_amd import hip_ops
+    cin = cout = 128
+    res = 128
+    x = torch.randn(batch, cin, res, res, device=device).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(3, 3, cin, cout, device=device) / 34.0
+    s = torch.rand(batch, cin, device=device) + 0.5
+    d = torch.rand(batch, cout, device=device) + 0.5
+    geom = hip_ops.ConvGeom(3, 3, 1, 1, 1, 1)
+    for _ in range(3):
+        hip_ops.conv2d_raw(x, w, geom, (res, res), cout, in_scale=s, out_scale=d)
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()     # same stream the kernels are launched on (torch's current stream)
+    for _ in range(reps):
+        hip_ops.conv2d_raw(x, w, geom, (res, res), cout, in_scale=s, out_scale=d)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    flops = 2.0 * batch * res * res * cout * cin * 9
+    achieved = flops / (ms * 1e-3) / 1e12
+    return dict(bound='mfma', kernel='conv_fwd_kernel<128,128,2,2> modconv 128x128 3x3 Cin=Cout=128 batch %d' % batch,
+                achieved=round(achieved, 2), peak=F32_MATRIX_PEAK_TFLOPS, unit='TFLOP/s', frac=round(achieved / F32_MATRIX_PEAK_TFLOPS, 4),
+                flops_per_launch=flops, us_per_launch=round(ms * 1e3, 1), traffic=None)
+
+
+def cpu_baseline(resolution, batch, lpips_weight):
+    """CPU oracle on a bounded sample: one G step + one D step (loss phases, fwd+bwd) of the same
+    configuration at the same per-GPU batch; the lazy-regularisation steps are left out of the sample."""
+    import numpy as np
+    import torch
+    from oracle import loss as OL
+    from oracle.misc import SeededRandom
+    from inclusivegan_amd.dnnlib import tflib
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    kw = dict(num_channels=3, resolution=resolution, label_size=0, fmap_base=8192, device='cpu')
+    G = tflib.Network('G', func_name='inclusivegan_amd.training.networks_stylegan2.G_main', architecture='skip', seed=1, **kw)
+    D = tflib.Network('D', func_name='inclusivegan_amd.training.networks_stylegan2.D_stylegan2_feature', architecture='resnet', seed=2, **kw)
+    Lp = tflib.Network('lpips', func_name='inclusivegan_amd.metrics.lpips.vgg16_zhang_perceptual', resolution=resolution, device='cpu', seed=3)
+    gp = {n: v.detach().clone().requires_grad_(v.requires_grad) for n, v in G.vars.items()}
+    dp = {n: v.detach().clone().requires_grad_(v.requires_grad) for n, v in D.vars.items()}
+    lp = {n: v.detach() for n, v in Lp.vars.items()}
+    cfg = dict(resolution=resolution, num_channels=3, fmap_base=8192, G_arch='skip', D_arch='resnet', fused_modconv=False)
+    rand = SeededRandom(0)
+    g = torch.Generator().manual_seed(1)
+    reals = lambda n: torch.rand(n, 3, resolution, resolution, generator=g) * 2 - 1
+    lat = lambda n: torch.nn.functional.normalize(torch.randn(n, 512, generator=g), dim=1)
+    t0 = time.time()
+    loss, _, _ = OL.G_loss(gp, {k: v.detach() for k, v in dp.items()}, lp, cfg, rand, batch, reals(batch), lat(batch), reals(batch), lat(batch),
+                           lpips_weight, phase='loss', state={})
+    torch.autograd.grad(loss.mean(), [p for p in gp.values() if p.requires_grad], allow_unused=True)
+    loss, _, _ = OL.D_loss({k: v.detach() for k, v in gp.items()}, dp, cfg, rand, batch, reals(2 * batch), gamma=100, phase='loss', state={})
+    torch.autograd.grad(loss.mean(), [p for p in dp.values() if p.requires_grad], allow_unused=True)
+    dt = time.time() - t0
+    return dict(value=round(2 * batch / dt, 4), unit='img/s', cores=cores, kind='port',
+                sample='1 iteration (G step + D step, forward+backward, no lazy-reg steps) at minibatch_gpu=%d, %dx%d, PyTorch-CPU fp32 oracle, %.1f s' % (batch, resolution, resolution, dt))
+
+
+def main():
+    args = parse_args()
+    import torch
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.distributed.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+
+    from inclusivegan_amd import _abi
+    _abi.get_plugin()   # fail loudly if the HIP extension is missing
+    from inclusivegan_amd.dnnlib import EasyDict
+    from inclusivegan_amd.training import training_loop as TL
+
+    B = args.minibatch_gpu
+    state = dict(t_start=None, t_end=None, refresh=[], iters=0)
+
+    def barrier_sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    def on_iteration(info):
+        state['iters'] += 1
+        if state['iters'] == args.warmup:
+            barrier_sync()
+            state['t_start'] = time.perf_counter()
+        if state['iters'] == args.warmup + args.steps:
+            barrier_sync()
+            state['t_end'] = time.perf_counter()
+            return True
+        return False
+
+    if args.warmup == 0:
+        raise SystemExit('--warmup must be >= 1 (the first iteration carries the IMLE refresh)')
+
+    kwargs = dict(
+        G_args=EasyDict(func_name='training.networks_stylegan2.G_main', init_mul=1.0, fmap_base=8 << 10, architecture='skip'),
+        D_args=EasyDict(func_name='training.networks_stylegan2.D_stylegan2_feature', fmap_base=8 << 10, architecture='resnet'),
+        G_opt_args=EasyDict(beta1=0.0, beta2=0.99, epsilon=1e-8), D_opt_args=EasyDict(beta1=0.0, beta2=0.99, epsilon=1e-8),
+        G_loss_args=EasyDict(func_name='training.loss.G_logistic_ns_rec_interp_arb_pathreg', NN_rec_lpips_weight=args.lpips_weight),
+        D_loss_args=EasyDict(func_name='training.loss.D_logistic_r1', gamma=100),
+        dataset_args=EasyDict(resolution=args.resolution, num_channels=3, label_size=40, label_kind='attributes'),
+        sched_args=EasyDict(G_lrate_base=0.002, D_lrate_base=0.002, minibatch_gpu_base=B, minibatch_size_base=B * world),
+        tf_config={'rnd.np_random_seed': 1000},
+        total_kimg=10 ** 6, data_size=args.data_size, num_epochs=10000,
+        init_staleness=10, num_samples_factor=args.num_samples_factor, knn_perturb_factor=0.05, candidate_batch_size=256,
+        hooks=dict(on_iteration=on_iteration, on_refresh=lambda s: state['refresh'].append(s)),
+    )
+    TL.training_loop(**kwargs)
+
+    elapsed = torch.tensor([state['t_end'] - state['t_start']], device=device, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(elapsed, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+    imgs = 2 * B * world * args.steps
+    out = {
+        'metric': 'training img/sec (whole node), CelebA 128x128 StyleGAN2+IMLE',
+        'value': round(imgs / elapsed, 3), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'CelebA-shaped %dx%d StyleGAN2+IMLE, config-e-Gskip-Dresnet (fmap_base 8192), minibatch_gpu %d, '
+                               'NN_rec_lpips_weight %g, lazy reg G/4 D/16, random-init weights' % (args.resolution, args.resolution, B, args.lpips_weight),
+                   'global_batch': B * world, 'images_per_step': 2 * B * world, 'parallelism': 'dp%d' % world,
+                   'data_size': args.data_size, 'num_samples_factor': args.num_samples_factor},
+        'imle_refresh_s': round(state['refresh'][0], 3) if state['refresh'] else None,
+    }
+    if rank == 0:
+        if not args.no_roofline:
+            out['roofline'] = conv_roofline(device, B)
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args.resolution, B, args.lpips_weight)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -197,14 +197,17 @@ int igan_mbstd_bwd(igan_stream_t stream, const float* x, const float* dy, float*
  * the lower index, so the result is deterministic.
  * qnorm / cnorm are the squared row norms (igan_row_sqnorm, fp64 accumulate);
  * the dot products run on the exact-fp32 MFMA and |q|^2 + |c|^2 - 2 q.c is combined
- * in fp64 before rounding to fp32.  The caller takes sqrt (Euclidean distance,
- * dci_code/src/util.c:62-69) when unpacking.
+ * in fp64 before rounding to fp32 (absolute error in the squared distance ~1e-6 * (|q|^2+|c|^2)).
+ * With refine != 0, every query whose running best came from THIS batch gets that distance
+ * recomputed as a direct difference in fp64 (exactly compute_dist, dci_code/src/util.c:62-69),
+ * so the distances finally reported for the winners carry no cancellation error.  The caller
+ * takes sqrt (Euclidean distance) when unpacking.
  */
 int igan_row_sqnorm(igan_stream_t stream, const float* a, float* out, int rows, int dim);
 int igan_nn1_update(igan_stream_t stream, const float* query, const float* qnorm,
                     const float* cand, const float* cnorm, unsigned long long* best,
                     float* dots /* caller workspace, nq*nc floats */,
-                    int nq, int nc, int dim, int idx_base);
+                    int nq, int nc, int dim, int idx_base, int refine);
 
 /* ------------------------------------------------------------------------
  * Flat-bucket optimizer step (dnnlib/tflib/optimizer.py:237-239,318-332):

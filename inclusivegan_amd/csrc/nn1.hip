@@ -59,6 +59,33 @@ __global__ __launch_bounds__(256) void nn1_fold_kernel(const float* dots, const 
     }
 }
 
+// Winners that come from THIS candidate batch get their distance recomputed as a direct
+// difference (fp64 accumulation, like compute_dist in dci_code/src/util.c:62-69), removing the
+// cancellation error of the |q|^2 + |c|^2 - 2 q.c form for close pairs.  One wavefront per query;
+// queries whose best did not change in this batch exit immediately (wave-uniform branch).
+__global__ __launch_bounds__(256) void nn1_refine_kernel(const float* query, const float* cand, unsigned long long* best,
+                                                         int nq, int nc, int dim, int idx_base) {
+    const int q = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (q >= nq) return;
+    const unsigned long long cur = best[q];
+    const long long idx = (long long)(cur & 0xFFFFFFFFull) - idx_base;
+    if (idx < 0 || idx >= nc) return;
+    const float* a = query + (size_t)q * dim;
+    const float* b = cand + (size_t)idx * dim;
+    double s = 0.0;
+    for (int i = lane; i < dim; i += 64) {
+        const double d = (double)a[i] - (double)b[i];
+        s += d * d;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) {
+        const float f = (float)s;
+        best[q] = ((unsigned long long)__float_as_uint(f) << 32) | (cur & 0xFFFFFFFFull);
+    }
+}
+
 }  // namespace
 
 extern "C" int igan_row_sqnorm(igan_stream_t stream_, const float* a, float* out, int rows, int dim) {
@@ -73,7 +100,7 @@ extern "C" int igan_row_sqnorm(igan_stream_t stream_, const float* a, float* out
 
 extern "C" int igan_nn1_update(igan_stream_t stream_, const float* query, const float* qnorm,
                                const float* cand, const float* cnorm, unsigned long long* best,
-                               float* dots, int nq, int nc, int dim, int idx_base) {
+                               float* dots, int nq, int nc, int dim, int idx_base, int refine) {
     using namespace igan;
     IGAN_REQUIRE(query && qnorm && cand && cnorm && best && dots, "nn1_update: null buffer");
     IGAN_REQUIRE(nq >= 1 && nc >= 1 && dim >= 1, "nn1_update: sizes must be positive");
@@ -91,5 +118,9 @@ extern "C" int igan_nn1_update(igan_stream_t stream_, const float* query, const 
     const int grid = ceil_div(nq, 4);
     hipLaunchKernelGGL(nn1_fold_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream_, dots, qnorm, cnorm, best, nq, nc, idx_base);
     IGAN_LAUNCH_CHECK("nn1_fold launch");
+    if (refine) {
+        hipLaunchKernelGGL(nn1_refine_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream_, query, cand, best, nq, nc, dim, idx_base);
+        IGAN_LAUNCH_CHECK("nn1_refine launch");
+    }
     return IGAN_OK;
 }

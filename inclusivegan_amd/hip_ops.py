@@ -531,7 +531,7 @@ def row_sqnorm_raw(a):
     return out
 
 
-def nn1_update_raw(query, qnorm, cand, cnorm, best, idx_base):
+def nn1_update_raw(query, qnorm, cand, cnorm, best, idx_base, refine=True):
     """Fold one candidate batch into the running packed (dist2, idx) minimum `best` (int64 view of uint64)."""
     lib = _abi.get_plugin()
     _require_cuda_f32(query, qnorm, cand, cnorm)
@@ -539,7 +539,7 @@ def nn1_update_raw(query, qnorm, cand, cnorm, best, idx_base):
     nc = cand.shape[0]
     dots = torch.empty((nq, nc), device=query.device, dtype=torch.float32)
     _abi.check(lib.igan_nn1_update(_stream(), _ptr(query), _ptr(qnorm), _ptr(cand), _ptr(cnorm), _ptr(best), _ptr(dots),
-                                   nq, nc, dim, idx_base))
+                                   nq, nc, dim, idx_base, 1 if refine else 0))
 
 
 def finite_check_raw(g, flag):

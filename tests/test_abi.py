@@ -1,0 +1,93 @@
+"""CPU: the C-ABI library loads without a GPU and exports every symbol include/igan_hip.h declares;
+argument validation returns the reference's error class before anything touches a device."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'igan_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(igan_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    from inclusivegan_amd import _abi
+    lib = _abi.get_plugin()
+    declared = _declared_symbols()
+    assert len(declared) >= 17
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert sorted(_abi.SIGNATURES) == declared
+    assert lib.igan_abi_version() == 1
+
+
+def test_struct_layouts_match_header_field_order():
+    from inclusivegan_amd import _abi
+    text = open(os.path.join(ROOT, 'include', 'igan_hip.h')).read()
+    for cname, cls in [('igan_upfirdn2d_params', _abi.UpFirDn2DParams), ('igan_fused_bias_act_params', _abi.FusedBiasActParams),
+                       ('igan_conv2d_params', _abi.Conv2DParams), ('igan_conv2d_wgrad_params', _abi.Conv2DWgradParams)]:
+        body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (cname, cname), text, flags=re.S).group(1)
+        body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+        names = []
+        for decl in body.split(';'):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(','):
+                names.append(re.findall(r'([A-Za-z_0-9]+)\s*$', part.strip())[0])
+        assert names == [f[0] for f in cls._fields_], cname
+
+
+def test_invalid_arguments_are_rejected_without_a_device():
+    from inclusivegan_amd import _abi
+    lib = _abi.get_plugin()
+    k = np.ones((4, 4), np.float32)
+    dummy = ctypes.c_void_p(16)   # never dereferenced: validation fails first
+    p = _abi.UpFirDn2DParams(x=16, k=k.ctypes.data, y=16, upx=0, upy=1, downx=1, downy=1, padx0=0, padx1=0, pady0=0, pady1=0,
+                             majorDim=1, inH=4, inW=4, minorDim=4, kernelH=4, kernelW=4, outH=1, outW=1)
+    assert lib.igan_upfirdn2d(None, ctypes.byref(p)) == _abi.IGAN_ERR_INVALID_ARGUMENT
+    assert b'upx and upy must be at least 1x1' in lib.igan_last_error()
+    with pytest.raises(ValueError):
+        _abi.check(_abi.IGAN_ERR_INVALID_ARGUMENT)
+    p.upx = 1
+    p.padx0 = -8
+    assert lib.igan_upfirdn2d(None, ctypes.byref(p)) == _abi.IGAN_ERR_INVALID_ARGUMENT
+    assert b'output must be at least 1x1' in lib.igan_last_error()
+    fp = _abi.FusedBiasActParams(x=16, b=None, ref=None, y=16, grad=1, act=3, alpha=0.2, gain=1.0, sizeX=8, sizeB=0, stepB=1)
+    assert lib.igan_fused_bias_act(None, ctypes.byref(fp)) == _abi.IGAN_ERR_INVALID_ARGUMENT   # ref missing for grad=1
+    cp = _abi.Conv2DParams(x=16, w=16, y=16, N=1, H=4, W=4, Cin=4, OH=4, OW=4, Cout=4, KH=3, KW=3, stride=2, up=2, pad_y=1, pad_x=1)
+    assert lib.igan_conv2d(None, ctypes.byref(cp)) == _abi.IGAN_ERR_INVALID_ARGUMENT
+    cp.stride = 1; cp.up = 3
+    assert lib.igan_conv2d(None, ctypes.byref(cp)) == _abi.IGAN_ERR_UNSUPPORTED
+    del dummy
+
+
+def test_plans_are_host_only():
+    from inclusivegan_amd import _abi
+    lib = _abi.get_plugin()
+    # 4x4 layer of config-e at batch 6: M = 96 -> must be split along K; 128x128 layer: no split
+    small = _abi.Conv2DParams(x=16, w=16, y=16, N=6, H=4, W=4, Cin=512, OH=4, OW=4, Cout=512, KH=3, KW=3, stride=1, up=1, pad_y=1, pad_x=1)
+    big = _abi.Conv2DParams(x=16, w=16, y=16, N=6, H=128, W=128, Cin=128, OH=128, OW=128, Cout=128, KH=3, KW=3, stride=1, up=1, pad_y=1, pad_x=1)
+    s, ws = ctypes.c_int(), ctypes.c_size_t()
+    assert lib.igan_conv2d_plan(ctypes.byref(small), ctypes.byref(s), ctypes.byref(ws)) == 0
+    assert s.value > 1 and ws.value == s.value * 6 * 16 * 512
+    assert lib.igan_conv2d_plan(ctypes.byref(big), ctypes.byref(s), ctypes.byref(ws)) == 0
+    assert s.value == 1 and ws.value == 0
+    wg = _abi.Conv2DWgradParams(x=16, dy=16, dw=16, N=6, H=128, W=128, Cin=128, OH=128, OW=128, Cout=128, KH=3, KW=3, stride=1, up=1, pad_y=1, pad_x=1)
+    assert lib.igan_conv2d_wgrad_plan(ctypes.byref(wg), ctypes.byref(s), ctypes.byref(ws)) == 0
+    assert s.value > 1 and ws.value == s.value * 9 * 128 * 128
+
+
+def test_no_cpu_fallback():
+    import torch
+    from inclusivegan_amd import hip_ops
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        hip_ops.upfirdn2d_raw(torch.zeros(1, 4, 4, 4), np.ones((4, 4), np.float32), 1, 1, 1, 1, 0, 0, 0, 0)
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        hip_ops.conv2d_raw(torch.zeros(1, 4, 4, 4), torch.zeros(3, 3, 4, 4), hip_ops.ConvGeom(3, 3, 1, 1, 1, 1), (4, 4), 4)

@@ -1,0 +1,201 @@
+"""GPU parity of the full G / D / loss / optimizer path against the CPU oracle, on
+Stacked-MNIST-shaped inputs (32x32) with reduced channel widths so the fp64 oracle runs in seconds.
+Random draws made by the HIP path are recorded and replayed into the oracle (RNG parity with TF is
+impossible, SURVEY.md section 7, so every random tensor is injected).
+
+Tolerances: network outputs / loss scalars 1e-4 relative (fp32 HIP vs fp64 oracle through ~20
+layers); parameter gradients 2e-3 relative to the largest entry of each tensor."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+RES = 32
+FMAP = 1024      # nf: 512,256,128,64,32 at 4..32  (config-e uses 8192)
+
+
+def _nets(dev, label_size=0):
+    from inclusivegan_amd.dnnlib import tflib
+    kw = dict(num_channels=3, resolution=RES, label_size=label_size, fmap_base=FMAP, device=dev)
+    G = tflib.Network('G', func_name='inclusivegan_amd.training.networks_stylegan2.G_main', architecture='skip', seed=11, **kw)
+    D = tflib.Network('D', func_name='inclusivegan_amd.training.networks_stylegan2.D_stylegan2_feature', architecture='resnet', seed=12, **kw)
+    rng = np.random.RandomState(0)
+    with torch.no_grad():   # biases / noise strengths are zero-initialised; make them matter
+        for net in (G, D):
+            for n, v in net.vars.items():
+                if n.endswith('bias') or n.endswith('noise_strength'):
+                    v.copy_(torch.from_numpy(rng.randn(*v.shape).astype(np.float32) * 0.1).to(dev))
+    return G, D
+
+
+def _oracle_params(net, dtype=torch.float64):
+    p = {n: v.detach().to(dtype).cpu() for n, v in net.vars.items()}
+    for n in net.trainables:
+        p[n].requires_grad_(True)
+    return p
+
+
+def test_generator_forward_matches_oracle(cuda_device):
+    from inclusivegan_amd.dnnlib.tflib import tfutil
+    from oracle import networks_stylegan2 as ON
+    from oracle.misc import Tape
+    G, _ = _nets(cuda_device)
+    z = torch.randn(4, 512, device=cuda_device)
+    lab = torch.zeros(4, 0, device=cuda_device)
+    gp = _oracle_params(G)
+    for training in (True, False):
+        rec = tfutil.RecordingRandom()
+        with tfutil.use_random(rec), torch.no_grad():
+            img = G.get_output_for(z, lab, is_training=training, is_validation=not training)
+        for fused in (True, False):
+            img_o = ON.G_main(gp, z.double().cpu(), Tape(rec.entries, torch.float64), RES, fmap_base=FMAP, architecture='skip',
+                              is_training=training, is_validation=not training, fused_modconv=fused)
+            assert rel_err(img, img_o) < 1e-4, (training, fused)
+
+
+def test_discriminator_forward_and_features(cuda_device):
+    from oracle import networks_stylegan2 as ON
+    _, D = _nets(cuda_device)
+    img = torch.randn(12, 3, RES, RES, device=cuda_device)
+    lab = torch.zeros(12, 0, device=cuda_device)
+    with torch.no_grad():
+        s, f = D.get_output_for(img, lab, is_training=True, return_features=True)
+        s2, f2 = D.get_output_for(img, lab, is_training=True)
+    assert f2 is None and torch.equal(s, s2)
+    so, fo = ON.D_stylegan2_feature(_oracle_params(D), img.double().cpu(), RES, fmap_base=FMAP, architecture='resnet')
+    assert rel_err(s, so) < 1e-4
+    assert tuple(f.shape) == tuple(fo.shape)
+    assert rel_err(f, fo) < 1e-4
+
+
+def _grad_errs(net, oparams):
+    errs = {}
+    for n, v in net.trainables.items():
+        go = oparams[n].grad
+        gh = v.grad
+        if go is None:
+            continue
+        errs[n] = rel_err(gh, go) if float(go.abs().max()) > 0 else float(gh.abs().max())
+    return errs
+
+
+def test_losses_and_gradients_match_oracle(cuda_device):
+    """G loss (rec + interp LPIPS + adversarial), G path-length reg, D loss, D R1 reg: values and the
+    gradients w.r.t. every trainable, including the second-order paths."""
+    from inclusivegan_amd.dnnlib import tflib
+    from inclusivegan_amd.dnnlib.tflib import tfutil
+    from inclusivegan_amd.training import loss as PL
+    from inclusivegan_amd.training.dataset import SyntheticDataset
+    from oracle import loss as OL
+    from oracle.misc import Tape
+    dev = cuda_device
+    G, D = _nets(dev)
+    lp = tflib.Network('lpips', func_name='inclusivegan_amd.metrics.lpips.vgg16_zhang_perceptual', resolution=RES, device=dev, seed=13)
+    ts = SyntheticDataset(resolution=RES, label_size=0, data_size=24, device=dev)
+    B = 4
+    g = torch.Generator().manual_seed(5)
+    reals1 = (torch.rand(B, 3, RES, RES, generator=g) * 2 - 1); reals2 = (torch.rand(B, 3, RES, RES, generator=g) * 2 - 1)
+    z1 = torch.nn.functional.normalize(torch.randn(B, 512, generator=g), dim=1); z2 = torch.nn.functional.normalize(torch.randn(B, 512, generator=g), dim=1)
+    lab = torch.zeros(B, 0, device=dev)
+    cfg = dict(resolution=RES, num_channels=3, fmap_base=FMAP, G_arch='skip', D_arch='resnet')
+    lpo = {n: v.detach().double().cpu() for n, v in lp.vars.items()}
+    cl = lambda t: t.to(dev).contiguous(memory_format=torch.channels_last)
+
+    for phase in ('loss', 'reg'):
+        G.zero_grad(); D.zero_grad()
+        D.requires_grad_(False)
+        rec = tfutil.RecordingRandom()
+        with tfutil.use_random(rec):
+            loss, reg = PL.G_logistic_ns_rec_interp_arb_pathreg(G, D, lp, ts, B, cl(reals1), lab, z1.to(dev), cl(reals2), lab, z2.to(dev),
+                                                                NN_rec_lpips_weight=2.5, phase=phase)
+        val = loss if phase == 'loss' else reg
+        torch.autograd.backward(val.mean(), inputs=list(G.trainables.values()))
+        D.requires_grad_(True)
+        gp = _oracle_params(G); dp = _oracle_params(D)
+        gp['dlatent_avg'] = torch.zeros_like(gp['dlatent_avg']) if phase == 'loss' else gp['dlatent_avg']
+        state = {}
+        if phase == 'reg':
+            # the HIP pass already moved dlatent_avg / pl_mean; the oracle must start from the pre-call state
+            pass
+        lo, ro, _ = OL.G_loss(gp, dp, lpo, cfg, Tape(rec.entries, torch.float64), B, reals1.double(), z1.double(), reals2.double(), z2.double(),
+                              2.5, phase=phase, state=state)
+        vo = lo if phase == 'loss' else ro
+        vo.mean().backward()
+        assert rel_err(val, vo) < 2e-4, phase
+        errs = _grad_errs(G, gp)
+        worst = max(errs, key=errs.get)
+        assert errs[worst] < 2e-3, (phase, worst, errs[worst])
+        G.pl_mean_var = torch.zeros((), device=dev)
+
+    for phase in ('loss', 'reg'):
+        G.zero_grad(); D.zero_grad()
+        reals = torch.rand(2 * B, 3, RES, RES, generator=g) * 2 - 1
+        lab2 = torch.zeros(2 * B, 0, device=dev)
+        rec = tfutil.RecordingRandom()
+        gp = _oracle_params(G); dp = _oracle_params(D)
+        with tfutil.use_random(rec):
+            loss, reg = PL.D_logistic_r1(G, D, ts, B, cl(reals), lab2, gamma=100, phase=phase)
+        val = loss if phase == 'loss' else reg
+        torch.autograd.backward(val.mean(), inputs=list(D.trainables.values()))
+        lo, ro, _ = OL.D_loss(gp, dp, cfg, Tape(rec.entries, torch.float64), B, reals.double(), gamma=100, phase=phase, state={})
+        vo = lo if phase == 'loss' else ro
+        vo.mean().backward()
+        assert rel_err(val, vo) < 2e-4, phase
+        errs = _grad_errs(D, dp)
+        worst = max(errs, key=errs.get)
+        assert errs[worst] < 2e-3, (phase, worst, errs[worst])
+
+
+def test_optimizer_step_and_ema_match_oracle(cuda_device):
+    """Optimizer.register_gradients/apply_updates (flat bucket, finite check, Adam with lazy-reg
+    beta scaling, shared slots) and Gs EMA against the NumPy SimpleAdam restatement."""
+    from inclusivegan_amd.dnnlib import tflib
+    from oracle import optimizer as OO
+    dev = cuda_device
+    G, _ = _nets(dev)
+    Gs = G.clone('Gs')
+    ema = Gs.setup_as_moving_average_of(G, beta=0.5 ** (12 / 10000.0))
+    c = 4 / 5
+    opt = tflib.Optimizer(name='TrainG', learning_rate=lambda: 0.002 * c, beta1=0.0 ** c, beta2=0.99 ** c, epsilon=1e-8)
+    reg_opt = tflib.Optimizer(name='RegG', share=opt, learning_rate=lambda: 0.002 * c, beta1=0.0 ** c, beta2=0.99 ** c, epsilon=1e-8)
+    w0 = G.flat_params.detach().cpu().numpy().copy()
+    adam = OO.SimpleAdam(w0.size, 0.002 * c, 0.0 ** c, 0.99 ** c, 1e-8)
+    wo = w0.copy(); gs_o = w0.copy()
+    for step, o in enumerate([opt, reg_opt, opt]):
+        loss = sum((p * p).sum() * (0.5 + 0.1 * step) for p in G.trainables.values())
+        o.register_gradients(loss, G)
+        g = G.flat_grads.detach().cpu().numpy().copy()
+        o.apply_updates()
+        ema()
+        adam.apply(wo, g)
+        gs_o = OO.ema(gs_o, wo, 0.5 ** (12 / 10000.0))
+    assert rel_err(G.flat_params, wo) < 2e-6
+    assert rel_err(Gs.flat_params, gs_o) < 2e-6
+
+
+def test_training_loop_runs_and_learns_shapes(cuda_device):
+    """A few iterations of the real loop on tiny synthetic data: the IMLE refresh, all four step kinds
+    (G, G-reg, D, D-reg) execute, parameters move, nothing becomes non-finite."""
+    from inclusivegan_amd.dnnlib import EasyDict
+    from inclusivegan_amd.training import training_loop as TL
+    seen = []
+    def on_it(info):
+        seen.append(info['cur_nimg'])
+        return len(seen) >= 3
+    refresh = []
+    out = TL.training_loop(
+        G_args=EasyDict(func_name='training.networks_stylegan2.G_main', fmap_base=512, architecture='skip'),
+        D_args=EasyDict(func_name='training.networks_stylegan2.D_stylegan2_feature', fmap_base=512, architecture='resnet'),
+        G_opt_args=EasyDict(beta1=0.0, beta2=0.99, epsilon=1e-8), D_opt_args=EasyDict(beta1=0.0, beta2=0.99, epsilon=1e-8),
+        G_loss_args=EasyDict(func_name='training.loss.G_logistic_ns_rec_interp_arb_pathreg', NN_rec_lpips_weight=2.5),
+        D_loss_args=EasyDict(func_name='training.loss.D_logistic_r1', gamma=100),
+        dataset_args=EasyDict(resolution=32, num_channels=3, label_size=10, label_kind='onehot'),
+        sched_args=EasyDict(minibatch_gpu_base=6, minibatch_size_base=6), tf_config={'rnd.np_random_seed': 1000},
+        total_kimg=1, data_size=48, num_samples_factor=4, init_staleness=10, knn_perturb_factor=0.05, candidate_batch_size=64,
+        hooks=dict(on_iteration=on_it, on_refresh=refresh.append))
+    assert seen == [12, 24, 36] and len(refresh) == 1
+    for net in (out['G'], out['D'], out['Gs']):
+        assert bool(torch.isfinite(net.flat_params).all())

@@ -1,0 +1,375 @@
+"""GPU parity tests of the HIP kernels (through the C ABI) against the CPU oracle.
+
+Tolerances (fp32 kernels vs an fp64 oracle evaluation of the same fp32 inputs), as relative
+max-abs error  max|hip - oracle| / max|oracle|:
+    streaming kernels (upfirdn2d, fused_bias_act, mbstd, Adam, EMA): <= 2e-6 .. 1e-5
+    MFMA convolutions (K up to ~4600 fp32 FMAs per output):           <= 3e-5
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import rel_err, to_nhwc_cuda
+
+pytestmark = pytest.mark.gpu
+
+
+# ----------------------------------------------------------------------------- upfirdn2d
+UPFIRDN_CASES = [
+    # (major, H, W, C, kshape, up, down, pad0, pad1)   call sites of config-e-Gskip-Dresnet + edge cases
+    (2, 17, 17, 8, 4, 1, 1, 1, 1),      # G Conv0_up post-filter
+    (2, 16, 16, 8, 4, 1, 1, 2, 2),      # D Conv1_down pre-filter
+    (2, 16, 16, 8, 4, 1, 1, 1, 1),      # D Skip pre-filter
+    (2, 8, 8, 3, 4, 2, 1, 2, 1),        # G RGB upsample_2d
+    (2, 16, 16, 3, 4, 1, 2, 1, 2),      # its gradient-like downsample
+    (1, 5, 7, 4, 3, 1, 1, 1, 1),        # 3x3 taps, ragged size (fast path, zero-extended taps)
+    (3, 9, 6, 5, 4, 1, 1, 0, 3),        # C % 4 != 0 -> generic path
+    (1, 6, 6, 4, 2, 2, 1, 1, 0),        # 2-tap upsample
+    (1, 12, 10, 4, 4, 1, 1, -1, 2),     # negative pad = crop
+    (2, 4, 4, 12, 4, 1, 1, 2, 2),       # outH < 8 -> small-strip variant
+    (1, 33, 31, 16, 4, 1, 1, 1, 1),     # strip tail (outH % 8 != 0)
+    (1, 7, 7, 4, 1, 1, 1, 0, 0),        # 1x1 filter
+    (1, 9, 9, 2, 6, 3, 2, 2, 3),        # up 3 / down 2 generic
+]
+
+
+@pytest.mark.parametrize('case', UPFIRDN_CASES)
+def test_upfirdn2d_forward_and_grads(case, cuda_device):
+    from oracle import upfirdn_2d as O
+    from inclusivegan_amd.dnnlib.tflib.ops.upfirdn_2d import upfirdn_2d
+    major, H, W, C, ks, up, down, p0, p1 = case
+    rng = np.random.RandomState(hash(case) % 2**31)
+    x = torch.from_numpy(rng.randn(major, H, W, C))
+    k = rng.rand(ks, ks).astype(np.float32) + 0.1
+    kw = dict(upx=up, upy=up, downx=down, downy=down, padx0=p0, padx1=p1, pady0=p0, pady1=p1)
+    xo = x.clone().requires_grad_(True)
+    yo = O.upfirdn_2d_ref(xo, k, **kw)
+    xg = x.to(torch.float32).to(cuda_device).requires_grad_(True)
+    yg = upfirdn_2d(xg, k, **kw)
+    assert tuple(yg.shape) == tuple(yo.shape)
+    assert rel_err(yg, yo) < 2e-6
+    # first and second order gradients (the op is linear: d/dx <dy, y> = op^T dy)
+    dy = torch.from_numpy(rng.randn(*yo.shape))
+    (gxo,) = torch.autograd.grad(yo, xo, dy, create_graph=True)
+    (gxg,) = torch.autograd.grad(yg, xg, dy.to(torch.float32).to(cuda_device), create_graph=True)
+    assert rel_err(gxg, gxo) < 2e-6
+    # differentiate the gradient w.r.t. dy direction: pass a second cotangent through the backward op
+    dyo = dy.clone().requires_grad_(True)
+    dyg = dy.to(torch.float32).to(cuda_device).requires_grad_(True)
+    (g2o,) = torch.autograd.grad(O.upfirdn_2d_ref(xo, k, **kw), xo, dyo, create_graph=True)
+    (g2g,) = torch.autograd.grad(upfirdn_2d(xg, k, **kw), xg, dyg, create_graph=True)
+    v = torch.from_numpy(rng.randn(*x.shape))
+    (ddo,) = torch.autograd.grad(g2o, dyo, v)
+    (ddg,) = torch.autograd.grad(g2g, dyg, v.to(torch.float32).to(cuda_device))
+    assert rel_err(ddg, ddo) < 2e-6
+
+
+def test_upfirdn2d_matches_loop_oracle_small(cuda_device):
+    from oracle import upfirdn_2d as O
+    from inclusivegan_amd.dnnlib.tflib.ops.upfirdn_2d import upfirdn_2d
+    rng = np.random.RandomState(5)
+    x = rng.randn(2, 6, 5, 4).astype(np.float32)
+    k = rng.rand(4, 4).astype(np.float32)
+    for kw in [dict(padx0=1, padx1=1, pady0=1, pady1=1), dict(upx=2, upy=2, padx0=2, padx1=1, pady0=2, pady1=1),
+               dict(downx=2, downy=2, padx0=1, padx1=1, pady0=1, pady1=1)]:
+        ref = O.upfirdn_2d_loops(x.astype(np.float64), k, **kw)
+        got = upfirdn_2d(torch.from_numpy(x).to(cuda_device), k, **kw)
+        assert rel_err(got, ref) < 2e-6
+
+
+def test_upfirdn2d_argument_errors(cuda_device):
+    from inclusivegan_amd import hip_ops
+    x = torch.zeros(1, 4, 4, 4, device=cuda_device)
+    k = np.ones((4, 4), np.float32)
+    with pytest.raises(ValueError):
+        hip_ops.upfirdn2d_raw(x, k, 1, 1, 1, 1, -10, 0, 0, 0)   # output must be at least 1x1
+    with pytest.raises(ValueError):
+        hip_ops.upfirdn2d_raw(x, np.ones((4,), np.float32), 1, 1, 1, 1, 0, 0, 0, 0)   # kernel must have rank 2
+
+
+# ----------------------------------------------------------------------------- fused_bias_act
+ACTS = ['linear', 'relu', 'lrelu', 'tanh', 'sigmoid', 'elu', 'selu', 'softplus', 'swish']
+
+
+@pytest.mark.parametrize('act', ACTS)
+@pytest.mark.parametrize('layout', ['nhwc4d', 'nchw4d', '2d', 'odd'])
+def test_fused_bias_act_forward_backward(act, layout, cuda_device):
+    from oracle import fused_bias_act as O
+    from inclusivegan_amd.dnnlib.tflib.ops.fused_bias_act import fused_bias_act
+    rng = np.random.RandomState(ACTS.index(act) * 7 + len(layout))
+    shape = {'nhwc4d': (3, 8, 5, 6), 'nchw4d': (3, 8, 5, 6), '2d': (5, 12), 'odd': (2, 3, 5, 7)}[layout]
+    x = torch.from_numpy(rng.randn(*shape))
+    b = torch.from_numpy(rng.randn(shape[1]))
+    xo = x.clone().requires_grad_(True); bo = b.clone().requires_grad_(True)
+    yo = O.fused_bias_act(xo, bo, act=act)
+    xg = x.to(torch.float32).to(cuda_device)
+    if layout == 'nhwc4d':
+        xg = xg.contiguous(memory_format=torch.channels_last)
+    xg = xg.requires_grad_(True)
+    bg = b.to(torch.float32).to(cuda_device).requires_grad_(True)
+    yg = fused_bias_act(xg, bg, act=act)
+    assert rel_err(yg, yo) < 1e-5
+    dy = torch.from_numpy(rng.randn(*shape))
+    gxo, gbo = torch.autograd.grad(yo, [xo, bo], dy)
+    if act == 'swish':
+        # Reference behaviour, not calculus: swish differentiates at ref = x, the op's *pre-bias* input
+        # (fused_bias_act.py:29,133; fused_bias_act.cu:109), so with a bias the reference's gradient is
+        # swish'(x), not swish'(x + b).  The product reproduces the reference.
+        gxo = O.fused_bias_act_kernel_ref(dy, None, x, 1, 9, 0.0, float(np.sqrt(2)), 1).reshape(shape)
+        gbo = gxo.sum(dim=[d for d in range(len(shape)) if d != 1])
+    gxg, gbg = torch.autograd.grad(yg, [xg, bg], dy.to(torch.float32).to(cuda_device))
+    assert rel_err(gxg, gxo) < 1e-5
+    assert rel_err(gbg, gbo) < 1e-5
+
+
+@pytest.mark.parametrize('act', ['linear', 'relu', 'lrelu'])
+def test_fused_bias_act_second_order(act, cuda_device):
+    from oracle import fused_bias_act as O
+    from inclusivegan_amd.dnnlib.tflib.ops.fused_bias_act import fused_bias_act
+    rng = np.random.RandomState(3)
+    x = torch.from_numpy(rng.randn(4, 8, 6, 6)); b = torch.from_numpy(rng.randn(8))
+    w = torch.from_numpy(rng.randn(4, 8, 6, 6))
+    def penalty(fba, x, b, w):
+        y = fba(x, b, act=act)
+        (gx,) = torch.autograd.grad((y * w).sum(), x, create_graph=True)   # R1-style: gradient norm penalty
+        return (gx * gx).sum() + (y * y).sum()
+    xo = x.clone().requires_grad_(True); bo = b.clone().requires_grad_(True)
+    po = penalty(O.fused_bias_act, xo, bo, w)
+    gxo, gbo = torch.autograd.grad(po, [xo, bo], allow_unused=True)
+    xg = x.float().to(cuda_device).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    bg = b.float().to(cuda_device).requires_grad_(True)
+    pg = penalty(fused_bias_act, xg, bg, w.float().to(cuda_device))
+    gxg, gbg = torch.autograd.grad(pg, [xg, bg], allow_unused=True)
+    assert rel_err(pg, po) < 1e-5
+    assert rel_err(gxg, gxo) < 1e-5
+    if gbo is not None:
+        assert rel_err(gbg, gbo) < 1e-5
+
+
+def test_fused_bias_act_kernel_table(cuda_device):
+    """grad = 0/1/2 kernels against the element-wise restatement of fused_bias_act.cu:64-111."""
+    from oracle import fused_bias_act as O
+    from inclusivegan_amd import hip_ops
+    rng = np.random.RandomState(11)
+    x = torch.from_numpy(rng.randn(6, 8).astype(np.float32)); ref = torch.from_numpy(rng.randn(6, 8).astype(np.float32) * 0.7)
+    b = torch.from_numpy(rng.randn(8).astype(np.float32))
+    for act_idx in range(1, 10):
+        for grad in (0, 1, 2):
+            want = O.fused_bias_act_kernel_ref(x.double(), b.double(), ref.double() if grad else None, grad, act_idx, 0.2, 1.3, 1)
+            got = hip_ops.fused_bias_act_raw(x.to(cuda_device), b.to(cuda_device), ref.to(cuda_device) if grad else None,
+                                             grad, act_idx, 0.2, 1.3, 8, 1)
+            assert rel_err(got.reshape(-1), want) < 1e-5, (act_idx, grad)
+
+
+# ----------------------------------------------------------------------------- conv2d family
+def _conv_oracle(x, w, stride, up, pad, out_hw):
+    """Direct statement of include/igan_hip.h's conv formula with torch ops (fp64)."""
+    import torch.nn.functional as F
+    n, c, h, wd = x.shape
+    if up > 1:
+        xu = torch.zeros(n, c, (h - 1) * up + 1, (wd - 1) * up + 1, dtype=x.dtype)
+        xu[:, :, ::up, ::up] = x
+    else:
+        xu = x
+    kh, kw = w.shape[0], w.shape[1]
+    oh, ow = out_hw
+    need_h = (oh - 1) * stride + kh
+    need_w = (ow - 1) * stride + kw
+    pad_b = max(need_h - pad - xu.shape[2], 0)
+    pad_r = max(need_w - pad - xu.shape[3], 0)
+    xp = F.pad(xu, [pad, pad_r, pad, pad_b])
+    y = F.conv2d(xp, w.permute(3, 2, 0, 1), stride=stride)
+    return y[:, :, :oh, :ow]
+
+
+CONV_CASES = [
+    # (N, Cin, H, W, Cout, K, stride, up, pad, out)   out=None -> derived
+    (2, 32, 8, 8, 64, 3, 1, 1, 1, None),     # SAME 3x3
+    (2, 16, 9, 7, 40, 3, 1, 1, 1, None),     # ragged sizes, Cout % 32 != 0
+    (3, 512, 4, 4, 512, 3, 1, 1, 1, None),   # 4x4 layer shape (split-K path)
+    (2, 48, 6, 6, 3, 1, 1, 1, 0, None),      # ToRGB 1x1, Cout = 3
+    (2, 3, 16, 16, 32, 1, 1, 1, 0, None),    # FromRGB 1x1, Cin = 3
+    (2, 24, 5, 5, 36, 3, 1, 2, 2, 11),       # transposed conv (up 2): (H-1)*2+3
+    (1, 64, 8, 8, 128, 3, 1, 2, 2, 17),
+    (2, 20, 11, 11, 28, 3, 2, 1, 0, 5),      # VALID stride 2
+    (2, 16, 9, 9, 24, 1, 2, 1, 0, 5),        # 1x1 stride 2 (D Skip)
+    (6, 513, 4, 4, 512, 3, 1, 1, 1, None),   # after mbstd: Cin = 513
+    (7, 64, 1, 1, 40, 1, 1, 1, 0, None),     # dense layer as 1x1 conv, M = 7
+    (2, 3, 12, 12, 64, 3, 1, 1, 1, None),    # VGG conv1_1
+    (1, 128, 32, 32, 128, 3, 1, 1, 1, None), # bigger tile grid
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv2d_forward_dgrad_wgrad(case, cuda_device):
+    from inclusivegan_amd import hip_ops
+    N, Cin, H, W, Cout, K, stride, up, pad, out = case
+    rng = np.random.RandomState(abs(hash(case)) % 2**31)
+    if out is None:
+        oh, ow = H, W
+    else:
+        oh = out
+        ow = out if H == W else None
+    if ow is None:
+        ow = W
+    x = torch.from_numpy(rng.randn(N, Cin, H, W).astype(np.float32))
+    w = torch.from_numpy((rng.randn(K, K, Cin, Cout) / np.sqrt(K * K * Cin)).astype(np.float32))
+    xo = x.double().requires_grad_(True); wo = w.double().requires_grad_(True)
+    yo = _conv_oracle(xo, wo, stride, up, pad, (oh, ow))
+    xg = to_nhwc_cuda(x, cuda_device).requires_grad_(True)
+    wg = w.to(cuda_device).requires_grad_(True)
+    geom = hip_ops.ConvGeom(K, K, stride, up, pad, pad)
+    yg = hip_ops.conv2d(xg, wg, geom, (oh, ow))
+    assert tuple(yg.shape) == tuple(yo.shape)
+    assert rel_err(yg, yo) < 3e-5
+    dy = torch.from_numpy(rng.randn(*yo.shape).astype(np.float32))
+    gxo, gwo = torch.autograd.grad(yo, [xo, wo], dy.double())
+    gxg, gwg = torch.autograd.grad(yg, [xg, wg], to_nhwc_cuda(dy, cuda_device))
+    assert rel_err(gxg, gxo) < 3e-5
+    assert rel_err(gwg, gwo) < 3e-5
+
+
+def test_conv2d_double_backward(cuda_device):
+    """R1-style penalty through conv (needs d(dgrad)/dw and d(dgrad)/d(dy))."""
+    from inclusivegan_amd import hip_ops
+    rng = np.random.RandomState(2)
+    for (stride, up, pad, H, out) in [(1, 1, 1, 8, 8), (2, 1, 0, 9, 4), (1, 2, 2, 5, 11)]:
+        x = torch.from_numpy(rng.randn(2, 16, H, H).astype(np.float32))
+        w = torch.from_numpy((rng.randn(3, 3, 16, 24) / 12).astype(np.float32))
+        def pen(conv, x, w):
+            y = conv(x, w)
+            (gx,) = torch.autograd.grad((y * y).sum() * 0.5, x, create_graph=True)
+            return (gx * gx).sum()
+        xo = x.double().requires_grad_(True); wo = w.double().requires_grad_(True)
+        po = pen(lambda a, b: _conv_oracle(a, b, stride, up, pad, (out, out)), xo, wo)
+        gxo, gwo = torch.autograd.grad(po, [xo, wo])
+        xg = to_nhwc_cuda(x, cuda_device).requires_grad_(True); wg = w.to(cuda_device).requires_grad_(True)
+        geom = hip_ops.ConvGeom(3, 3, stride, up, pad, pad)
+        pg = pen(lambda a, b: hip_ops.conv2d(a, b, geom, (out, out)), xg, wg)
+        gxg, gwg = torch.autograd.grad(pg, [xg, wg])
+        assert rel_err(pg, po) < 5e-5
+        assert rel_err(gxg, gxo) < 5e-5
+        assert rel_err(gwg, gwo) < 5e-5
+
+
+@pytest.mark.parametrize('mode', ['plain', 'up', 'down'])
+@pytest.mark.parametrize('demod', [True, False])
+def test_modconv_fused_scales(mode, demod, cuda_device):
+    """ModConv2dFn (scales folded into the MFMA kernel) == composite, values and all four gradients,
+    first order and through create_graph."""
+    from inclusivegan_amd import hip_ops
+    rng = np.random.RandomState(9)
+    N, Cin, Cout, H = 3, 20, 28, 6
+    geom, out = {'plain': (hip_ops.ConvGeom(3, 3, 1, 1, 1, 1), 6), 'up': (hip_ops.ConvGeom(3, 3, 1, 2, 2, 2), 13),
+                 'down': (hip_ops.ConvGeom(3, 3, 2, 1, 0, 0), 2)}[mode]
+    x = torch.from_numpy(rng.randn(N, Cin, H, H).astype(np.float32))
+    w = torch.from_numpy((rng.randn(3, 3, Cin, Cout) / 13).astype(np.float32))
+    s = torch.from_numpy((rng.randn(N, Cin) * 0.3 + 1).astype(np.float32))
+    d = torch.from_numpy((rng.rand(N, Cout) + 0.5).astype(np.float32)) if demod else None
+    def run(fn, create_graph):
+        xs = to_nhwc_cuda(x, cuda_device).requires_grad_(True); ws = w.to(cuda_device).requires_grad_(True)
+        ss = s.to(cuda_device).requires_grad_(True); ds = d.to(cuda_device).requires_grad_(True) if demod else None
+        y = fn(xs, ws, ss, ds)
+        ins = [xs, ws, ss] + ([ds] if demod else [])
+        dy = torch.from_numpy(np.random.RandomState(1).randn(*y.shape).astype(np.float32)).to(cuda_device)
+        gs = torch.autograd.grad(y, ins, dy, create_graph=create_graph)
+        return y, gs
+    y1, g1 = run(lambda a, b, c, e: hip_ops.ModConv2dFn.apply(a, b, c, e, geom, (out, out)), False)
+    y2, g2 = run(lambda a, b, c, e: hip_ops.modconv_composite(a, b, c, e, geom, (out, out)), False)
+    y3, g3 = run(lambda a, b, c, e: hip_ops.ModConv2dFn.apply(a, b, c, e, geom, (out, out)), True)
+    assert rel_err(y1, y2) < 3e-5
+    for a, b, c in zip(g1, g2, g3):
+        assert rel_err(a, b) < 5e-5
+        assert rel_err(c, b) < 5e-5
+
+
+# ----------------------------------------------------------------------------- minibatch stddev
+@pytest.mark.parametrize('N,G', [(6, 6), (12, 6), (4, 6), (8, 4)])
+def test_mbstd(N, G, cuda_device):
+    from oracle import networks_stylegan2 as ON
+    from inclusivegan_amd.training.networks_stylegan2 import minibatch_stddev_layer
+    rng = np.random.RandomState(N * 10 + G)
+    x = torch.from_numpy(rng.randn(N, 16, 4, 4))
+    xo = x.clone().requires_grad_(True)
+    yo = ON.minibatch_stddev_layer(xo, G)
+    xg = to_nhwc_cuda(x, cuda_device).requires_grad_(True)
+    yg = minibatch_stddev_layer(xg, G)
+    assert rel_err(yg, yo) < 1e-5
+    dy = torch.from_numpy(rng.randn(*yo.shape))
+    (gxo,) = torch.autograd.grad(yo, xo, dy, create_graph=True)
+    (gxg,) = torch.autograd.grad(yg, xg, to_nhwc_cuda(dy, cuda_device))
+    assert rel_err(gxg, gxo) < 1e-5
+    # second order
+    yg2 = minibatch_stddev_layer(xg, G)
+    (gxg2,) = torch.autograd.grad(yg2, xg, to_nhwc_cuda(dy, cuda_device), create_graph=True)
+    (hg,) = torch.autograd.grad((gxg2 * gxg2).sum(), xg)
+    (ho,) = torch.autograd.grad((gxo * gxo).sum(), xo)
+    assert rel_err(hg, ho) < 1e-4
+
+
+# ----------------------------------------------------------------------------- nearest neighbour
+def test_nn1_exact_vs_oracle_and_dci_golden(cuda_device):
+    import os
+    from oracle import nn as ONN
+    from inclusivegan_amd.dci_code.dci import DCI
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'dci_golden.npz'))
+    data, queries = g['data'], g['queries']
+    db = DCI(data.shape[1], 3, 15, device=cuda_device)
+    db.cand_chunk = 700     # force several candidate batches + a ragged tail
+    db.add(data, num_levels=3, field_of_view=10, prop_to_retrieve=0.002)
+    idx, dist = db.query(queries, num_neighbours=1, field_of_view=200, prop_to_retrieve=1.0)
+    idx = np.array([i[0] for i in idx]); dist = np.array([d[0] for d in dist])
+    oidx, odist = ONN.nearest_neighbour(data, queries)
+    assert idx.dtype == np.int32 and dist.dtype == np.float64
+    assert (idx == oidx).all()
+    assert np.abs(dist - odist).max() <= 1e-5 * odist.max()
+    # the reference's (approximate) DCI can never beat the exact search
+    assert (dist <= g['dist'] * (1 + 1e-4) + 1e-6).all()
+    assert (idx == g['idx']).mean() >= 0.9
+    db.reset()
+    assert db.num_points == 0
+
+
+def test_nn1_large_dim_and_ties(cuda_device):
+    from oracle import nn as ONN
+    from inclusivegan_amd.dci_code.dci import DCI
+    rng = np.random.RandomState(0)
+    data = rng.uniform(-1, 1, size=(300, 3 * 32 * 32)).astype(np.float32)
+    data[17] = data[5]                       # exact duplicate -> the lower index must win
+    q = data[[5, 100, 299]] + rng.randn(3, data.shape[1]).astype(np.float32) * 0.01
+    db = DCI(data.shape[1], device=cuda_device)
+    db.add(torch.from_numpy(data).to(cuda_device))
+    idx, dist = db.query(torch.from_numpy(q).to(cuda_device), num_neighbours=1)
+    oidx, odist = ONN.nearest_neighbour(data, q)
+    assert [int(i[0]) for i in idx] == [5, 100, 299] == list(oidx)
+    assert np.abs(np.array([d[0] for d in dist]) - odist).max() < 1e-5 * odist.max()   # refined: direct differences
+
+
+# ----------------------------------------------------------------------------- optimizer kernels
+def test_adam_ema_finite_check(cuda_device):
+    from oracle import optimizer as OO
+    from inclusivegan_amd import hip_ops
+    rng = np.random.RandomState(4)
+    n = 10007
+    w = rng.randn(n).astype(np.float32); m = np.zeros(n, np.float32)
+    wt = torch.from_numpy(w.copy()).to(cuda_device); mt = torch.zeros(n, device=cuda_device); vt = torch.zeros(n, device=cuda_device)
+    powt = torch.ones(2, device=cuda_device); flag = torch.zeros(1, dtype=torch.int32, device=cuda_device)
+    adam = OO.SimpleAdam(n, learning_rate=0.002 * 0.8, beta1=0.0, beta2=0.99 ** 0.8, epsilon=1e-8)
+    wo = w.copy()
+    for step in range(5):
+        g = rng.randn(n).astype(np.float32)
+        if step == 2:
+            g[123] = np.inf        # overflow step: skipped on both sides, beta powers must not advance
+        gt = torch.from_numpy(g).to(cuda_device)
+        flag.zero_()
+        hip_ops.finite_check_raw(gt, flag)
+        hip_ops.adam_step_raw(wt, gt, mt, vt, 0.002 * 0.8, 0.0, 0.99 ** 0.8, 1e-8, powt, flag)
+        applied = adam.apply(wo, g)
+        assert bool(flag.item()) == (not applied)
+    assert rel_err(wt, wo) < 2e-6
+    assert rel_err(vt, adam.v) < 2e-6
+    assert abs(float(powt[1]) - float(adam.b2pow)) < 1e-6
+    src = torch.from_numpy(rng.randn(n).astype(np.float32)).to(cuda_device)
+    dst0 = wt.clone()
+    hip_ops.ema_raw(wt, src, 0.9995)
+    assert rel_err(wt, OO.ema(dst0.cpu().numpy(), src.cpu().numpy(), 0.9995)) < 1e-6
