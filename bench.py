@@ -84,7 +84,7 @@ def cpu_baseline(resolution, batch, lpips_weight):
     from oracle import loss as OL
     from oracle.misc import SeededRandom
     from inclusivegan_amd.dnnlib import tflib
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     kw = dict(num_channels=3, resolution=resolution, label_size=0, fmap_base=8192, device='cpu')
     G = tflib.Network('G', func_name='inclusivegan_amd.training.networks_stylegan2.G_main', architecture='skip', seed=1, **kw)
@@ -107,6 +107,31 @@ def cpu_baseline(resolution, batch, lpips_weight):
     dt = time.time() - t0
     return dict(value=round(2 * batch / dt, 4), unit='img/s', cores=cores, kind='port',
                 sample='1 iteration (G step + D step, forward+backward, no lazy-reg steps) at minibatch_gpu=%d, %dx%d, PyTorch-CPU fp32 oracle, %.1f s' % (batch, resolution, resolution, dt))
+
+
+def cpu_baseline_subprocess(resolution, batch, lpips_weight, timeout_s=600):
+    """Runs cpu_baseline() in a child process that never touches HIP (devices hidden), with a time
+    limit, so that a slow host cannot hold the benchmark hostage."""
+    import subprocess
+    code = ('import json,sys; sys.path.insert(0, %r); import bench; '
+            'print("CPU_BASELINE " + json.dumps(bench.cpu_baseline(%d, %d, %r)))' % (ROOT, resolution, batch, lpips_weight))
+    env = dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
+    try:
+        r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=timeout_s, env=env)
+        for line in r.stdout.splitlines():
+            if line.startswith('CPU_BASELINE '):
+                return json.loads(line[len('CPU_BASELINE '):])
+        return dict(value=None, unit='img/s', cores=0, kind='port', sample='cpu baseline failed: %s' % r.stderr[-300:])
+    except subprocess.TimeoutExpired:
+        return dict(value=None, unit='img/s', cores=0, kind='port', sample='cpu baseline exceeded %d s' % timeout_s)
+
+
+def log(msg):
+    if int(os.environ.get('RANK', '0')) == 0:
+        print('[bench %7.1fs] %s' % (time.time() - _T0, msg), file=sys.stderr, flush=True)
+
+
+_T0 = time.time()
 
 
 def main():
@@ -137,6 +162,7 @@ def main():
 
     def on_iteration(info):
         state['iters'] += 1
+        log('iteration %d done' % state['iters'])
         if state['iters'] == args.warmup:
             barrier_sync()
             state['t_start'] = time.perf_counter()
@@ -160,9 +186,11 @@ def main():
         tf_config={'rnd.np_random_seed': 1000},
         total_kimg=10 ** 6, data_size=args.data_size, num_epochs=10000,
         init_staleness=10, num_samples_factor=args.num_samples_factor, knn_perturb_factor=0.05, candidate_batch_size=256,
-        hooks=dict(on_iteration=on_iteration, on_refresh=lambda s: state['refresh'].append(s)),
+        hooks=dict(on_iteration=on_iteration, on_refresh=lambda s: (state['refresh'].append(s), log('IMLE refresh %.1f s' % s))),
     )
+    log('starting training loop')
     TL.training_loop(**kwargs)
+    log('timed region done')
 
     elapsed = torch.tensor([state['t_end'] - state['t_start']], device=device, dtype=torch.float64)
     if world > 1:
@@ -182,9 +210,11 @@ def main():
     }
     if rank == 0:
         if not args.no_roofline:
+            log('timing the dominant kernel')
             out['roofline'] = conv_roofline(device, B)
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(args.resolution, B, args.lpips_weight)
+            log('timing the CPU oracle baseline')
+            out['cpu_baseline'] = cpu_baseline_subprocess(args.resolution, 2 if args.resolution >= 128 else B, args.lpips_weight)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()

@@ -20,7 +20,8 @@
  *   - return value 0 == IGAN_OK; on failure a thread-local message is available
  *     from igan_last_error() (invalid arguments mirror the reference's
  *     OP_REQUIRES checks, e.g. upfirdn_2d.cu:228-229,241-244,252,256,266);
- *   - element counts are limited to int32 like the reference (upfirdn_2d.cu:243).
+ *   - element counts are limited to int32 like the reference (upfirdn_2d.cu:243); operands the
+ *     conv / 1-NN kernels read through buffer descriptors are limited to 2 GiB each.
  *   - all activation tensors are fp32, channel-minor ("NHWC"): [N, H, W, C].
  */
 #ifndef IGAN_HIP_H
@@ -101,6 +102,21 @@ int igan_fused_bias_act(igan_stream_t stream, const igan_fused_bias_act_params* 
 size_t igan_bias_grad_workspace_floats(int sizeX, int sizeB, int stepB);
 int igan_bias_grad(igan_stream_t stream, const float* dx, float* db, float* partial,
                    int sizeX, int sizeB, int stepB);
+
+/* Fused synthesis-layer epilogue (training/networks_stylegan2.py:351-357) on channel-minor data
+ * x[rows = N*H*W][C], C % 4 == 0:
+ *     y = act(x + noise[row] * (*strength) + b[c]) * gain          act in {1 linear, 2 relu, 3 lrelu}
+ * noise/strength NULL -> plain apply_bias_act (networks_stylegan2.py:66-68).  The backward produces, in
+ * ONE pass over (dy, y):  dx = dy * gain * act'(y)   (FusedBiasAct grad=1 with ref = y),
+ *     db[c] = sum_rows dx   (fused_bias_act.py:137-146),   *dstrength = sum_rows noise[row] * sum_c dx.
+ * db / dstrength may be NULL when not wanted.  Deterministic; `workspace` holds
+ * igan_bias_act_noise_workspace_floats(rows, C) floats. */
+size_t igan_bias_act_noise_workspace_floats(int rows, int C);
+int igan_bias_act_noise_fwd(igan_stream_t stream, const float* x, const float* noise, const float* strength,
+                            const float* b, float* y, int rows, int C, int act, float alpha, float gain);
+int igan_bias_act_noise_bwd(igan_stream_t stream, const float* dy, const float* y, const float* noise,
+                            float* dx, float* db, float* dstrength, float* workspace,
+                            int rows, int C, int act, float alpha, float gain);
 
 /* ------------------------------------------------------------------------
  * conv2d (implicit GEMM on f32 MFMA, exact fp32 accumulate).

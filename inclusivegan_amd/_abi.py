@@ -83,6 +83,9 @@ SIGNATURES = {
     'igan_fused_bias_act': (_I, [_P, ctypes.POINTER(FusedBiasActParams)]),
     'igan_bias_grad_workspace_floats': (_SZ, [_I, _I, _I]),
     'igan_bias_grad': (_I, [_P, _P, _P, _P, _I, _I, _I]),
+    'igan_bias_act_noise_workspace_floats': (_SZ, [_I, _I]),
+    'igan_bias_act_noise_fwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F]),
+    'igan_bias_act_noise_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F]),
     'igan_conv2d_plan': (_I, [ctypes.POINTER(Conv2DParams), ctypes.POINTER(_I), ctypes.POINTER(_SZ)]),
     'igan_conv2d': (_I, [_P, ctypes.POINTER(Conv2DParams)]),
     'igan_conv2d_wgrad_plan': (_I, [ctypes.POINTER(Conv2DWgradParams), ctypes.POINTER(_I), ctypes.POINTER(_SZ)]),

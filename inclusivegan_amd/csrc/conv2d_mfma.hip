@@ -63,17 +63,32 @@ struct ConvArgs {
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ float4 f4mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 
-// Load 4 consecutive floats p[0..3] with element bound `left` (number of valid
-// elements starting at p; may be <= 0).  vec: pointer is 16 B aligned and the
-// four elements are all-in or all-out.
-__device__ __forceinline__ float4 load4(const float* p, int left, bool vec) {
-    if (vec) return (left > 0) ? *reinterpret_cast<const float4*>(p) : f4zero();
-    float4 r = f4zero();
-    if (left > 0) r.x = p[0];
-    if (left > 1) r.y = p[1];
-    if (left > 2) r.z = p[2];
-    if (left > 3) r.w = p[3];
-    return r;
+// Predicated operand loads through buffer descriptors: an out-of-range offset makes the hardware
+// return 0 for that lane, so padding taps, ragged tile edges and channel tails need no branch and no
+// select -- all of a chunk's loads issue back to back (a per-load exec-mask branch would serialise
+// them behind s_waitcnt).  Offsets are 32-bit bytes, hence the 2 GiB-per-operand limit in the ABI.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0x7FFFFFF0u;   // >= any num_records we create
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)bytes, 0x00020000);
+}
+
+// 4 consecutive floats at element offset `off`; elements at or beyond `left` (counted from off, may
+// be <= 0) read as 0.  VEC: off % 4 == 0, base 16 B aligned, all four in or all four out.
+template <bool VEC>
+__device__ __forceinline__ float4 load4(__amdgpu_buffer_rsrc_t r, int off, int left) {
+    if constexpr (VEC) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (left > 0) ? (unsigned)off * 4u : OOB, 0, 0);
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    } else {
+        float4 f;
+        f.x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (left > 0) ? (unsigned)(off + 0) * 4u : OOB, 0, 0));
+        f.y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (left > 1) ? (unsigned)(off + 1) * 4u : OOB, 0, 0));
+        f.z = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (left > 2) ? (unsigned)(off + 2) * 4u : OOB, 0, 0));
+        f.w = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (left > 3) ? (unsigned)(off + 3) * 4u : OOB, 0, 0));
+        return f;
+    }
 }
 
 // One chunk of MFMAs for this wave.  A image: [m][k] (A_KMAJOR = false, pitch LDK)
@@ -124,7 +139,7 @@ __device__ __forceinline__ void mma_chunk(const float* __restrict__ As, const fl
 // ------------------------------------------------------------------------------
 // Forward-type kernel (conv, transposed conv, dense, and all data gradients).
 // grid = (m tiles of the largest class, n tiles, classes * splits)
-template <int BM, int BN, int WM, int WN, bool WT>
+template <int BM, int BN, int WM, int WN, bool WT, bool VEC>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
@@ -202,11 +217,20 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     const int krow0 = WT ? 0 : (tid / NV);
     const int brow0 = tid >> 3;           // transposed layout: n row
 
-    float4 ra[AR], rb[BR];
+    float4 ra[AR], rsa[AR], rb[BR];
 
-    auto load_chunk = [&](int c) {
-        const int t = c / a.cpt;
-        const int ci0 = (c - t * a.cpt) * BK;
+    // (tap, channel-chunk) of the next chunk to load, advanced incrementally (no per-chunk division)
+    int ld_t = (c_begin < c_end) ? c_begin / a.cpt : 0;
+    int ld_cc = (c_begin < c_end) ? c_begin - ld_t * a.cpt : 0;
+    const bool has_in_scale = a.in_scale != nullptr;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, (unsigned)a.N * a.H * a.W * a.Cin * 4u);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.w, (unsigned)a.KH * a.KW * a.Cin * a.Cout * 4u);
+    // absent scale: zero records -> every load is out of range (no memory access), value unused
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(has_in_scale ? a.in_scale : a.x, has_in_scale ? (unsigned)a.N * a.Cin * 4u : 0u);
+
+    auto load_chunk = [&]() {
+        const int t = ld_t;
+        const int ci0 = ld_cc * BK;
         const int ta = t / nkx, tb = t - ta * nkx;
         const int ky = ky0 + (ta << a.up_shift), kx = kx0 + (tb << a.up_shift);
         const int ci = ci0 + 4 * kvec;
@@ -215,10 +239,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
             const int vy = rby[i] + ky, vx = rbx[i] + kx;
             const int iy = vy >> a.up_shift, ix = vx >> a.up_shift;
             const bool ok = rok[i] & (vy >= 0) & (vx >= 0) & (iy < a.H) & (ix < a.W);
-            const float* p = a.x + ((rn[i] * a.H + iy) * a.W + ix) * a.Cin + ci;
-            float4 v = load4(p, ok ? (a.Cin - ci) : 0, a.vecA);
-            if (a.in_scale) v = f4mul(v, load4(a.in_scale + rn[i] * a.Cin + ci, ok ? (a.Cin - ci) : 0, a.vecS));
-            ra[i] = v;
+            const int left = ok ? (a.Cin - ci) : 0;
+            ra[i] = load4<VEC>(rx, ((rn[i] * a.H + iy) * a.W + ix) * a.Cin + ci, left);
+            rsa[i] = load4<VEC>(rs, rn[i] * a.Cin + ci, left);   // multiplied in at store time (after the MFMAs)
         }
         if constexpr (!WT) {
 #pragma unroll
@@ -226,23 +249,23 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
                 const int kr = krow0 + KROWS * i;
                 const int cik = ci0 + kr;
                 const int co = n0 + 4 * nvec;
-                const float* p = a.w + ((ky * a.KW + kx) * a.Cin + cik) * a.Cout + co;
-                rb[i] = load4(p, (cik < a.Cin) ? (a.Cout - co) : 0, a.vecB);
+                rb[i] = load4<VEC>(rw, ((ky * a.KW + kx) * a.Cin + cik) * a.Cout + co, (cik < a.Cin) ? (a.Cout - co) : 0);
             }
         } else {
 #pragma unroll
             for (int i = 0; i < BR; i++) {
                 const int co = n0 + brow0 + 32 * i;
-                const float* p = a.w + (((a.KH - 1 - ky) * a.KW + (a.KW - 1 - kx)) * a.Cout + co) * a.Cin + ci;
-                rb[i] = load4(p, (co < a.Cout) ? (a.Cin - ci) : 0, a.vecB);
+                rb[i] = load4<VEC>(rw, (((a.KH - 1 - ky) * a.KW + (a.KW - 1 - kx)) * a.Cout + co) * a.Cin + ci, (co < a.Cout) ? (a.Cin - ci) : 0);
             }
         }
+        if (++ld_cc == a.cpt) { ld_cc = 0; ++ld_t; }
     };
     auto store_chunk = [&](int buf) {
         float* A = As + buf * A_ELEMS;
         float* B = Bs + buf * B_ELEMS;
 #pragma unroll
-        for (int i = 0; i < AR; i++) *reinterpret_cast<float4*>(A + (arow0 + 32 * i) * LDK + 4 * kvec) = ra[i];
+        for (int i = 0; i < AR; i++)
+            *reinterpret_cast<float4*>(A + (arow0 + 32 * i) * LDK + 4 * kvec) = has_in_scale ? f4mul(ra[i], rsa[i]) : ra[i];
         if constexpr (!WT) {
 #pragma unroll
             for (int i = 0; i < BR; i++) *reinterpret_cast<float4*>(B + (krow0 + KROWS * i) * LDB + 4 * nvec) = rb[i];
@@ -261,14 +284,14 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
             for (int r = 0; r < 16; r++) acc[tm][tn][r] = 0.0f;
 
     if (c_begin < c_end) {
-        load_chunk(c_begin);
+        load_chunk();
         store_chunk(0);
     }
     __syncthreads();
     for (int c = c_begin; c < c_end; c++) {
         const int cur = (c - c_begin) & 1;
         const bool more = (c + 1 < c_end);
-        if (more) load_chunk(c + 1);
+        if (more) load_chunk();
         mma_chunk<TM, TN, false, !WT, LDK, LDB>(As + cur * A_ELEMS, Bs + cur * B_ELEMS, acc,
                                                  wm * (BM / WM), wn * (BN / WN), l31, h);
         if (more) store_chunk(cur ^ 1);
@@ -333,7 +356,7 @@ struct WgradArgs {
     int vecA, vecB, vecSA, vecSB;
 };
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool VEC>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
@@ -372,7 +395,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int amv = tid % MV, aprow0 = tid / MV;
     const int bnv = tid % NV, bprow0 = tid / NV;
 
-    float4 ra[AR], rb[BR];
+    float4 ra[AR], rsa[AR], rb[BR], rsb[BR];
 
     auto decode = [&](int kp, int& nn, int& oy, int& ox) {
         nn = kp / (QH * QW);
@@ -381,42 +404,47 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         oy = qy * up + py;
         ox = qx * up + px;
     };
+    const bool has_in_scale = a.in_scale != nullptr, has_out_scale = a.out_scale != nullptr;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, (unsigned)a.N * a.H * a.W * a.Cin * 4u);
+    const __amdgpu_buffer_rsrc_t rdy = make_rsrc(a.dy, (unsigned)a.N * a.OH * a.OW * a.Cout * 4u);
+    const __amdgpu_buffer_rsrc_t rsi = make_rsrc(has_in_scale ? a.in_scale : a.x, has_in_scale ? (unsigned)a.N * a.Cin * 4u : 0u);
+    const __amdgpu_buffer_rsrc_t rso = make_rsrc(has_out_scale ? a.out_scale : a.dy, has_out_scale ? (unsigned)a.N * a.Cout * 4u : 0u);
     auto load_chunk = [&](int c) {
 #pragma unroll
         for (int i = 0; i < AR; i++) {
             const int kp = c * BK + aprow0 + AROWS * i;
             int nn = 0, oy = 0, ox = 0;
             const bool in = kp < Kpix;
-            if (in) decode(kp, nn, oy, ox);
+            decode(in ? kp : 0, nn, oy, ox);
             const int vy = oy * a.stride + ky - a.pad_y, vx = ox * a.stride + kx - a.pad_x;
             const int iy = vy >> a.up_shift, ix = vx >> a.up_shift;
             const bool ok = in & (vy >= 0) & (vx >= 0) & (iy < a.H) & (ix < a.W);
             const int ci = m0 + 4 * amv;
-            const float* p = a.x + ((nn * a.H + iy) * a.W + ix) * a.Cin + ci;
-            float4 v = load4(p, ok ? (a.Cin - ci) : 0, a.vecA);
-            if (a.in_scale) v = f4mul(v, load4(a.in_scale + nn * a.Cin + ci, ok ? (a.Cin - ci) : 0, a.vecSA));
-            ra[i] = v;
+            const int left = ok ? (a.Cin - ci) : 0;
+            ra[i] = load4<VEC>(rx, ((nn * a.H + iy) * a.W + ix) * a.Cin + ci, left);
+            rsa[i] = load4<VEC>(rsi, nn * a.Cin + ci, left);
         }
 #pragma unroll
         for (int i = 0; i < BR; i++) {
             const int kp = c * BK + bprow0 + BROWS * i;
             int nn = 0, oy = 0, ox = 0;
             const bool in = kp < Kpix;
-            if (in) decode(kp, nn, oy, ox);
+            decode(in ? kp : 0, nn, oy, ox);
             const int co = n0 + 4 * bnv;
-            const float* p = a.dy + ((nn * a.OH + oy) * a.OW + ox) * a.Cout + co;
-            float4 v = load4(p, in ? (a.Cout - co) : 0, a.vecB);
-            if (a.out_scale) v = f4mul(v, load4(a.out_scale + nn * a.Cout + co, in ? (a.Cout - co) : 0, a.vecSB));
-            rb[i] = v;
+            const int left = in ? (a.Cout - co) : 0;
+            rb[i] = load4<VEC>(rdy, ((nn * a.OH + oy) * a.OW + ox) * a.Cout + co, left);
+            rsb[i] = load4<VEC>(rso, nn * a.Cout + co, left);
         }
     };
     auto store_chunk = [&](int buf) {
         float* A = As + buf * A_ELEMS;
         float* B = Bs + buf * B_ELEMS;
 #pragma unroll
-        for (int i = 0; i < AR; i++) *reinterpret_cast<float4*>(A + (aprow0 + AROWS * i) * LDA + 4 * amv) = ra[i];
+        for (int i = 0; i < AR; i++)
+            *reinterpret_cast<float4*>(A + (aprow0 + AROWS * i) * LDA + 4 * amv) = has_in_scale ? f4mul(ra[i], rsa[i]) : ra[i];
 #pragma unroll
-        for (int i = 0; i < BR; i++) *reinterpret_cast<float4*>(B + (bprow0 + BROWS * i) * LDB + 4 * bnv) = rb[i];
+        for (int i = 0; i < BR; i++)
+            *reinterpret_cast<float4*>(B + (bprow0 + BROWS * i) * LDB + 4 * bnv) = has_out_scale ? f4mul(rb[i], rsb[i]) : rb[i];
     };
 
     f32x16 acc[TM][TN];
@@ -485,9 +513,10 @@ int fwd_geometry_check(const igan_conv2d_params* p) {
     IGAN_REQUIRE(p->stride >= 1 && p->up >= 1, "conv2d: stride and up must be at least 1");
     IGAN_REQUIRE(p->stride == 1 || p->up == 1, "conv2d: at most one of stride, up may exceed 1");
     if (!(p->up == 1 || p->up == 2)) return igan::fail(IGAN_ERR_UNSUPPORTED, "conv2d: up must be 1 or 2 (got %d)", p->up);
-    IGAN_REQUIRE((long long)p->N * p->H * p->W * p->Cin <= INT32_MAX, "conv2d: input too large");
+    // operands are addressed with 32-bit byte offsets through buffer descriptors: < 2 GiB each
+    IGAN_REQUIRE((long long)p->N * p->H * p->W * p->Cin * 4 <= 0x7FFFFFF0LL, "conv2d: input too large (2 GiB per operand)");
     IGAN_REQUIRE((long long)p->N * p->OH * p->OW * p->Cout <= INT32_MAX, "conv2d: output too large");
-    IGAN_REQUIRE((long long)p->KH * p->KW * p->Cin * p->Cout <= INT32_MAX, "conv2d: filter too large");
+    IGAN_REQUIRE((long long)p->KH * p->KW * p->Cin * p->Cout * 4 <= 0x7FFFFFF0LL, "conv2d: filter too large (2 GiB per operand)");
     return IGAN_OK;
 }
 
@@ -502,9 +531,14 @@ void fwd_counts(const igan_conv2d_params* p, int& Mmax, int& chunks_max, int& nc
 }
 
 template <int BM, int BN, int WM, int WN>
-void launch_fwd(hipStream_t stream, const ConvArgs& a, dim3 grid, bool wt) {
-    if (wt) hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, true>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, false>), grid, dim3(256), 0, stream, a);
+void launch_fwd(hipStream_t stream, const ConvArgs& a, dim3 grid, bool wt, bool vec) {
+    if (wt) {
+        if (vec) hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, true, true>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, true, false>), grid, dim3(256), 0, stream, a);
+    } else {
+        if (vec) hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, false, true>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, false, false>), grid, dim3(256), 0, stream, a);
+    }
 }
 
 }  // namespace
@@ -563,10 +597,11 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
 
     dim3 grid(ceil_div(Mmax, t.BM), ceil_div(p->Cout, t.BN), nclass * splits);
     const bool wt = p->w_transposed != 0;
-    if (t.BM == 128 && t.BN == 128) launch_fwd<128, 128, 2, 2>(stream, a, grid, wt);
-    else if (t.BM == 128 && t.BN == 64) launch_fwd<128, 64, 2, 2>(stream, a, grid, wt);
-    else if (t.BM == 128 && t.BN == 32) launch_fwd<128, 32, 4, 1>(stream, a, grid, wt);
-    else launch_fwd<32, 128, 1, 4>(stream, a, grid, wt);
+    const bool vec = a.vecA && a.vecB && (a.in_scale == nullptr || a.vecS);
+    if (t.BM == 128 && t.BN == 128) launch_fwd<128, 128, 2, 2>(stream, a, grid, wt, vec);
+    else if (t.BM == 128 && t.BN == 64) launch_fwd<128, 64, 2, 2>(stream, a, grid, wt, vec);
+    else if (t.BM == 128 && t.BN == 32) launch_fwd<128, 32, 4, 1>(stream, a, grid, wt, vec);
+    else launch_fwd<32, 128, 1, 4>(stream, a, grid, wt, vec);
     IGAN_LAUNCH_CHECK("conv2d launch");
 
     if (splits > 1) {
@@ -589,8 +624,8 @@ int wgrad_geometry_check(const igan_conv2d_wgrad_params* p) {
     IGAN_REQUIRE(p->stride >= 1 && p->up >= 1, "conv2d_wgrad: stride and up must be at least 1");
     IGAN_REQUIRE(p->stride == 1 || p->up == 1, "conv2d_wgrad: at most one of stride, up may exceed 1");
     if (!(p->up == 1 || p->up == 2)) return igan::fail(IGAN_ERR_UNSUPPORTED, "conv2d_wgrad: up must be 1 or 2 (got %d)", p->up);
-    IGAN_REQUIRE((long long)p->N * p->H * p->W * p->Cin <= INT32_MAX, "conv2d_wgrad: input too large");
-    IGAN_REQUIRE((long long)p->N * p->OH * p->OW * p->Cout <= INT32_MAX, "conv2d_wgrad: output too large");
+    IGAN_REQUIRE((long long)p->N * p->H * p->W * p->Cin * 4 <= 0x7FFFFFF0LL, "conv2d_wgrad: input too large (2 GiB per operand)");
+    IGAN_REQUIRE((long long)p->N * p->OH * p->OW * p->Cout * 4 <= 0x7FFFFFF0LL, "conv2d_wgrad: output gradient too large (2 GiB per operand)");
     IGAN_REQUIRE((long long)p->KH * p->KW * p->Cin * p->Cout <= INT32_MAX, "conv2d_wgrad: filter too large");
     return IGAN_OK;
 }
@@ -655,9 +690,17 @@ extern "C" int igan_conv2d_wgrad(igan_stream_t stream_, const igan_conv2d_wgrad_
 
     const WgTile t = pick_wg_tile(p->Cin, p->Cout);
     dim3 grid(ceil_div(p->Cin, t.BM), ceil_div(p->Cout, t.BN), p->KH * p->KW * splits);
-    if (t.BM == 128 && t.BN == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2>), grid, dim3(256), 0, stream, a);
-    else if (t.BM == 128 && t.BN == 32) hipLaunchKernelGGL((conv_wgrad_kernel<128, 32, 4, 1>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 4>), grid, dim3(256), 0, stream, a);
+    const bool vec = a.vecA && a.vecB && (a.in_scale == nullptr || a.vecSA) && (a.out_scale == nullptr || a.vecSB);
+    if (t.BM == 128 && t.BN == 128) {
+        if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, true>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, false>), grid, dim3(256), 0, stream, a);
+    } else if (t.BM == 128 && t.BN == 32) {
+        if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<128, 32, 4, 1, true>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<128, 32, 4, 1, false>), grid, dim3(256), 0, stream, a);
+    } else {
+        if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 4, true>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 4, false>), grid, dim3(256), 0, stream, a);
+    }
     IGAN_LAUNCH_CHECK("conv2d_wgrad launch");
     if (splits > 1) {
         const int total = (int)wsize;

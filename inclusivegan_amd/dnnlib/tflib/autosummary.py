@@ -1,7 +1,9 @@
 """Running means of training scalars, standing in for `dnnlib/tflib/autosummary.py:45-74`
 (`autosummary(name, value)` accumulates [count, sum] and ignores non-finite values, :64).
-Accumulation happens on the device without host synchronisation; `flush()` (called once per tick,
-training_loop.py:523) reads the means back and resets."""
+Accumulation happens on the device without host synchronisation, as in-place adds into
+accumulators that persist across flushes -- so the adds can be captured into a hipGraph and replayed
+(the accumulator must exist before capture: the loop runs its first iterations eagerly).
+`flush()` (called once per tick, training_loop.py:523) reads the means back and zeroes in place."""
 from collections import OrderedDict
 
 import torch
@@ -29,10 +31,11 @@ def autosummary(name, value):
 
 
 def flush():
-    """-> OrderedDict name -> mean; resets the accumulators."""
+    """-> OrderedDict name -> mean; zeroes the accumulators in place."""
     out = OrderedDict()
     for name, t in _acc.items():
         c, s = t.cpu().tolist()
-        out[name] = s / c if c > 0 else float('nan')
-    _acc.clear()
+        if c > 0:
+            out[name] = s / c
+        t.zero_()
     return out

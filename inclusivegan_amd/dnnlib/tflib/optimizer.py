@@ -68,6 +68,19 @@ class Optimizer:
         torch.autograd.backward(loss, inputs=params)
         self._num_registered += 1
 
+    def differentiate(self, loss, net):
+        """The device work of register_gradients() for ONE registration, without Python-side
+        bookkeeping: zero the bucket, backpropagate.  Safe to capture into a hipGraph; after each replay
+        call `mark_registered(net)` and then `apply_updates()`."""
+        self._bind(net)
+        net.flat_grads.zero_()
+        params = [p for p in net.trainables.values() if p.requires_grad]
+        torch.autograd.backward(loss, inputs=params)
+
+    def mark_registered(self, net, count=1):
+        self._bind(net)
+        self._num_registered = count
+
     def apply_updates(self, allow_no_op=False):
         if self._num_registered == 0:
             if allow_no_op:

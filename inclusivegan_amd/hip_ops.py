@@ -230,6 +230,92 @@ class FusedBiasActFn(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------
+# fused layer epilogue: noise + bias + activation (one pass forward, one pass backward)
+
+def _rows_c(x):
+    """(rows, C) of a channel-minor tensor: channels_last 4-D or plain 2-D; None if not eligible."""
+    if x.dim() == 4 and x.is_contiguous(memory_format=CL) and x.shape[1] % 4 == 0:
+        return x.shape[0] * x.shape[2] * x.shape[3], x.shape[1]
+    if x.dim() == 2 and x.is_contiguous() and x.shape[1] % 4 == 0:
+        return x.shape[0], x.shape[1]
+    return None
+
+
+def bias_act_noise_fwd_raw(x, noise, strength, b, act_idx, alpha, gain):
+    if _is_meta(x):
+        return torch.empty_like(x)
+    lib = _abi.get_plugin()
+    _require_cuda_f32(x, noise, strength, b)
+    rows, c = _rows_c(x)
+    y = torch.empty_like(x)
+    _abi.check(lib.igan_bias_act_noise_fwd(_stream(), _ptr(x), _ptr(noise), _ptr(strength), _ptr(b), _ptr(y),
+                                           rows, c, act_idx, float(alpha), float(gain)))
+    return y
+
+
+def bias_act_noise_bwd_raw(dy, y, noise, act_idx, alpha, gain, want_db):
+    lib = _abi.get_plugin()
+    _require_cuda_f32(dy, y, noise)
+    rows, c = _rows_c(y)
+    dy = _match_layout(dy, y)
+    dx = torch.empty_like(y)
+    ws = torch.empty((int(lib.igan_bias_act_noise_workspace_floats(rows, c)),), device=y.device, dtype=torch.float32)
+    db = torch.empty((c,), device=y.device, dtype=torch.float32) if want_db else None
+    ds = torch.empty((), device=y.device, dtype=torch.float32) if noise is not None else None
+    _abi.check(lib.igan_bias_act_noise_bwd(_stream(), _ptr(dy), _ptr(y), _ptr(noise), _ptr(dx), _ptr(db), _ptr(ds), _ptr(ws),
+                                           rows, c, act_idx, float(alpha), float(gain)))
+    return dx, db, ds
+
+
+class BiasActNoiseFn(torch.autograd.Function):
+    """y = act(x + noise * strength + b) * gain for act in {linear, relu, lrelu}; noise/strength may be
+    None.  First-order backward is the fused one-pass kernel; under create_graph it is written with the
+    closed `_FbaGradFn` / `_BiasGradFn` pair (piecewise-linear activations: nothing depends on x)."""
+
+    @staticmethod
+    def forward(ctx, x, b, noise, strength, act_idx, alpha, gain):
+        y = bias_act_noise_fwd_raw(x, noise, strength, b, act_idx, alpha, gain)
+        ctx.save_for_backward(y, noise)
+        ctx.cfg = (act_idx, alpha, gain)
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, noise = ctx.saved_tensors
+        act_idx, alpha, gain = ctx.cfg
+        need_b = ctx.has_b and ctx.needs_input_grad[1]
+        need_s = noise is not None and ctx.needs_input_grad[3]
+        if torch.is_grad_enabled():
+            c = y.shape[1]
+            dx = _FbaGradFn.apply(dy, None, y, 1, act_idx, alpha, gain, c, 1, True)
+            db = _BiasGradFn.apply(dx, 1, c, 1) if need_b else None
+            ds = (dx * noise.reshape(_noise_view(y))).sum() if need_s else None
+            return dx, db, None, ds, None, None, None
+        dx, db, ds = bias_act_noise_bwd_raw(dy, y, noise, act_idx, alpha, gain, need_b)
+        return dx, db, None, (ds if need_s else None), None, None, None
+
+
+def _noise_view(y):
+    return (y.shape[0], 1, y.shape[2], y.shape[3]) if y.dim() == 4 else (y.shape[0], 1)
+
+
+def bias_act_noise(x, b, noise, strength, act_idx, alpha, gain):
+    """Dispatch: the fused kernels when x is 2-D / 4-D with C % 4 == 0 (made channel-minor if it is
+    not), otherwise the general ops."""
+    if _is_meta(x):
+        return torch.empty_like(x)
+    if x.dim() in (2, 4) and x.shape[1] % 4 == 0:
+        x = nhwc(x) if x.dim() == 4 else x.contiguous()
+        if noise is not None:
+            noise = noise.expand(_noise_view(x)).contiguous()
+        return BiasActNoiseFn.apply(x, b, noise, strength, act_idx, alpha, gain)
+    if noise is not None:
+        x = x + noise * strength
+    return FusedBiasActFn.apply(x, b, 1, act_idx, alpha, gain, 'y', True)
+
+
+# ----------------------------------------------------------------------------
 # conv2d family
 
 # Geometry of y = conv(x, w): see include/igan_hip.h (igan_conv2d_params).
@@ -426,18 +512,31 @@ class ModConv2dFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w, s, d, y = ctx.saved_tensors
         geom = ctx.geom
-        if torch.is_grad_enabled():
-            with torch.enable_grad():
-                y2 = modconv_composite(x, w, s, d, geom, ctx.out_hw)
-                ins = [t for t, need in zip((x, w, s, d), ctx.needs_input_grad[:4]) if need and t is not None]
-                gs = torch.autograd.grad(y2, ins, dy, create_graph=True, allow_unused=True)
-            it = iter(gs)
-            outs = [next(it) if (need and t is not None) else None for t, need in zip((x, w, s, d), ctx.needs_input_grad[:4])]
-            return tuple(outs) + (None, None)
+        need_x, need_w, need_s, need_d = ctx.needs_input_grad[:4]
         in_hw = (x.shape[2], x.shape[3])
+        if torch.is_grad_enabled():
+            # create_graph=True: the partial derivatives w.r.t. (x, w, s, d) -- each treated as an
+            # independent input, although d is itself a function of (s, w) upstream -- written with
+            # differentiable pieces (the closed conv triple + elementwise ops), so that the result can
+            # be differentiated again.  (A nested autograd.grad over a recomputed forward would follow
+            # d's history into s and w and count that path twice.)
+            dx = dw = ds = dd = None
+            dyd = dy * d[:, :, None, None] if d is not None else dy
+            if need_x or need_s:
+                dxs = ConvDgradFn.apply(dyd, w, geom, in_hw)
+                if need_x:
+                    dx = dxs * s[:, :, None, None]
+                if need_s:
+                    ds = (dxs * x).sum(dim=(2, 3))
+            if need_w or (need_d and d is not None):
+                xs = x * s[:, :, None, None]
+                if need_w:
+                    dw = ConvWgradFn.apply(xs, dyd, geom)
+                if need_d and d is not None:
+                    dd = (dy * Conv2dFn.apply(xs, w, geom, ctx.out_hw)).sum(dim=(2, 3))
+            return dx, dw, ds, dd, None, None
         dx = dw = ds = dd = None
         dy = nhwc(dy)
-        need_x, need_w, need_s, need_d = ctx.needs_input_grad[:4]
         if need_x or need_s:
             # dxs = dgrad(dy * d, w)   (un-modulated input gradient)
             dxs = conv2d_raw(dy, w, dgrad_geom(geom), in_hw, w.shape[2], w_transposed=True, in_scale=d)

@@ -49,11 +49,22 @@ def _conv_relu(x, fmaps, name):
         return fused_bias_act(x, b=b, act='relu', gain=1.0)
 
 
+_const_cache = {}
+
+
+def _consts(dev):
+    """Per-device shift / scale constants, created once (no host->device copy inside a captured step)."""
+    key = str(dev)
+    if key not in _const_cache:
+        _const_cache[key] = (torch.tensor(_SHIFT, device=dev, dtype=torch.float32).view(1, 3, 1, 1),
+                             torch.tensor(_SCALE, device=dev, dtype=torch.float32).view(1, 3, 1, 1))
+    return _const_cache[key]
+
+
 def vgg_features(images):
     """images: [N,3,H,W] in [0,255] -> list of 5 channel-normalised feature maps."""
     dev = images.device
-    shift = torch.tensor(_SHIFT, device=dev, dtype=torch.float32).view(1, 3, 1, 1)
-    scale = torch.tensor(_SCALE, device=dev, dtype=torch.float32).view(1, 3, 1, 1)
+    shift, scale = _consts(dev)
     x = (images / 127.5 - 1.0 - shift) / scale
     x = x.contiguous(memory_format=torch.channels_last) if x.device.type != 'meta' else x
     feats = []

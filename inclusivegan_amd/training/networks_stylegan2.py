@@ -70,8 +70,17 @@ def conv2d_layer(x, fmaps, kernel, up=False, down=False, resample_kernel=None, g
 #----------------------------------------------------------------------------
 # Apply bias and activation func (:66-68).
 
-def apply_bias_act(x, act='linear', alpha=None, gain=None, lrmul=1, bias_var='bias'):
-    b = get_variable(bias_var, shape=[int(x.shape[1])], initializer=('zeros',)) * float(lrmul)
+def apply_bias_act(x, act='linear', alpha=None, gain=None, lrmul=1, bias_var='bias', noise=None, noise_strength=None):
+    b = get_variable(bias_var, shape=[int(x.shape[1])], initializer=('zeros',))
+    if lrmul != 1:
+        b = b * float(lrmul)
+    if noise is not None:
+        from ..dnnlib.tflib.ops.fused_bias_act import activation_funcs
+        spec = activation_funcs[act]
+        if spec.hip_idx in (1, 2, 3):
+            a = alpha if alpha is not None else (spec.def_alpha or 0.0)
+            return hip_ops.bias_act_noise(x, b, noise, noise_strength, spec.hip_idx, a, spec.def_gain if gain is None else gain)
+        x = x + noise * noise_strength
     return fused_bias_act(x, b=b, act=act, alpha=alpha, gain=gain)
 
 #----------------------------------------------------------------------------
@@ -309,8 +318,8 @@ def G_synthesis_stylegan2(
         else:
             noise = noise_inputs[layer_idx]
         noise_strength = get_variable('noise_strength', shape=[], initializer=('zeros',))
-        x = x + noise * noise_strength
-        return apply_bias_act(x, act=act)
+        # x += noise * noise_strength; apply_bias_act(x, act)  (:356-357) as one fused pass
+        return apply_bias_act(x, act=act, noise=noise, noise_strength=noise_strength)
 
     # Building blocks for main layers (:360-377).
     def block(x, res): # res = 3..resolution_log2

@@ -161,6 +161,38 @@ def test_fused_bias_act_kernel_table(cuda_device):
             assert rel_err(got.reshape(-1), want) < 1e-5, (act_idx, grad)
 
 
+@pytest.mark.parametrize('shape', [(2, 8, 5, 6), (6, 512, 32, 32), (3, 128, 17, 9), (4, 1024, 4, 4), (5, 12, 3, 3), (7, 512)])
+@pytest.mark.parametrize('act', ['lrelu', 'linear', 'relu'])
+def test_bias_act_noise_fused_epilogue(shape, act, cuda_device):
+    """x + noise*strength -> bias -> act (networks_stylegan2.py:351-357): forward, dx, db, dstrength, and
+    the create_graph path, against the oracle composition."""
+    from oracle import fused_bias_act as O
+    from inclusivegan_amd import hip_ops
+    from inclusivegan_amd.dnnlib.tflib.ops.fused_bias_act import activation_funcs
+    rng = np.random.RandomState(len(shape) * 31 + shape[1])
+    spec = activation_funcs[act]
+    x = torch.from_numpy(rng.randn(*shape)); b = torch.from_numpy(rng.randn(shape[1]))
+    has_noise = len(shape) == 4
+    noise = torch.from_numpy(rng.randn(shape[0], 1, shape[2], shape[3])) if has_noise else None
+    st = torch.tensor(0.37, dtype=torch.float64)
+    xo = x.clone().requires_grad_(True); bo = b.clone().requires_grad_(True); so = st.clone().requires_grad_(True)
+    yo = O.fused_bias_act(xo + noise * so if has_noise else xo, bo, act=act)
+    xg = x.float().to(cuda_device)
+    xg = (xg.contiguous(memory_format=torch.channels_last) if has_noise else xg).requires_grad_(True)
+    bg = b.float().to(cuda_device).requires_grad_(True); sg = st.float().to(cuda_device).requires_grad_(True)
+    ng = noise.float().to(cuda_device) if has_noise else None
+    yg = hip_ops.bias_act_noise(xg, bg, ng, sg if has_noise else None, spec.hip_idx, spec.def_alpha or 0.0, spec.def_gain)
+    assert rel_err(yg, yo) < 1e-5
+    dy = torch.from_numpy(rng.randn(*shape))
+    ins_o = [xo, bo] + ([so] if has_noise else []); ins_g = [xg, bg] + ([sg] if has_noise else [])
+    go = torch.autograd.grad(yo, ins_o, dy, create_graph=True)
+    gg = torch.autograd.grad(yg, ins_g, dy.float().to(cuda_device), retain_graph=True)
+    gg2 = torch.autograd.grad(yg, ins_g, dy.float().to(cuda_device), create_graph=True)
+    for a_, b_, c_ in zip(gg, go, gg2):
+        assert rel_err(a_, b_) < 2e-5
+        assert rel_err(c_, b_) < 2e-5
+
+
 # ----------------------------------------------------------------------------- conv2d family
 def _conv_oracle(x, w, stride, up, pad, out_hw):
     """Direct statement of include/igan_hip.h's conv formula with torch ops (fp64)."""
