@@ -190,6 +190,16 @@ typedef struct igan_conv2d_wgrad_params {
 int igan_conv2d_wgrad_plan(const igan_conv2d_wgrad_params* p, int* splits, size_t* workspace_floats);
 int igan_conv2d_wgrad(igan_stream_t stream, const igan_conv2d_wgrad_params* p);
 
+/* Per-sample channel dot products of two channel-minor tensors a, b [N, HW, C] (C % 4 == 0):
+ *     dot[n,c] = sum_hw a[n,hw,c] * b[n,hw,c];   if out != NULL: out[n,hw,c] = b[n,hw,c] * s[n,c]
+ * (out may alias b; s may be NULL = 1).  These are the style / demodulation gradients of
+ * modulated_conv2d_layer in its non-fused form (networks_stylegan2.py:112,126): ds = dot(x, g) with
+ * dx = g * s, and dd = dot(dy, y) / d.  Deterministic; workspace of
+ * igan_scale_dot_workspace_floats(N, HW, C) floats. */
+size_t igan_scale_dot_workspace_floats(int N, int HW, int C);
+int igan_scale_dot(igan_stream_t stream, const float* a, const float* b, const float* s, float* out,
+                   float* dot, float* workspace, int N, int HW, int C);
+
 /* ------------------------------------------------------------------------
  * minibatch_stddev_layer statistics (networks_stylegan2.py:132-144), NHWC input
  * x[N, H, W, C], group size G (N % G == 0, M = N / G, num_new_features = 1):

@@ -127,19 +127,22 @@ __global__ __launch_bounds__(256) void ban_bwd_kernel(BanArgs a) {
     }
 }
 
-// db[c] = sum_j partial[j][c]; dstrength = sum_j partial[j][C].  grid.x = ceil((C+1)/64), 256 threads:
-// 64 columns x 4 groups of partial rows, folded through LDS.
+// db[c] = sum_j partial[j][c]; dstrength = sum_j partial[j][C].  One block per 16 columns: 16 columns x
+// 16 groups of partial rows (each thread adds <= blocks/16 values, 64 B coalesced per 16 lanes), folded
+// through LDS in fixed order.
 __global__ __launch_bounds__(256) void ban_final_kernel(const float* partial, float* db, float* dstrength, int blocks, int C) {
     __shared__ float red[256];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int grp = threadIdx.x >> 6;
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int grp = threadIdx.x >> 4;
     float s = 0.f;
     if (c <= C)
-        for (int j = grp; j < blocks; j += 4) s += partial[(size_t)j * (C + 1) + c];
+        for (int j = grp; j < blocks; j += 16) s += partial[(size_t)j * (C + 1) + c];
     red[threadIdx.x] = s;
     __syncthreads();
     if (grp == 0 && c <= C) {
-        const float t = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; g++) t += red[g * 16 + threadIdx.x];
         if (c < C) { if (db) db[c] = t; }
         else if (dstrength) *dstrength = t;
     }
@@ -195,7 +198,7 @@ extern "C" int igan_bias_act_noise_bwd(igan_stream_t stream_, const float* dy, c
     const int blocks = ban_blocks(rows, C);
     dim3 grid(blocks, ceil_div(C / 4, 256));
     hipLaunchKernelGGL(ban_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream_, a);
-    hipLaunchKernelGGL(ban_final_kernel, dim3(ceil_div(C + 1, 64)), dim3(256), 0, (hipStream_t)stream_,
+    hipLaunchKernelGGL(ban_final_kernel, dim3(ceil_div(C + 1, 16)), dim3(256), 0, (hipStream_t)stream_,
                        (const float*)workspace, db, noise ? dstrength : nullptr, blocks, C);
     IGAN_LAUNCH_CHECK("bias_act_noise_bwd launch");
     return IGAN_OK;

@@ -62,6 +62,8 @@ struct ConvArgs {
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ float4 f4mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+// scale operand: the loaded values when the scale exists, 1.0 otherwise (select, not branch)
+__device__ __forceinline__ float4 f4sel(bool has, float4 s) { return make_float4(has ? s.x : 1.f, has ? s.y : 1.f, has ? s.z : 1.f, has ? s.w : 1.f); }
 
 // Predicated operand loads through buffer descriptors: an out-of-range offset makes the hardware
 // return 0 for that lane, so padding taps, ragged tile edges and channel tails need no branch and no
@@ -74,19 +76,31 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, unsi
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)bytes, 0x00020000);
 }
 
-// 4 consecutive floats at element offset `off`; elements at or beyond `left` (counted from off, may
-// be <= 0) read as 0.  VEC: off % 4 == 0, base 16 B aligned, all four in or all four out.
+// Address of 4 consecutive floats at element offset `off`, of which `left` (may be <= 0) are valid.
+// VEC: off % 4 == 0, base 16 B aligned, all four in or all four out -> one byte offset (or OOB).
+// !VEC: byte offset of element 0 (never OOB) plus the valid count, resolved per element at load time.
+struct LoadAddr {
+    unsigned off;
+    int left;
+};
 template <bool VEC>
-__device__ __forceinline__ float4 load4(__amdgpu_buffer_rsrc_t r, int off, int left) {
+__device__ __forceinline__ LoadAddr make_addr(int off, int left) {
+    LoadAddr a;
+    if constexpr (VEC) { a.off = (left > 0) ? (unsigned)off * 4u : OOB; a.left = 0; }
+    else { a.off = (unsigned)off * 4u; a.left = left; }
+    return a;
+}
+template <bool VEC>
+__device__ __forceinline__ float4 load4(__amdgpu_buffer_rsrc_t r, LoadAddr a) {
     if constexpr (VEC) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (left > 0) ? (unsigned)off * 4u : OOB, 0, 0);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, a.off, 0, 0);
         return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     } else {
         float4 f;
-        f.x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (left > 0) ? (unsigned)(off + 0) * 4u : OOB, 0, 0));
-        f.y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (left > 1) ? (unsigned)(off + 1) * 4u : OOB, 0, 0));
-        f.z = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (left > 2) ? (unsigned)(off + 2) * 4u : OOB, 0, 0));
-        f.w = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (left > 3) ? (unsigned)(off + 3) * 4u : OOB, 0, 0));
+        f.x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (a.left > 0) ? a.off + 0u : OOB, 0, 0));
+        f.y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (a.left > 1) ? a.off + 4u : OOB, 0, 0));
+        f.z = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (a.left > 2) ? a.off + 8u : OOB, 0, 0));
+        f.w = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (a.left > 3) ? a.off + 12u : OOB, 0, 0));
         return f;
     }
 }
@@ -220,28 +234,32 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     float4 ra[AR], rsa[AR], rb[BR];
 
     // (tap, channel-chunk) of the next chunk to load, advanced incrementally (no per-chunk division)
-    int ld_t = (c_begin < c_end) ? c_begin / a.cpt : 0;
-    int ld_cc = (c_begin < c_end) ? c_begin - ld_t * a.cpt : 0;
+    const int ld_t0 = (c_begin < c_end) ? c_begin / a.cpt : 0;
+    int ld_cc = (c_begin < c_end) ? c_begin - ld_t0 * a.cpt : 0;
+    int ld_ta = (c_begin < c_end) ? ld_t0 / nkx : 0;
+    int ld_tb = (c_begin < c_end) ? ld_t0 - ld_ta * nkx : 0;
     const bool has_in_scale = a.in_scale != nullptr;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, (unsigned)a.N * a.H * a.W * a.Cin * 4u);
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.w, (unsigned)a.KH * a.KW * a.Cin * a.Cout * 4u);
     // absent scale: zero records -> every load is out of range (no memory access), value unused
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(has_in_scale ? a.in_scale : a.x, has_in_scale ? (unsigned)a.N * a.Cin * 4u : 0u);
 
-    auto load_chunk = [&]() {
-        const int t = ld_t;
+    // Addresses of the NEXT prefetch are computed one stage ahead, inside the MFMA phase (pure VALU
+    // that the scheduler tucks into MFMA shadows); the prefetch itself is then 3*AR.. buffer loads
+    // issued back to back at the top of the iteration.
+    LoadAddr aa[AR], as_[AR], ab[BR];
+    auto prep_chunk = [&](bool live) {
         const int ci0 = ld_cc * BK;
-        const int ta = t / nkx, tb = t - ta * nkx;
-        const int ky = ky0 + (ta << a.up_shift), kx = kx0 + (tb << a.up_shift);
+        const int ky = ky0 + (ld_ta << a.up_shift), kx = kx0 + (ld_tb << a.up_shift);
         const int ci = ci0 + 4 * kvec;
 #pragma unroll
         for (int i = 0; i < AR; i++) {
             const int vy = rby[i] + ky, vx = rbx[i] + kx;
             const int iy = vy >> a.up_shift, ix = vx >> a.up_shift;
-            const bool ok = rok[i] & (vy >= 0) & (vx >= 0) & (iy < a.H) & (ix < a.W);
+            const bool ok = live & rok[i] & (vy >= 0) & (vx >= 0) & (iy < a.H) & (ix < a.W);
             const int left = ok ? (a.Cin - ci) : 0;
-            ra[i] = load4<VEC>(rx, ((rn[i] * a.H + iy) * a.W + ix) * a.Cin + ci, left);
-            rsa[i] = load4<VEC>(rs, rn[i] * a.Cin + ci, left);   // multiplied in at store time (after the MFMAs)
+            aa[i] = make_addr<VEC>(((rn[i] * a.H + iy) * a.W + ix) * a.Cin + ci, left);
+            as_[i] = make_addr<VEC>(rn[i] * a.Cin + ci, left);
         }
         if constexpr (!WT) {
 #pragma unroll
@@ -249,23 +267,39 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
                 const int kr = krow0 + KROWS * i;
                 const int cik = ci0 + kr;
                 const int co = n0 + 4 * nvec;
-                rb[i] = load4<VEC>(rw, ((ky * a.KW + kx) * a.Cin + cik) * a.Cout + co, (cik < a.Cin) ? (a.Cout - co) : 0);
+                ab[i] = make_addr<VEC>(((ky * a.KW + kx) * a.Cin + cik) * a.Cout + co, (live & (cik < a.Cin)) ? (a.Cout - co) : 0);
             }
         } else {
 #pragma unroll
             for (int i = 0; i < BR; i++) {
                 const int co = n0 + brow0 + 32 * i;
-                rb[i] = load4<VEC>(rw, (((a.KH - 1 - ky) * a.KW + (a.KW - 1 - kx)) * a.Cout + co) * a.Cin + ci, (co < a.Cout) ? (a.Cin - ci) : 0);
+                ab[i] = make_addr<VEC>((((a.KH - 1 - ky) * a.KW + (a.KW - 1 - kx)) * a.Cout + co) * a.Cin + ci, (live & (co < a.Cout)) ? (a.Cin - ci) : 0);
             }
         }
-        if (++ld_cc == a.cpt) { ld_cc = 0; ++ld_t; }
+        // branch-free advance (keeps the loop body one basic block)
+        ++ld_cc;
+        const int w1 = (ld_cc == a.cpt) ? 1 : 0;
+        ld_cc = w1 ? 0 : ld_cc;
+        ld_tb += w1;
+        const int w2 = (ld_tb == nkx) ? 1 : 0;
+        ld_tb = w2 ? 0 : ld_tb;
+        ld_ta += w2;
+    };
+    auto issue_loads = [&]() {
+#pragma unroll
+        for (int i = 0; i < AR; i++) {
+            ra[i] = load4<VEC>(rx, aa[i]);
+            rsa[i] = load4<VEC>(rs, as_[i]);   // multiplied in at store time (after the MFMAs)
+        }
+#pragma unroll
+        for (int i = 0; i < BR; i++) rb[i] = load4<VEC>(rw, ab[i]);
     };
     auto store_chunk = [&](int buf) {
         float* A = As + buf * A_ELEMS;
         float* B = Bs + buf * B_ELEMS;
 #pragma unroll
         for (int i = 0; i < AR; i++)
-            *reinterpret_cast<float4*>(A + (arow0 + 32 * i) * LDK + 4 * kvec) = has_in_scale ? f4mul(ra[i], rsa[i]) : ra[i];
+            *reinterpret_cast<float4*>(A + (arow0 + 32 * i) * LDK + 4 * kvec) = f4mul(ra[i], f4sel(has_in_scale, rsa[i]));
         if constexpr (!WT) {
 #pragma unroll
             for (int i = 0; i < BR; i++) *reinterpret_cast<float4*>(B + (krow0 + KROWS * i) * LDB + 4 * nvec) = rb[i];
@@ -284,17 +318,25 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
             for (int r = 0; r < 16; r++) acc[tm][tn][r] = 0.0f;
 
     if (c_begin < c_end) {
-        load_chunk();
+        prep_chunk(true);
+        issue_loads();
         store_chunk(0);
+        prep_chunk(c_begin + 1 < c_end);
     }
     __syncthreads();
     for (int c = c_begin; c < c_end; c++) {
         const int cur = (c - c_begin) & 1;
-        const bool more = (c + 1 < c_end);
-        if (more) load_chunk();
+        // Prefetch of chunk c+1 (predicated off -- every lane out of range, no memory traffic -- on the
+        // last iteration, instead of branched around: the loop body stays ONE basic block).
+        issue_loads();
+        __builtin_amdgcn_sched_barrier(0);   // the prefetch stays AHEAD of the MFMAs ...
         mma_chunk<TM, TN, false, !WT, LDK, LDB>(As + cur * A_ELEMS, Bs + cur * B_ELEMS, acc,
                                                  wm * (BM / WM), wn * (BN / WN), l31, h);
-        if (more) store_chunk(cur ^ 1);
+        prep_chunk(c + 2 < c_end);           // addresses of chunk c+2: VALU only, free to interleave with the MFMAs
+        // ... and its consumers (with their s_waitcnt vmcnt) stay BEHIND them: without this fence hipcc
+        // hoists the first scale-multiply + ds_write up to the first MFMA and stalls there.
+        __builtin_amdgcn_sched_barrier(0);
+        store_chunk(cur ^ 1);
         __syncthreads();
     }
 
@@ -409,31 +451,44 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const __amdgpu_buffer_rsrc_t rdy = make_rsrc(a.dy, (unsigned)a.N * a.OH * a.OW * a.Cout * 4u);
     const __amdgpu_buffer_rsrc_t rsi = make_rsrc(has_in_scale ? a.in_scale : a.x, has_in_scale ? (unsigned)a.N * a.Cin * 4u : 0u);
     const __amdgpu_buffer_rsrc_t rso = make_rsrc(has_out_scale ? a.out_scale : a.dy, has_out_scale ? (unsigned)a.N * a.Cout * 4u : 0u);
-    auto load_chunk = [&](int c) {
+    LoadAddr aa[AR], as_[AR], ab[BR], abs_[BR];
+    auto prep_chunk = [&](int c, bool live) {
 #pragma unroll
         for (int i = 0; i < AR; i++) {
             const int kp = c * BK + aprow0 + AROWS * i;
             int nn = 0, oy = 0, ox = 0;
-            const bool in = kp < Kpix;
+            const bool in = live & (kp < Kpix);
             decode(in ? kp : 0, nn, oy, ox);
             const int vy = oy * a.stride + ky - a.pad_y, vx = ox * a.stride + kx - a.pad_x;
             const int iy = vy >> a.up_shift, ix = vx >> a.up_shift;
             const bool ok = in & (vy >= 0) & (vx >= 0) & (iy < a.H) & (ix < a.W);
             const int ci = m0 + 4 * amv;
             const int left = ok ? (a.Cin - ci) : 0;
-            ra[i] = load4<VEC>(rx, ((nn * a.H + iy) * a.W + ix) * a.Cin + ci, left);
-            rsa[i] = load4<VEC>(rsi, nn * a.Cin + ci, left);
+            aa[i] = make_addr<VEC>(((nn * a.H + iy) * a.W + ix) * a.Cin + ci, left);
+            as_[i] = make_addr<VEC>(nn * a.Cin + ci, left);
         }
 #pragma unroll
         for (int i = 0; i < BR; i++) {
             const int kp = c * BK + bprow0 + BROWS * i;
             int nn = 0, oy = 0, ox = 0;
-            const bool in = kp < Kpix;
+            const bool in = live & (kp < Kpix);
             decode(in ? kp : 0, nn, oy, ox);
             const int co = n0 + 4 * bnv;
             const int left = in ? (a.Cout - co) : 0;
-            rb[i] = load4<VEC>(rdy, ((nn * a.OH + oy) * a.OW + ox) * a.Cout + co, left);
-            rsb[i] = load4<VEC>(rso, nn * a.Cout + co, left);
+            ab[i] = make_addr<VEC>(((nn * a.OH + oy) * a.OW + ox) * a.Cout + co, left);
+            abs_[i] = make_addr<VEC>(nn * a.Cout + co, left);
+        }
+    };
+    auto issue_loads = [&]() {
+#pragma unroll
+        for (int i = 0; i < AR; i++) {
+            ra[i] = load4<VEC>(rx, aa[i]);
+            rsa[i] = load4<VEC>(rsi, as_[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < BR; i++) {
+            rb[i] = load4<VEC>(rdy, ab[i]);
+            rsb[i] = load4<VEC>(rso, abs_[i]);
         }
     };
     auto store_chunk = [&](int buf) {
@@ -441,10 +496,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         float* B = Bs + buf * B_ELEMS;
 #pragma unroll
         for (int i = 0; i < AR; i++)
-            *reinterpret_cast<float4*>(A + (aprow0 + AROWS * i) * LDA + 4 * amv) = has_in_scale ? f4mul(ra[i], rsa[i]) : ra[i];
+            *reinterpret_cast<float4*>(A + (aprow0 + AROWS * i) * LDA + 4 * amv) = f4mul(ra[i], f4sel(has_in_scale, rsa[i]));
 #pragma unroll
         for (int i = 0; i < BR; i++)
-            *reinterpret_cast<float4*>(B + (bprow0 + BROWS * i) * LDB + 4 * bnv) = has_out_scale ? f4mul(rb[i], rsb[i]) : rb[i];
+            *reinterpret_cast<float4*>(B + (bprow0 + BROWS * i) * LDB + 4 * bnv) = f4mul(rb[i], f4sel(has_out_scale, rsb[i]));
     };
 
     f32x16 acc[TM][TN];
@@ -456,17 +511,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
             for (int r = 0; r < 16; r++) acc[tm][tn][r] = 0.0f;
 
     if (c_begin < c_end) {
-        load_chunk(c_begin);
+        prep_chunk(c_begin, true);
+        issue_loads();
         store_chunk(0);
+        prep_chunk(c_begin + 1, c_begin + 1 < c_end);
     }
     __syncthreads();
     for (int c = c_begin; c < c_end; c++) {
         const int cur = (c - c_begin) & 1;
-        const bool more = (c + 1 < c_end);
-        if (more) load_chunk(c + 1);
+        issue_loads();                        // chunk c+1 (predicated off on the last iteration)
+        __builtin_amdgcn_sched_barrier(0);
         mma_chunk<TM, TN, true, true, LDA, LDB>(As + cur * A_ELEMS, Bs + cur * B_ELEMS, acc,
                                                  wm * (BM / WM), wn * (BN / WN), l31, h);
-        if (more) store_chunk(cur ^ 1);
+        prep_chunk(c + 2, c + 2 < c_end);     // pixel decode + addresses of chunk c+2 in the MFMA shadows
+        __builtin_amdgcn_sched_barrier(0);
+        store_chunk(cur ^ 1);
         __syncthreads();
     }
 
@@ -640,13 +699,23 @@ WgTile pick_wg_tile(int Cin, int Cout) {
 }
 
 int wgrad_splits(const igan_conv2d_wgrad_params* p) {
+    // One block per (tap, Cin tile, Cout tile, pixel slice).  The kernel runs 2 workgroups per CU
+    // (LDS / VGPR), i.e. 512 co-resident workgroups on 256 CUs: size the grid to whole rounds of 512
+    // so that no round runs half empty (a 774-block grid ran 1.5 rounds: 25 % of the machine idle
+    // for a third of the time).
     const WgTile t = pick_wg_tile(p->Cin, p->Cout);
     const long long tiles = (long long)igan::ceil_div(p->Cin, t.BM) * igan::ceil_div(p->Cout, t.BN) * p->KH * p->KW;
     const int up = p->up;
     const long long kpix = (long long)p->N * ((p->OH + up - 1) / up) * ((p->OW + up - 1) / up);
     const int chunks = (int)((kpix + BK - 1) / BK);
-    int s = (int)((768 + tiles - 1) / tiles);
-    s = std::min(s, std::max(1, chunks / 4));
+    const int max_by_work = std::max(1, chunks / 4);          // >= 4 chunks per block
+    int s;
+    if (tiles >= 512) s = 1;
+    else {
+        s = (int)(512 / tiles);                               // one full round
+        if (s > max_by_work) s = max_by_work;
+        else if (chunks / s > 96 && 1024 / tiles <= max_by_work) s = (int)(1024 / tiles);   // long slices: two rounds
+    }
     s = std::min(s, 256);
     return std::max(s, 1);
 }

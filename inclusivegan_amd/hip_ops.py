@@ -490,6 +490,22 @@ def matmul(x, w):
 # ----------------------------------------------------------------------------
 # modulated conv (fused scales on the first-order path)
 
+def scale_dot_raw(a, b, s=None, want_scaled=False):
+    """dot[n,c] = sum_hw a*b for channels_last a, b [N,C,H,W]; optionally also b*s[n,c] (written over b)."""
+    lib = _abi.get_plugin()
+    _require_cuda_f32(a, b, s)
+    a = nhwc(a)
+    b = nhwc(b)
+    n, c, h, w = a.shape
+    dot = torch.empty((n, c), device=a.device, dtype=torch.float32)
+    ws = torch.empty((int(lib.igan_scale_dot_workspace_floats(n, h * w, c)),), device=a.device, dtype=torch.float32)
+    if s is not None:
+        s = s.contiguous()
+    _abi.check(lib.igan_scale_dot(_stream(), _ptr(a), _ptr(b), _ptr(s), _ptr(b) if want_scaled else ctypes.c_void_p(0),
+                                  _ptr(dot), _ptr(ws), n, h * w, c))
+    return dot, (b if want_scaled else None)
+
+
 class ModConv2dFn(torch.autograd.Function):
     """y = d * conv(x * s, w): modulated_conv2d_layer in its non-fused form
     (networks_stylegan2.py:112,126) with the two scalings folded into the MFMA kernel's operand
@@ -540,14 +556,23 @@ class ModConv2dFn(torch.autograd.Function):
         if need_x or need_s:
             # dxs = dgrad(dy * d, w)   (un-modulated input gradient)
             dxs = conv2d_raw(dy, w, dgrad_geom(geom), in_hw, w.shape[2], w_transposed=True, in_scale=d)
-            if need_s:
-                ds = (x * dxs).sum(dim=(2, 3))
-            if need_x:
-                dx = dxs * s[:, :, None, None]
+            if x.shape[1] % 4 == 0:
+                # one pass: ds = sum_hw x * dxs, and dx = dxs * s written in place over dxs
+                ds, dx = scale_dot_raw(x, dxs, s, want_scaled=need_x)
+                if not need_s:
+                    ds = None
+            else:
+                if need_s:
+                    ds = (x * dxs).sum(dim=(2, 3))
+                if need_x:
+                    dx = dxs * s[:, :, None, None]
         if need_w:
             dw = conv2d_wgrad_raw(x, dy, geom, in_scale=s, out_scale=d)
         if need_d and d is not None:
-            dd = (dy * y).sum(dim=(2, 3)) / d
+            if y.shape[1] % 4 == 0:
+                dd = scale_dot_raw(dy, y)[0] / d
+            else:
+                dd = (dy * y).sum(dim=(2, 3)) / d
         return dx, dw, ds, dd, None, None
 
 
