@@ -46,9 +46,9 @@ def parse_args():
     return p.parse_args()
 
 
-def conv_roofline(device, batch, reps=20):
-    """Dominant kernel: conv_fwd_kernel<128,128,2,2> on the 128x128 Conv1 shape
-    (GEMM M = batch*128*128, N = 128, K = 1152)."""
+def headline_shape_roofline(device, batch, reps=20):
+    """The north-star shape: modulated conv 128x128 Conv1 (GEMM M = batch*128*128, N = 128, K = 1152;
+    SURVEY.md section 8a/8d), timed alone with HIP events on the launch stream."""
     import torch
     from inclusivegan_amd import hip_ops
     cin = cout = 128
@@ -71,9 +71,29 @@ def conv_roofline(device, batch, reps=20):
     ms = e0.elapsed_time(e1) / reps
     flops = 2.0 * batch * res * res * cout * cin * 9
     achieved = flops / (ms * 1e-3) / 1e12
-    return dict(bound='mfma', kernel='conv_fwd_kernel<128,128,2,2> modconv 128x128 3x3 Cin=Cout=128 batch %d' % batch,
-                achieved=round(achieved, 2), peak=F32_MATRIX_PEAK_TFLOPS, unit='TFLOP/s', frac=round(achieved / F32_MATRIX_PEAK_TFLOPS, 4),
-                flops_per_launch=flops, us_per_launch=round(ms * 1e3, 1), traffic=None)
+    return dict(shape='modulated conv 128x128 3x3 Cin=Cout=128 batch %d (M=%d N=128 K=1152)' % (batch, batch * res * res),
+                achieved=round(achieved, 2), frac=round(achieved / F32_MATRIX_PEAK_TFLOPS, 4),
+                flops_per_launch=flops, us_per_launch=round(ms * 1e3, 1))
+
+
+def step_roofline(log):
+    """Roofline of the dominant kernel over the launches of real training iterations: per-launch HIP
+    events (recorded by hip_ops.conv2d_raw on the launch stream) grouped by kernel instantiation; the
+    instantiation with the largest total time is the dominant kernel.  achieved = sum of algorithmic
+    FLOPs / sum of launch durations; avg_launch_us is what a rocprofv3 --stats run reports as that
+    kernel's average duration (launches with split-K include their small reduce kernel)."""
+    agg = {}
+    for name, flops, splits, e0, e1 in log:
+        a = agg.setdefault(name, [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += flops
+        a[2] += e0.elapsed_time(e1) * 1e-3
+    name, (calls, flops, secs) = max(agg.items(), key=lambda kv: kv[1][2])
+    achieved = flops / secs / 1e12
+    total_conv = sum(v[2] for v in agg.values())
+    return dict(bound='mfma', kernel=name, achieved=round(achieved, 2), peak=F32_MATRIX_PEAK_TFLOPS, unit='TFLOP/s',
+                frac=round(achieved / F32_MATRIX_PEAK_TFLOPS, 4), launches=calls, avg_launch_us=round(secs / calls * 1e6, 1),
+                flops_per_launch=round(flops / calls), share_of_conv_time=round(secs / total_conv, 3), traffic=None)
 
 
 def cpu_baseline(resolution, batch, lpips_weight):
@@ -154,6 +174,7 @@ def main():
 
     B = args.minibatch_gpu
     state = dict(t_start=None, t_end=None, refresh=[], iters=0)
+    profile_iters = 0 if args.no_roofline else 16     # eager, per-launch-timed iterations after the timed region
 
     def barrier_sync():
         if world > 1:
@@ -169,6 +190,16 @@ def main():
         if state['iters'] == args.warmup + args.steps:
             barrier_sync()
             state['t_end'] = time.perf_counter()
+            if profile_iters == 0:
+                return True
+            # roofline leg: same iterations, run eagerly with every conv launch bracketed by HIP events
+            from inclusivegan_amd import hip_ops
+            from inclusivegan_amd.dnnlib.tflib.graphs import GraphedStep
+            GraphedStep.force_eager = True
+            if rank == 0:
+                hip_ops.launch_log = []
+        if state['iters'] == args.warmup + args.steps + profile_iters:
+            torch.cuda.synchronize()
             return True
         return False
 
@@ -210,8 +241,11 @@ def main():
     }
     if rank == 0:
         if not args.no_roofline:
-            log('timing the dominant kernel')
-            out['roofline'] = conv_roofline(device, B)
+            from inclusivegan_amd import hip_ops
+            log('aggregating %d timed conv launches' % len(hip_ops.launch_log))
+            out['roofline'] = step_roofline(hip_ops.launch_log)
+            hip_ops.launch_log = None
+            out['roofline']['headline_shape'] = headline_shape_roofline(device, B)
         if world == 1 and not args.no_cpu_baseline:
             log('timing the CPU oracle baseline')
             out['cpu_baseline'] = cpu_baseline_subprocess(args.resolution, 2 if args.resolution >= 128 else B, args.lpips_weight)

@@ -164,6 +164,9 @@ typedef struct igan_conv2d_params {
 
 int igan_conv2d_plan(const igan_conv2d_params* p, int* splits, size_t* workspace_floats);
 int igan_conv2d(igan_stream_t stream, const igan_conv2d_params* p);
+/* Host-only: name of the kernel instantiation igan_conv2d() launches for these parameters (as reported
+ * by rocprofv3, minus the anonymous-namespace prefix).  For profiling tools. */
+int igan_conv2d_kernel_name(const igan_conv2d_params* p, char* buf, int buflen);
 
 /* Weight gradient of the op above (same geometry fields):
  *   dw[ky,kx,ci,co] = sum_{n,oy,ox} xup[n, oy*stride+ky-pad_y, ox*stride+kx-pad_x, ci]

@@ -88,6 +88,7 @@ SIGNATURES = {
     'igan_bias_act_noise_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F]),
     'igan_conv2d_plan': (_I, [ctypes.POINTER(Conv2DParams), ctypes.POINTER(_I), ctypes.POINTER(_SZ)]),
     'igan_conv2d': (_I, [_P, ctypes.POINTER(Conv2DParams)]),
+    'igan_conv2d_kernel_name': (_I, [ctypes.POINTER(Conv2DParams), ctypes.c_char_p, _I]),
     'igan_conv2d_wgrad_plan': (_I, [ctypes.POINTER(Conv2DWgradParams), ctypes.POINTER(_I), ctypes.POINTER(_SZ)]),
     'igan_conv2d_wgrad': (_I, [_P, ctypes.POINTER(Conv2DWgradParams)]),
     'igan_scale_dot_workspace_floats': (_SZ, [_I, _I, _I]),

@@ -621,6 +621,26 @@ extern "C" int igan_conv2d_plan(const igan_conv2d_params* p, int* splits, size_t
     return IGAN_OK;
 }
 
+// Which instantiation igan_conv2d() launches for these parameters (host-only; for profiling tools:
+// the string equals the kernel name rocprofv3 reports, up to the anonymous namespace prefix).
+extern "C" int igan_conv2d_kernel_name(const igan_conv2d_params* p, char* buf, int buflen) {
+    IGAN_REQUIRE(p && buf && buflen > 0, "conv2d_kernel_name: null argument");
+    if (int rc = fwd_geometry_check(p)) return rc;
+    int Mmax, chunks_max, nclass;
+    fwd_counts(p, Mmax, chunks_max, nclass);
+    const FwdTile t = pick_fwd_tile(Mmax, p->Cout);
+    const bool wt = p->w_transposed != 0;
+    const bool vecA = (p->Cin % 4 == 0) && (((uintptr_t)p->x & 15) == 0);
+    const bool vecS = (p->Cin % 4 == 0) && (((uintptr_t)p->in_scale & 15) == 0);
+    const bool vecB = ((wt ? p->Cin : p->Cout) % 4 == 0) && (((uintptr_t)p->w & 15) == 0);
+    const bool vec = vecA && vecB && (p->in_scale == nullptr || vecS);
+    int wm = 2, wn = 2;
+    if (t.BM == 128 && t.BN == 32) { wm = 4; wn = 1; }
+    if (t.BM == 32) { wm = 1; wn = 4; }
+    snprintf(buf, (size_t)buflen, "conv_fwd_kernel<%d, %d, %d, %d, %s, %s>", t.BM, t.BN, wm, wn, wt ? "true" : "false", vec ? "true" : "false");
+    return IGAN_OK;
+}
+
 extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
     using namespace igan;
     hipStream_t stream = (hipStream_t)stream_;

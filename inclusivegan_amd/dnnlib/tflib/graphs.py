@@ -26,6 +26,7 @@ def graphs_enabled(default=True):
 
 class GraphedStep:
     _pool = None
+    force_eager = False     # profiling switch: run every step eagerly (per-launch event timing)
 
     def __init__(self, fn, enabled=True, eager_calls=2, name='step'):
         self.fn = fn
@@ -37,7 +38,7 @@ class GraphedStep:
         self.out = None
 
     def __call__(self):
-        if not self.enabled or self.calls < self.eager_calls:
+        if not self.enabled or GraphedStep.force_eager or self.calls < self.eager_calls:
             self.calls += 1
             return self.fn()
         if self.graph is None:

@@ -324,6 +324,27 @@ ConvGeom = namedtuple('ConvGeom', 'kh kw stride up pad_y pad_x')
 _plan_cache = {}
 _wplan_cache = {}
 
+# Profiling hook (bench.py): when set to a list, every conv2d_raw launch is bracketed by HIP events on the
+# launch stream and logged as (kernel name, algorithmic FLOPs, start event, end event).
+launch_log = None
+
+
+def conv_flops(n, h, w, cin, oh, ow, cout, geom):
+    """Algorithmic FLOPs of one conv2d call: 2 * (output pixel, tap) pairs that exist * Cin * Cout
+    (a transposed conv only counts the taps of each output parity class)."""
+    up = geom.up
+    pairs = 0
+    for py in range(up):
+        for px in range(up):
+            qh = (oh - py + up - 1) // up
+            qw = (ow - px + up - 1) // up
+            ky0 = (geom.pad_y - py * geom.stride) % up
+            kx0 = (geom.pad_x - px * geom.stride) % up
+            nky = (geom.kh - ky0 + up - 1) // up if ky0 < geom.kh else 0
+            nkx = (geom.kw - kx0 + up - 1) // up if kx0 < geom.kw else 0
+            pairs += qh * qw * nky * nkx
+    return 2.0 * n * pairs * cin * cout
+
 
 def conv2d_raw(x, w, geom, out_hw, cout, w_transposed=False, in_scale=None, out_scale=None):
     """x: logical [N,Cin,H,W] (channels_last).  w: HWIO [KH,KW,Cin,Cout] (or the forward layer's
@@ -364,6 +385,16 @@ def conv2d_raw(x, w, geom, out_hw, cout, w_transposed=False, in_scale=None, out_
         p.workspace = ws.data_ptr()
         p.workspace_floats = plan[1]
         p.splits = plan[0]
+    if launch_log is not None:
+        buf = ctypes.create_string_buffer(128)
+        _abi.check(lib.igan_conv2d_kernel_name(ctypes.byref(p), buf, 128))
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _abi.check(lib.igan_conv2d(_stream(), ctypes.byref(p)))
+        e1.record()
+        launch_log.append((buf.value.decode(), conv_flops(n, h, wd, cin, oh, ow, cout, geom), plan[0], e0, e1))
+        return y
     _abi.check(lib.igan_conv2d(_stream(), ctypes.byref(p)))
     return y
 

@@ -135,8 +135,13 @@ def imle_refresh(G, training_set_rec, latent_candidates, data_size, minibatch_si
             z = torch.from_numpy(latent_candidates[c0:c0 + candidate_batch_size]).to(device)
             lab = torch.zeros((z.shape[0], label_size), device=device)
             imgs = []
-            for j in range(0, z.shape[0], minibatch_size):
-                imgs.append(G.get_output_for(z[j:j + minibatch_size], lab[j:j + minibatch_size], is_validation=True))
+            # Inference batch: the reference feeds sched.minibatch_size at a time (G.run(..., minibatch_size=), :361);
+            # the images do not depend on how the candidates are batched, so use a batch that fills the MFMA
+            # tiles (bounded so that the largest intermediate, [n, C, 2R+1, 2R+1], stays under 2 GiB).
+            per_img = 4 * max(training_set_rec.shape[0], 128) * (training_set_rec.shape[1] * 2 + 1) ** 2 // 4
+            infer_batch = int(max(minibatch_size, min(candidate_batch_size, 64, (1 << 30) // max(per_img, 1))))
+            for j in range(0, z.shape[0], infer_batch):
+                imgs.append(G.get_output_for(z[j:j + infer_batch], lab[j:j + infer_batch], is_validation=True))
             cand = torch.cat(imgs, dim=0).contiguous().reshape(z.shape[0], -1)   # logical NCHW flatten (:363)
             cnorm = hip_ops.row_sqnorm_raw(cand)
             for q0 in range(0, data_size, query_chunk):
