@@ -68,6 +68,7 @@ class Network:
             self._templating = True
             self.flat_params = None
             self.flat_grads = None
+            self._derived = {}            # per-training-op cache of tensors derived from variables only
 
         # Template pass on the meta device: creates variable specs, infers shapes.
         self.input_names = [p.name for p in inspect.signature(self._build_func).parameters.values()
@@ -120,6 +121,25 @@ class Network:
         shape = tuple(int(s) for s in (shape if shape is not None else ()))
         root._specs[full] = (shape, initializer or ('zeros',), bool(trainable))
         return torch.empty(shape, device='meta')
+
+    def derived(self, key, fn):
+        """Cache of tensors that depend on the network's variables only (e.g. the equalised-LR weight
+        w * runtime_coef, networks_stylegan2.py:36, or sum_k w^2 for demodulation): computed once per
+        training op and shared by all forward passes of that op (the G loss runs G four times on
+        unchanged weights).  Keyed by autograd mode; `invalidate_derived()` must be called whenever the
+        variables change (optimizer update, EMA, copy) -- the training loop does so at the start of every op."""
+        root = self._root
+        if root._templating or root.device.type == 'meta':
+            return fn()
+        k = (self._prefix, key, torch.is_grad_enabled())
+        v = root._derived.get(k)
+        if v is None:
+            v = fn()
+            root._derived[k] = v
+        return v
+
+    def invalidate_derived(self):
+        self._root._derived.clear()
 
     def _materialize(self):
         """Allocate the flat buckets and initialise every variable (seeded NumPy stream, so all
@@ -206,6 +226,7 @@ class Network:
         assert self._root is self
         for v in self.trainables.values():
             v.requires_grad_(flag)
+        self._derived.clear()     # cached derived tensors carry the old requires_grad state
         return self
 
     def get_var(self, name):
@@ -220,6 +241,7 @@ class Network:
     def copy_vars_from(self, src):
         assert self._root is self and src._root is src
         same = list(self._offsets.items()) == list(src._offsets.items())
+        self._derived.clear()
         with torch.no_grad():
             if same:
                 self.flat_params.copy_(src.flat_params)
@@ -244,6 +266,7 @@ class Network:
 
         def update_op():
             b = beta() if callable(beta) else beta
+            self._derived.clear()
             with torch.no_grad():
                 hip_ops.ema_raw(self.flat_params, src_net.flat_params, b)
                 for name, var in self.vars.items():

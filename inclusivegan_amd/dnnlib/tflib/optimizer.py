@@ -104,6 +104,7 @@ class Optimizer:
             hip_ops.adam_step_raw(net.flat_params, g, st['m'], st['v'], lr, self.beta1, self.beta2, self.epsilon,
                                   st['pow'], st['flag'])                                     # :318-332
             st['overflows'] += st['flag'].to(torch.int64)                                    # overflow_frequency (:251)
+        net.invalidate_derived()        # the variables changed: drop cached w * coef etc.
         self._num_registered = 0
 
     def reset_optimizer_state(self):

@@ -77,6 +77,14 @@ def get_variable(name, shape=None, initializer=None, trainable=True):
     full = '/'.join(st.scopes + [name])
     return st.store._get_variable(full, shape, initializer, trainable)
 
+def derived(key, fn):
+    """Per-training-op cache of a tensor derived from variables only, scoped like get_variable
+    (see Network.derived)."""
+    st = _stack()
+    if st.store is None:
+        return fn()
+    return st.store.derived('/'.join(st.scopes + [key]), fn)
+
 #----------------------------------------------------------------------------
 # Random source.  Default: torch device generator.  Tests install a RandomTape that replays
 # recorded tensors in call order, and can record what the default source produced.

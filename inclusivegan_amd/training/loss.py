@@ -33,45 +33,46 @@ def G_logistic_ns_rec_interp_arb_pathreg(G, D, lpips, training_set, minibatch_si
     reg = None
 
     if phase in ('both', 'loss'):
+        # The reference evaluates G four times on the same weights (rec_1 :25, rec_2 :26, interp :39,
+        # arb :48).  Here the four latent batches go through ONE generator pass (G_main num_calls=4 keeps
+        # the per-call semantics: own style-mixing cutoff, own dlatent_avg update) and ONE VGG pass per
+        # gradient role -- bigger GEMMs, a quarter of the launches, identical values.
+        latents_random_shape = [minibatch_size] + latent_shape
         if NN_rec_lpips_weight != 0:
-            # loss.py:25-33
-            rec_images_1_out = G.get_output_for(latents_rec_1, labels_rec_1, is_training=True)
-            rec_images_2_out = G.get_output_for(latents_rec_2, labels_rec_2, is_training=True)
-            rec_images_1_out = (rec_images_1_out + 1) * (255 / 2)
-            rec_images_2_out = (rec_images_2_out + 1) * (255 / 2)
-            reals_1 = (reals_rec_1 + 1) * (255 / 2)
-            reals_2 = (reals_rec_2 + 1) * (255 / 2)
+            interp_factors = tfutil.random_uniform([minibatch_size, 1], dev, 0.0, 1.0)          # :36
+            latents_random = tfutil.random_normal(latents_random_shape, dev)                     # :46
+            interp_latents = tflib.slerp(latents_rec_2, latents_rec_1, interp_factors)          # :37
+            interp_labels = tflib.lerp(labels_rec_2, labels_rec_1, interp_factors)              # :38
+            labels_random = training_set.get_random_labels_tf(minibatch_size)                    # :47
+            z_all = torch.cat([latents_rec_1, latents_rec_2, interp_latents, latents_random], dim=0)
+            l_all = torch.cat([labels_rec_1, labels_rec_2, interp_labels, labels_random], dim=0)
+            imgs = G.get_output_for(z_all, l_all, is_training=True, num_calls=4)
+            n = minibatch_size
+            arb_images_out = imgs[3 * n:]
+            gen_255 = (imgs[:3 * n] + 1) * (255 / 2)                                             # :27-28,40
+            reals_255 = (torch.cat([reals_rec_1, reals_rec_2], dim=0) + 1) * (255 / 2)           # :29-30
 
-            # loss.py:36-40
-            interp_factors = tfutil.random_uniform([minibatch_size, 1], dev, 0.0, 1.0)
-            interp_latents = tflib.slerp(latents_rec_2, latents_rec_1, interp_factors)
-            interp_labels = tflib.lerp(labels_rec_2, labels_rec_1, interp_factors)
-            interp_images_out = G.get_output_for(interp_latents, interp_labels, is_training=True)
-            interp_images_out = (interp_images_out + 1) * (255 / 2)
-
-            # VGG features once per image batch (the reference graph evaluates reals and the interpolated
-            # image twice, :31,41 -- same values).
             with torch.no_grad():
-                f_real_1 = lpips_mod.features_of(lpips, reals_1)
-                f_real_2 = lpips_mod.features_of(lpips, reals_2)
-            f_rec_1 = lpips_mod.features_of(lpips, rec_images_1_out)
-            f_rec_2 = lpips_mod.features_of(lpips, rec_images_2_out)
-            f_interp = lpips_mod.features_of(lpips, interp_images_out)
+                f_real = lpips_mod.features_of(lpips, reals_255)
+            f_gen = lpips_mod.features_of(lpips, gen_255)
+            f_real_1 = [f[:n] for f in f_real]; f_real_2 = [f[n:] for f in f_real]
+            f_rec_1 = [f[:n] for f in f_gen]; f_rec_2 = [f[n:2 * n] for f in f_gen]; f_interp = [f[2 * n:] for f in f_gen]
 
-            loss_NN_rec_lpips = (lpips_mod.distance_of(lpips, f_rec_1, f_real_1) + lpips_mod.distance_of(lpips, f_rec_2, f_real_2)) * 0.5
+            loss_NN_rec_lpips = (lpips_mod.distance_of(lpips, f_rec_1, f_real_1) + lpips_mod.distance_of(lpips, f_rec_2, f_real_2)) * 0.5   # :31
             loss_NN_rec_lpips = loss_NN_rec_lpips * NN_rec_lpips_weight
             loss_NN_rec_lpips = autosummary('Loss/loss_NN_rec_lpips', loss_NN_rec_lpips)
             loss = loss_addup(loss, loss_NN_rec_lpips)
 
-            loss_NN_interp_lpips = tflib.lerp(lpips_mod.distance_of(lpips, f_interp, f_real_2), lpips_mod.distance_of(lpips, f_interp, f_real_1), interp_factors.squeeze(1))
+            loss_NN_interp_lpips = tflib.lerp(lpips_mod.distance_of(lpips, f_interp, f_real_2), lpips_mod.distance_of(lpips, f_interp, f_real_1), interp_factors.squeeze(1))   # :41
             loss_NN_interp_lpips = loss_NN_interp_lpips * (NN_rec_lpips_weight * 0.4)
             loss_NN_interp_lpips = autosummary('Loss/loss_NN_interp_lpips', loss_NN_interp_lpips)
             loss = loss_addup(loss, loss_NN_interp_lpips)
+        else:
+            latents_random = tfutil.random_normal(latents_random_shape, dev)
+            labels_random = training_set.get_random_labels_tf(minibatch_size)
+            arb_images_out = G.get_output_for(latents_random, labels_random, is_training=True)
 
-        # loss.py:46-52
-        latents_random = tfutil.random_normal([minibatch_size] + latent_shape, dev)
-        labels_random = training_set.get_random_labels_tf(minibatch_size)
-        arb_images_out = G.get_output_for(latents_random, labels_random, is_training=True)
+        # loss.py:49-52
         arb_scores_out, _ = D.get_output_for(arb_images_out, labels_random, is_training=True)
         loss_G_arb = F.softplus(-arb_scores_out)
         loss_G_arb = autosummary('Loss/loss_G_arb', loss_G_arb)

@@ -40,7 +40,8 @@ def get_weight(shape, gain=1, use_wscale=True, lrmul=1, weight_var='weight', ini
         init_std = he_std / lrmul
         runtime_coef = lrmul
     w = get_variable(weight_var, shape=shape, initializer=('normal', init_std * init_mul))
-    return w * float(runtime_coef)
+    # one multiply per training op, shared by every forward pass of that op (tfutil.derived)
+    return tfutil.derived(weight_var + ':scaled', lambda: w * float(runtime_coef))
 
 #----------------------------------------------------------------------------
 # Fully-connected layer (:41-46).
@@ -102,7 +103,7 @@ def modulated_conv2d_layer(x, y, fmaps, kernel, up=False, down=False, demodulate
     # Demodulate: d[b,o] = rsqrt(sum_{k,k,i} (w*s)^2 + 1e-8) = rsqrt((s^2) @ (sum_kk w^2) + 1e-8).
     d = None
     if demodulate:
-        wsq = (w * w).sum(dim=(0, 1))                    # [I,O]
+        wsq = tfutil.derived(weight_var + ':sumsq', lambda: (w * w).sum(dim=(0, 1)))   # [I,O]
         d = torch.rsqrt(hip_ops.matmul(s * s, wsq) + 1e-8) # [BO]
 
     # Convolution with optional up/downsampling; scales folded into the kernel.
@@ -162,6 +163,9 @@ def G_main(
     mapping_func            = 'G_mapping',
     synthesis_func          = 'G_synthesis_stylegan2',
     init_mul                = 1.0,
+    num_calls               = 1,        # extension: evaluate the batch as `num_calls` independent calls of
+                                        # batch/num_calls samples (per-call style-mixing cutoff and dlatent_avg
+                                        # update): the same function as calling G that many times, in one pass.
     **kwargs):
 
     # Validate arguments (:171-183).
@@ -196,21 +200,29 @@ def G_main(
     # Evaluate mapping network.
     dlatents = components.mapping.get_output_for(latents_in, labels_in, is_training=is_training, **kwargs)
 
-    # Update moving average of W (:202-207).
+    batch = int(latents_in.shape[0])
+    assert batch % num_calls == 0
+    per_call = batch // num_calls
+
+    # Update moving average of W (:202-207), once per (virtual) call, in call order.
     if dlatent_avg_beta is not None and not is_template_graph:
         with torch.no_grad():
-            batch_avg = dlatents[:, 0].mean(dim=0)
-            dlatent_avg.copy_(tfutil.lerp(batch_avg, dlatent_avg, dlatent_avg_beta))
+            call_avgs = dlatents[:, 0].reshape(num_calls, per_call, -1).mean(dim=1)
+            for k in range(num_calls):
+                dlatent_avg.copy_(tfutil.lerp(call_avgs[k], dlatent_avg, dlatent_avg_beta))
 
-    # Perform style mixing regularization (:210-221).
+    # Perform style mixing regularization (:210-221); the coin and the cutoff are per call.
     if style_mixing_prob is not None:
         latents2 = tfutil.random_normal(latents_in.shape, dev)
         dlatents2 = components.mapping.get_output_for(latents2, labels_in, is_training=is_training, **kwargs)
         layer_idx = torch.arange(num_layers, device=dev)[None, :, None]
         cur_layers = num_layers   # lod is always 0 on this path (no progressive growing, training_loop.py:93-94)
-        u = tfutil.random_uniform((), dev, 0.0, 1.0)
-        r = tfutil.random_int(1, cur_layers, dev)
-        mixing_cutoff = torch.where(u < style_mixing_prob, r, torch.full_like(r, cur_layers))
+        cutoffs = []
+        for _k in range(num_calls):
+            u = tfutil.random_uniform((), dev, 0.0, 1.0)
+            r = tfutil.random_int(1, cur_layers, dev)
+            cutoffs.append(torch.where(u < style_mixing_prob, r, torch.full_like(r, cur_layers)))
+        mixing_cutoff = cutoffs[0] if num_calls == 1 else torch.stack(cutoffs).repeat_interleave(per_call)[:, None, None]
         dlatents = torch.where(layer_idx < mixing_cutoff, dlatents, dlatents2)
 
     # Apply truncation trick (:224-232).

@@ -283,6 +283,7 @@ def training_loop(
     use_graphs = graphs.graphs_enabled(hip_graphs)
 
     def G_grad():
+        G.invalidate_derived(); D.invalidate_derived()
         D.requires_grad_(False)
         reals_1, labels_1 = process_reals(feed['reals_rec_1'], feed['labels_rec_1'], 0, mirror_augment, training_set.dynamic_range, drange_net)
         reals_2, labels_2 = process_reals(feed['reals_rec_2'], feed['labels_rec_2'], 0, mirror_augment, training_set.dynamic_range, drange_net)
@@ -294,6 +295,7 @@ def training_loop(
         return loss
 
     def G_reg_grad():
+        G.invalidate_derived(); D.invalidate_derived()
         D.requires_grad_(False)
         _, reg = G_loss_fn(G=G, D=D, lpips=lpips, training_set=training_set, minibatch_size=B,
                            reals_rec_1=None, labels_rec_1=None, latents_rec_1=feed['latents_rec_1'],
@@ -303,6 +305,7 @@ def training_loop(
         return reg
 
     def D_grad():
+        G.invalidate_derived(); D.invalidate_derived()
         reals, labels = process_reals(feed['reals'], feed['labels'], 0, mirror_augment, training_set.dynamic_range, drange_net)
         G.requires_grad_(False)
         loss, _ = D_loss_fn(G=G, D=D, training_set=training_set, minibatch_size=B, reals=reals, labels=labels, phase='loss', **D_loss_args)
@@ -311,6 +314,7 @@ def training_loop(
         return loss
 
     def D_reg_grad():
+        G.invalidate_derived(); D.invalidate_derived()
         reals, labels = process_reals(feed['reals'], feed['labels'], 0, mirror_augment, training_set.dynamic_range, drange_net)
         G.requires_grad_(False)
         _, reg = D_loss_fn(G=G, D=D, training_set=training_set, minibatch_size=B, reals=reals, labels=labels, phase='reg', **D_loss_args)
