@@ -24,6 +24,21 @@ import torch
 from ... import hip_ops
 
 
+def allreduce_mean_(flat_grads, num_registered=1, group=None):
+    """Gradient averaging of optimizer.py:169-201 on the flat bucket, in place: scale by
+    1 / (registrations * world size), then ONE all-reduce(sum) over the data-parallel group (the reference
+    issues one nccl all_sum per variable).  Backend-agnostic (RCCL on GPUs, gloo in the CPU tests)."""
+    world = 1
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        world = torch.distributed.get_world_size(group)
+    scale = 1.0 / num_registered / world    # optimizer.py:186
+    if scale != 1.0:
+        flat_grads.mul_(scale)
+    if world > 1:
+        torch.distributed.all_reduce(flat_grads, op=torch.distributed.ReduceOp.SUM, group=group)  # :199
+    return flat_grads
+
+
 class Optimizer:
     def __init__(self, name='Train', learning_rate=0.001, share=None, beta1=0.9, beta2=0.999, epsilon=1e-8,
                  minibatch_multiplier=None, use_loss_scaling=False, process_group=None, **kwargs):
@@ -88,15 +103,7 @@ class Optimizer:
             raise RuntimeError('Optimizer.apply_updates() without registered gradients')
         net = self._net
         st = self._state
-        g = net.flat_grads
-        world = 1
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            world = torch.distributed.get_world_size(self.process_group)
-        scale = 1.0 / self._num_registered / world    # optimizer.py:186
-        if scale != 1.0:
-            g.mul_(scale)
-        if world > 1:
-            torch.distributed.all_reduce(g, op=torch.distributed.ReduceOp.SUM, group=self.process_group)  # :199
+        g = allreduce_mean_(net.flat_grads, self._num_registered, self.process_group)
         lr = self.learning_rate() if callable(self.learning_rate) else self.learning_rate
         with torch.no_grad():
             st['flag'].zero_()

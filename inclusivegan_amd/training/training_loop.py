@@ -108,6 +108,15 @@ def _dist_info():
     return 0, 1
 
 
+def combine_best_(best, world):
+    """Merge the per-rank running minima: packed (fp32 distance bits << 32 | candidate index) words are
+    non-negative int64, so an element-wise all-reduce(min) keeps, for every real, the closest candidate
+    over all ranks' shards (ties -> lowest index)."""
+    if world > 1:
+        torch.distributed.all_reduce(best, op=torch.distributed.ReduceOp.MIN)
+    return best
+
+
 def imle_refresh(G, training_set_rec, latent_candidates, data_size, minibatch_size, candidate_batch_size,
                  drange_net, device, rank=0, world=1, query_chunk=4096):
     """IMLE assignment (:357-406, non-exclusive, no projection): every real image (dataset order,
@@ -147,8 +156,7 @@ def imle_refresh(G, training_set_rec, latent_candidates, data_size, minibatch_si
             for q0 in range(0, data_size, query_chunk):
                 hip_ops.nn1_update_raw(reals[q0:q0 + query_chunk], rnorm[q0:q0 + query_chunk], cand, cnorm,
                                        best[q0:q0 + query_chunk], c0)
-    if world > 1:
-        torch.distributed.all_reduce(best, op=torch.distributed.ReduceOp.MIN)
+    combine_best_(best, world)
     idx, dist = unpack_best(best)
     return idx.cpu().numpy(), dist.cpu().numpy().astype(np.float64)
 
