@@ -71,9 +71,16 @@ def headline_shape_roofline(device, batch, reps=20):
     ms = e0.elapsed_time(e1) / reps
     flops = 2.0 * batch * res * res * cout * cin * 9
     achieved = flops / (ms * 1e-3) / 1e12
-    return dict(shape='modulated conv 128x128 3x3 Cin=Cout=128 batch %d (M=%d N=128 K=1152)' % (batch, batch * res * res),
-                achieved=round(achieved, 2), frac=round(achieved / F32_MATRIX_PEAK_TFLOPS, 4),
-                flops_per_launch=flops, us_per_launch=round(ms * 1e3, 1))
+    out = dict(shape='modulated conv 128x128 3x3 Cin=Cout=128 batch %d (M=%d N=128 K=1152)' % (batch, batch * res * res),
+               achieved=round(achieved, 2), frac=round(achieved / F32_MATRIX_PEAK_TFLOPS, 4),
+               flops_per_launch=flops, us_per_launch=round(ms * 1e3, 1), traffic=None)
+    # HBM-side bytes per launch of this shape from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled per
+    # the gfx950 correction + WRITE_SIZE); only valid for the batch they were taken at.
+    pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_conv_headline.json')
+    if batch == 6 and os.path.isfile(pmc):
+        with open(pmc) as f:
+            out['traffic'] = json.load(f)['traffic_bytes_per_launch']
+    return out
 
 
 def step_roofline(log):

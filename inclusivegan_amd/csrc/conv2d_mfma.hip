@@ -35,6 +35,7 @@
 //    across workgroups; partial tiles go to a caller-owned workspace and a second
 //    kernel adds them in fixed order (bit-reproducible, no float atomics).
 #include "igan_common.h"
+#include <cmath>
 
 namespace {
 
@@ -609,12 +610,23 @@ extern "C" int igan_conv2d_plan(const igan_conv2d_params* p, int* splits, size_t
     fwd_counts(p, Mmax, chunks_max, nclass);
     const FwdTile t = pick_fwd_tile(Mmax, p->Cout);
     const long long blocks = (long long)igan::ceil_div(Mmax, t.BM) * igan::ceil_div(p->Cout, t.BN) * nclass;
+    // Split-K choice by a small cost model.  The kernel keeps 2 workgroups per CU resident = 512 slots;
+    // a grid of T tiles takes ceil(T*s/512)/s "tile times" when every tile is cut into s slices, so a
+    // 768-tile layer (1.5 rounds -> 2 tile times) runs in 1.5 with s = 2 and a 384-tile layer (0.75 of
+    // a round -> 1 tile time) in 0.75 with s = 4.  Against that stands the partial-sum traffic
+    // ((2s+1) x output bytes through HBM) of the fixed-order reduce.
+    const double slots = 512.0;
+    const double chunk_s = 4.6e-6 * (t.BM == 128 ? 1.0 : 0.4) * (t.BN / 128.0 > 0.5 ? 1.0 : 0.5);   // one chunk, 2 co-resident workgroups
+    const double out_bytes = 4.0 * p->N * p->OH * p->OW * p->Cout;
+    const double bw = 4.0e12;
+    const int cand[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
     int s = 1;
-    if (blocks < 256) {
-        s = (int)((512 + blocks - 1) / blocks);
-        s = std::min(s, std::max(1, chunks_max / 2));
-        s = std::min(s, 64);
-        s = std::max(s, 1);
+    double best = 1e30;
+    for (int c : cand) {
+        if (c > 1 && c > std::max(1, chunks_max / 2)) break;
+        const double rounds = std::ceil((double)blocks * c / slots) / c;
+        double tt = rounds * chunks_max * chunk_s + (c > 1 ? (2.0 * c + 1.0) * out_bytes / bw + 4e-6 : 0.0);
+        if (tt < best * 0.90) { best = tt; s = c; }   // prefer fewer slices unless clearly (>10 %) better
     }
     *splits = s;
     *workspace_floats = (s > 1) ? (size_t)s * p->N * p->OH * p->OW * p->Cout : 0;

@@ -69,6 +69,7 @@ class Network:
             self.flat_params = None
             self.flat_grads = None
             self._derived = {}            # per-training-op cache of tensors derived from variables only
+            self._derived_depth = 0       # > 0 while inside derived_scope()
 
         # Template pass on the meta device: creates variable specs, infers shapes.
         self.input_names = [p.name for p in inspect.signature(self._build_func).parameters.values()
@@ -123,13 +124,12 @@ class Network:
         return torch.empty(shape, device='meta')
 
     def derived(self, key, fn):
-        """Cache of tensors that depend on the network's variables only (e.g. the equalised-LR weight
-        w * runtime_coef, networks_stylegan2.py:36, or sum_k w^2 for demodulation): computed once per
-        training op and shared by all forward passes of that op (the G loss runs G four times on
-        unchanged weights).  Keyed by autograd mode; `invalidate_derived()` must be called whenever the
-        variables change (optimizer update, EMA, copy) -- the training loop does so at the start of every op."""
+        """Tensors that depend on the network's variables only (the equalised-LR weight w * runtime_coef,
+        networks_stylegan2.py:36; sum_k w^2 for demodulation).  Inside a `derived_scope()` they are computed
+        once and shared by every forward pass of that scope (the G loss evaluates G on unchanged weights
+        several times); outside a scope nothing is cached."""
         root = self._root
-        if root._templating or root.device.type == 'meta':
+        if root._derived_depth == 0 or root._templating or root.device.type == 'meta':
             return fn()
         k = (self._prefix, key, torch.is_grad_enabled())
         v = root._derived.get(k)
@@ -137,6 +137,24 @@ class Network:
             v = fn()
             root._derived[k] = v
         return v
+
+    def derived_scope(self):
+        """Context manager delimiting one training op: variables must not change inside it."""
+        import contextlib
+        root = self._root
+
+        @contextlib.contextmanager
+        def scope():
+            if root._derived_depth == 0:
+                root._derived.clear()
+            root._derived_depth += 1
+            try:
+                yield
+            finally:
+                root._derived_depth -= 1
+                if root._derived_depth == 0:
+                    root._derived.clear()
+        return scope()
 
     def invalidate_derived(self):
         self._root._derived.clear()

@@ -26,6 +26,12 @@ def _lpips_pair(lpips, a, b):
 def G_logistic_ns_rec_interp_arb_pathreg(G, D, lpips, training_set, minibatch_size, reals_rec_1, labels_rec_1, latents_rec_1, reals_rec_2, labels_rec_2, latents_rec_2,
     NN_rec_lpips_weight,
     pl_minibatch_shrink=2, pl_decay=0.01, pl_weight=2.0, phase='both'):
+    with G.derived_scope(), D.derived_scope():     # weights are constant inside one loss evaluation
+        return _G_loss_impl(G, D, lpips, training_set, minibatch_size, reals_rec_1, labels_rec_1, latents_rec_1, reals_rec_2, labels_rec_2,
+                            latents_rec_2, NN_rec_lpips_weight, pl_minibatch_shrink, pl_decay, pl_weight, phase)
+
+def _G_loss_impl(G, D, lpips, training_set, minibatch_size, reals_rec_1, labels_rec_1, latents_rec_1, reals_rec_2, labels_rec_2, latents_rec_2,
+    NN_rec_lpips_weight, pl_minibatch_shrink, pl_decay, pl_weight, phase):
     assert phase in ('both', 'loss', 'reg')
     dev = latents_rec_1.device
     latent_shape = G.input_shapes[0][1:]
@@ -106,6 +112,10 @@ def G_logistic_ns_rec_interp_arb_pathreg(G, D, lpips, training_set, minibatch_si
 
 def D_logistic_r1(G, D, training_set, minibatch_size, reals, labels,
     gamma=10.0, phase='both'):
+    with G.derived_scope(), D.derived_scope():
+        return _D_loss_impl(G, D, training_set, minibatch_size, reals, labels, gamma, phase)
+
+def _D_loss_impl(G, D, training_set, minibatch_size, reals, labels, gamma, phase):
     assert phase in ('both', 'loss', 'reg')
     dev = reals.device
     latent_shape = G.input_shapes[0][1:]
@@ -122,8 +132,20 @@ def D_logistic_r1(G, D, training_set, minibatch_size, reals, labels,
         labels_random = training_set.get_random_labels_tf(minibatch_size * 2)
         with torch.no_grad():   # only D's trainables are differentiated in this step (training_loop.py:291)
             arb_images_out = G.get_output_for(latents_random, labels_random, is_training=True)
-        arb_scores_out, _ = D.get_output_for(arb_images_out, labels_random, is_training=True)
-        real_scores_out, _ = D.get_output_for(reals, labels, is_training=True)
+        gs = D.static_kwargs.get('mbstd_group_size', 6)
+        if phase == 'loss' and arb_images_out.shape == reals.shape and (gs <= 1 or int(reals.shape[0]) % gs == 0):
+            # D(fakes) and D(reals) (:101-102) as ONE pass: the two minibatches are interleaved so that
+            # every sample keeps the minibatch-stddev group it has in a separate pass (all other layers are
+            # per-sample), i.e. the scores are those of the two reference calls.
+            perm, inv = _mbstd_preserving_interleave(int(reals.shape[0]), gs, dev)
+            both = torch.cat([arb_images_out, reals], dim=0).index_select(0, perm)
+            both_labels = torch.cat([labels_random, labels], dim=0).index_select(0, perm)
+            scores, _ = D.get_output_for(both, both_labels, is_training=True)
+            scores = scores.index_select(0, inv)
+            arb_scores_out, real_scores_out = scores[:reals.shape[0]], scores[reals.shape[0]:]
+        else:
+            arb_scores_out, _ = D.get_output_for(arb_images_out, labels_random, is_training=True)
+            real_scores_out, _ = D.get_output_for(reals, labels, is_training=True)
         loss_D = F.softplus(arb_scores_out) + F.softplus(-real_scores_out)
         loss_D = autosummary('Loss/loss_D', loss_D)
         loss = loss_addup(loss, loss_D)
@@ -140,6 +162,30 @@ def D_logistic_r1(G, D, training_set, minibatch_size, reals, labels,
     return loss, reg
 
 #----------------------------------------------------------------------------
+
+_interleave_cache = {}
+
+def _mbstd_preserving_interleave(n, group_size, device):
+    """Index tensors (perm, inv) for evaluating two minibatches a, b of n samples each in one D pass.
+    minibatch_stddev_layer (networks_stylegan2.py:132-144) groups sample i of an n-batch with
+    {i mod M} where M = n / G, G = min(group_size, n).  In the combined 2n-batch M' = 2M, so placing
+    a's group m at residue m and b's group m at residue M + m,
+        combined[g * 2M + m]     = a[g * M + m],    combined[g * 2M + M + m] = b[g * M + m],
+    reproduces both partitions.  perm indexes cat(a, b); inv undoes it."""
+    key = (n, group_size, str(device))
+    if key not in _interleave_cache:
+        G = min(group_size, n) if group_size > 1 else 1
+        assert n % G == 0
+        M = n // G
+        perm = np.empty(2 * n, dtype=np.int64)
+        for g in range(G):
+            for m in range(M):
+                perm[g * 2 * M + m] = g * M + m
+                perm[g * 2 * M + M + m] = n + g * M + m
+        inv = np.empty_like(perm)
+        inv[perm] = np.arange(2 * n)
+        _interleave_cache[key] = (torch.from_numpy(perm).to(device), torch.from_numpy(inv).to(device))
+    return _interleave_cache[key]
 
 def loss_addup(loss, loss_):
     if loss is None:

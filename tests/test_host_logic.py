@@ -175,3 +175,17 @@ def test_data_parallel_exchange_gloo_world2():
     assert r0[1] == [20, 11, 5] and r1[1] == [20, 11, 5]         # per-real winner over both shards; tie (9.0) -> lower index
     assert r0[2] == [pytest.approx(2.0 ** 0.5), 1.0, 3.0]        # Euclidean (sqrt) distances
     assert r0[3] == r1[3]
+
+
+def test_mbstd_preserving_interleave_is_exact():
+    """One D pass over interleaved (fakes, reals) gives every sample the minibatch-stddev statistic of its own
+    separate pass (loss.D_logistic_r1 relies on this)."""
+    from inclusivegan_amd.training.loss import _mbstd_preserving_interleave
+    from oracle.networks_stylegan2 import minibatch_stddev_layer
+    for n, g in [(12, 6), (6, 6), (24, 6), (8, 4)]:
+        a = torch.randn(n, 4, 4, 4, dtype=torch.float64)
+        b = torch.randn(n, 4, 4, 4, dtype=torch.float64)
+        perm, inv = _mbstd_preserving_interleave(n, g, 'cpu')
+        assert sorted(perm.tolist()) == list(range(2 * n)) and torch.equal(perm[inv], torch.arange(2 * n))
+        y = minibatch_stddev_layer(torch.cat([a, b]).index_select(0, perm), g).index_select(0, inv)
+        assert torch.equal(y[:n], minibatch_stddev_layer(a, g)) and torch.equal(y[n:], minibatch_stddev_layer(b, g))

@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Single-kernel microbenchmarks for roofline evidence (run bare, or under rocprofv3 --pmc ...).
+  python tools/kernel_bench.py conv     [batch] [reps]   modulated conv 128x128 (north-star GEMM shape) -> TFLOP/s vs 157.3
+  python tools/kernel_bench.py upfirdn  [batch] [reps]   the three upfirdn2d call sites at 128x128     -> GB/s vs 8 TB/s
+  python tools/kernel_bench.py epilogue [batch] [reps]   fused noise+bias+lrelu forward / backward      -> GB/s
+Algorithmic bytes = (numel_in + numel_out) * 4."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from inclusivegan_amd import hip_ops  # noqa: E402
+
+HBM_PEAK = 8000.0   # GB/s (spec); ~6300 achievable (MI355X_MICROARCH.md)
+
+
+def time_ms(fn, reps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    mode = sys.argv[1] if len(sys.argv) > 1 else 'conv'
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+    reps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+    dev = torch.device('cuda', 0)
+    if mode == 'conv':
+        x = torch.randn(B, 128, 128, 128, device=dev).contiguous(memory_format=torch.channels_last)
+        w = torch.randn(3, 3, 128, 128, device=dev) / 34.0
+        s = torch.rand(B, 128, device=dev) + 0.5
+        d = torch.rand(B, 128, device=dev) + 0.5
+        g = hip_ops.ConvGeom(3, 3, 1, 1, 1, 1)
+        ms = time_ms(lambda: hip_ops.conv2d_raw(x, w, g, (128, 128), 128, in_scale=s, out_scale=d), reps)
+        fl = 2.0 * B * 128 * 128 * 128 * 128 * 9
+        print('modconv 128x128 B=%d: %.1f us  %.1f TFLOP/s  = %.1f %% of 157.3' % (B, ms * 1e3, fl / ms / 1e9, fl / ms / 1e9 / 157.3 * 100))
+    elif mode == 'upfirdn':
+        k = np.outer([1, 3, 3, 1], [1, 3, 3, 1]).astype(np.float32) / 64
+        sites = [('G Conv0_up post-filter  [B,129,129,128] pad 1/1 x4', (B, 129, 129, 128), k * 4, 1, 1),
+                 ('D Conv1_down pre-filter [2B,128,128,128] pad 2/2', (2 * B, 128, 128, 128), k, 2, 2),
+                 ('D Skip pre-filter       [2B,128,128,128] pad 1/1', (2 * B, 128, 128, 128), k, 1, 1)]
+        for name, shape, kk, p0, p1 in sites:
+            x = torch.randn(*shape, device=dev)
+            y = hip_ops.upfirdn2d_raw(x, kk, 1, 1, 1, 1, p0, p1, p0, p1)
+            ms = time_ms(lambda: hip_ops.upfirdn2d_raw(x, kk, 1, 1, 1, 1, p0, p1, p0, p1), reps)
+            by = (x.numel() + y.numel()) * 4.0
+            print('%-52s %7.1f us  %7.1f GB/s = %.1f %% of 8 TB/s' % (name, ms * 1e3, by / ms / 1e6, by / ms / 1e6 / HBM_PEAK * 100))
+    elif mode == 'epilogue':
+        x = torch.randn(B, 128, 128, 128, device=dev).contiguous(memory_format=torch.channels_last)
+        b = torch.randn(128, device=dev); noise = torch.randn(B, 1, 128, 128, device=dev); st = torch.tensor(0.3, device=dev)
+        y = hip_ops.bias_act_noise_fwd_raw(x, noise, st, b, 3, 0.2, 2 ** 0.5)
+        ms = time_ms(lambda: hip_ops.bias_act_noise_fwd_raw(x, noise, st, b, 3, 0.2, 2 ** 0.5), reps)
+        print('epilogue fwd  [B,128,128,128] %7.1f us  %7.1f GB/s' % (ms * 1e3, 2 * x.numel() * 4 / ms / 1e6))
+        dy = torch.randn_like(x)
+        ms = time_ms(lambda: hip_ops.bias_act_noise_bwd_raw(dy, y, noise, 3, 0.2, 2 ** 0.5, True), reps)
+        print('epilogue bwd  [B,128,128,128] %7.1f us  %7.1f GB/s' % (ms * 1e3, 3 * x.numel() * 4 / ms / 1e6))
+    else:
+        raise SystemExit(__doc__)
+
+
+if __name__ == '__main__':
+    main()
