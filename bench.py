@@ -43,6 +43,7 @@ def parse_args():
     p.add_argument('--lpips-weight', type=float, default=2.5)
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true')
+    p.add_argument('--op-times', action='store_true', help='also report the mean device time of each training op (HIP events)')
     return p.parse_args()
 
 
@@ -191,7 +192,7 @@ def main():
     def on_iteration(info):
         state['iters'] += 1
         log('iteration %d done' % state['iters'])
-        if state['iters'] == args.warmup:
+        if state['iters'] == args.warmup and args.warmup > 0:
             barrier_sync()
             state['t_start'] = time.perf_counter()
         if state['iters'] == args.warmup + args.steps:
@@ -210,8 +211,12 @@ def main():
             return True
         return False
 
-    if args.warmup == 0:
-        raise SystemExit('--warmup must be >= 1 (the first iteration carries the IMLE refresh)')
+    def on_refresh(seconds):
+        state['refresh'].append(seconds)
+        log('IMLE refresh %.1f s' % seconds)
+        if args.warmup == 0 and state['t_start'] is None:     # the refresh opens iteration 1: start timing right after it
+            barrier_sync()
+            state['t_start'] = time.perf_counter()
 
     kwargs = dict(
         G_args=EasyDict(func_name='training.networks_stylegan2.G_main', init_mul=1.0, fmap_base=8 << 10, architecture='skip'),
@@ -224,7 +229,8 @@ def main():
         tf_config={'rnd.np_random_seed': 1000},
         total_kimg=10 ** 6, data_size=args.data_size, num_epochs=10000,
         init_staleness=10, num_samples_factor=args.num_samples_factor, knn_perturb_factor=0.05, candidate_batch_size=256,
-        hooks=dict(on_iteration=on_iteration, on_refresh=lambda s: (state['refresh'].append(s), log('IMLE refresh %.1f s' % s))),
+        hooks=dict(on_iteration=on_iteration, on_refresh=on_refresh,
+                   **({'op_times': state.setdefault('op_times', {})} if args.op_times else {})),
     )
     log('starting training loop')
     TL.training_loop(**kwargs)
@@ -246,6 +252,10 @@ def main():
                    'data_size': args.data_size, 'num_samples_factor': args.num_samples_factor},
         'imle_refresh_s': round(state['refresh'][0], 3) if state['refresh'] else None,
     }
+    if args.op_times:
+        torch.cuda.synchronize()
+        out['op_ms'] = {k: round(sum(a.elapsed_time(b) for a, b in v[2:]) / max(len(v) - 2, 1), 3) for k, v in state['op_times'].items()}
+        out['op_calls'] = {k: len(v) for k, v in state['op_times'].items()}
     if rank == 0:
         if not args.no_roofline:
             from inclusivegan_amd import hip_ops

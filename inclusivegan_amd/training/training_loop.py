@@ -330,10 +330,29 @@ def training_loop(
         D_reg_opt.differentiate(torch.mean(reg * D_reg_interval), D)   # :289
         return reg
 
-    G_grad_step = graphs.GraphedStep(G_grad, use_graphs, eager_calls=2, name='G')
+    G_grad_step = graphs.GraphedStep(G_grad, use_graphs, eager_calls=1, name='G')
     G_reg_step = graphs.GraphedStep(G_reg_grad, use_graphs, eager_calls=1, name='G_reg')
-    D_grad_step = graphs.GraphedStep(D_grad, use_graphs, eager_calls=2, name='D')
+    D_grad_step = graphs.GraphedStep(D_grad, use_graphs, eager_calls=1, name='D')
     D_reg_step = graphs.GraphedStep(D_reg_grad, use_graphs, eager_calls=1, name='D_reg')
+
+    if use_graphs:
+        # Build all four graphs before the first iteration: one eager dry run of each op's device work
+        # (creates every lazily allocated piece of state), then capture.  No optimizer update is applied;
+        # the state the dry runs touch (dlatent_avg, pl_mean, summary accumulators) is restored afterwards.
+        saved = {n: v.clone() for n, v in G.vars.items() if n in ('dlatent_avg',)}
+        for k in ('latents_rec_1', 'latents_rec_2'):
+            feed[k].normal_()
+        for step in (G_grad_step, G_reg_step, D_grad_step, D_reg_step):
+            step()      # eager
+            step()      # capture + first replay
+        with torch.no_grad():
+            for n, v in saved.items():
+                G.vars[n].copy_(v)
+            if hasattr(G, 'pl_mean_var'):
+                G.pl_mean_var.zero_()
+            G.flat_grads.zero_(); D.flat_grads.zero_()
+        autosummary_mod.flush()
+        torch.cuda.synchronize()
 
     def next_reals():
         # `training_set.get_minibatch_tf()` is an iterator op: every session.run that consumes it
@@ -456,13 +475,20 @@ def training_loop(
                 feed['latents_rec_%d' % (h + 1)].copy_(torch.from_numpy(np.ascontiguousarray(z_[rs]).astype(np.float32)), non_blocking=True)
 
             # Run training ops (:474-479).
-            G_train_op()
+            timed = hooks.get('op_times')          # optional: dict name -> list of (start, end) HIP events
+            def run(name, op):
+                if timed is None:
+                    return op()
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(); op(); e1.record()
+                timed.setdefault(name, []).append((e0, e1))
+            run('G_train', G_train_op)
             if run_G_reg:
-                G_reg_op()
-            D_train_op()
-            Gs_update_op()
+                run('G_reg', G_reg_op)
+            run('D_train', D_train_op)
+            run('Gs_update', Gs_update_op)
             if run_D_reg:
-                D_reg_op()
+                run('D_reg', D_reg_op)
 
             cur_nimg += mb * 2
             running_mb_counter += 1
