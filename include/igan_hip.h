@@ -203,6 +203,17 @@ size_t igan_scale_dot_workspace_floats(int N, int HW, int C);
 int igan_scale_dot(igan_stream_t stream, const float* a, const float* b, const float* s, float* out,
                    float* dot, float* workspace, int N, int HW, int C);
 
+/* LPIPS per-layer distance (Zhang et al. 2018; role of lpips.get_output_for, training/loss.py:31,41) on raw
+ * channel-minor VGG features fa, fb [N, HW, C], C in {64,128,256,512}, lin[C] >= 0:
+ *     partial[n][j] = sum over block j's pixels of sum_c lin_c (fa_c/(|fa|+1e-10) - fb_c/(|fb|+1e-10))^2
+ * (igan_lpips_layer_blocks(N, HW) partial sums per sample; caller adds them and divides by HW), and
+ *     dfa = g[n] * d(distance sum)/d fa        (swap fa, fb for the other argument).  One pass each. */
+int igan_lpips_layer_blocks(int N, int HW);
+int igan_lpips_layer_fwd(igan_stream_t stream, const float* fa, const float* fb, const float* lin,
+                         float* partial, int N, int HW, int C);
+int igan_lpips_layer_bwd(igan_stream_t stream, const float* fa, const float* fb, const float* lin,
+                         const float* g, float* dfa, int N, int HW, int C);
+
 /* ------------------------------------------------------------------------
  * minibatch_stddev_layer statistics (networks_stylegan2.py:132-144), NHWC input
  * x[N, H, W, C], group size G (N % G == 0, M = N / G, num_new_features = 1):

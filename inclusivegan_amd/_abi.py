@@ -93,6 +93,9 @@ SIGNATURES = {
     'igan_conv2d_wgrad': (_I, [_P, ctypes.POINTER(Conv2DWgradParams)]),
     'igan_scale_dot_workspace_floats': (_SZ, [_I, _I, _I]),
     'igan_scale_dot': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I]),
+    'igan_lpips_layer_blocks': (_I, [_I, _I]),
+    'igan_lpips_layer_fwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I]),
+    'igan_lpips_layer_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I]),
     'igan_mbstd_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I]),
     'igan_mbstd_bwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I]),
     'igan_row_sqnorm': (_I, [_P, _P, _P, _I, _I]),

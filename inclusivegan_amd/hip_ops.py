@@ -55,6 +55,21 @@ def _is_meta(t):
     return t.device.type == 'meta'
 
 
+def _needed(ctx, i):
+    """Is the gradient w.r.t. input i actually consumed by the running backward pass?
+    `ctx.needs_input_grad` is static (requires_grad of the input); when a backward is restricted to some
+    inputs -- torch.autograd.grad(scores, [reals]) for R1 (loss.py:108), grad(..., [dlatents]) for the
+    path-length term (loss.py:65), backward(inputs=one network's trainables) -- the engine prunes the
+    other branches, and computing e.g. a filter gradient for them is wasted MFMA time."""
+    if not ctx.needs_input_grad[i]:
+        return False
+    try:
+        node = ctx.next_functions[i][0]
+        return node is not None and torch._C._will_engine_execute_node(node)
+    except Exception:
+        return True
+
+
 def nhwc(x):
     """Logical NCHW tensor -> same tensor, physically [N,H,W,C] dense."""
     return x.contiguous(memory_format=CL)
@@ -225,7 +240,7 @@ class FusedBiasActFn(torch.autograd.Function):
         (ref,) = ctx.saved_tensors
         axis, act_idx, alpha, gain, size_b, step_b, zero_2nd = ctx.cfg
         dx = _FbaGradFn.apply(dy, None, ref, axis, act_idx, alpha, gain, size_b, step_b, zero_2nd)
-        db = _BiasGradFn.apply(dx, axis, size_b, step_b) if ctx.has_b else None
+        db = _BiasGradFn.apply(dx, axis, size_b, step_b) if (ctx.has_b and _needed(ctx, 1)) else None
         return (dx, db) + (None,) * 6
 
 
@@ -284,8 +299,8 @@ class BiasActNoiseFn(torch.autograd.Function):
     def backward(ctx, dy):
         y, noise = ctx.saved_tensors
         act_idx, alpha, gain = ctx.cfg
-        need_b = ctx.has_b and ctx.needs_input_grad[1]
-        need_s = noise is not None and ctx.needs_input_grad[3]
+        need_b = ctx.has_b and _needed(ctx, 1)
+        need_s = noise is not None and _needed(ctx, 3)
         if torch.is_grad_enabled():
             c = y.shape[1]
             dx = _FbaGradFn.apply(dy, None, y, 1, act_idx, alpha, gain, c, 1, True)
@@ -459,9 +474,9 @@ class Conv2dFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dx = dw = None
-        if ctx.needs_input_grad[0]:
+        if _needed(ctx, 0):
             dx = ConvDgradFn.apply(dy, w, ctx.geom, ctx.in_hw)
-        if ctx.needs_input_grad[1]:
+        if _needed(ctx, 1):
             dw = ConvWgradFn.apply(x, dy, ctx.geom)
         return dx, dw, None, None
 
@@ -480,9 +495,9 @@ class ConvDgradFn(torch.autograd.Function):
     def backward(ctx, ddx):
         dy, w = ctx.saved_tensors
         d_dy = d_w = None
-        if ctx.needs_input_grad[0]:
+        if _needed(ctx, 0):
             d_dy = Conv2dFn.apply(ddx, w, ctx.geom, ctx.out_hw)
-        if ctx.needs_input_grad[1]:
+        if _needed(ctx, 1):
             d_w = ConvWgradFn.apply(ddx, dy, ctx.geom)
         return d_dy, d_w, None, None
 
@@ -500,9 +515,9 @@ class ConvWgradFn(torch.autograd.Function):
     def backward(ctx, ddw):
         x, dy = ctx.saved_tensors
         d_x = d_dy = None
-        if ctx.needs_input_grad[0]:
+        if _needed(ctx, 0):
             d_x = ConvDgradFn.apply(dy, ddw, ctx.geom, (x.shape[2], x.shape[3]))
-        if ctx.needs_input_grad[1]:
+        if _needed(ctx, 1):
             d_dy = Conv2dFn.apply(x, ddw, ctx.geom, (dy.shape[2], dy.shape[3]))
         return d_x, d_dy, None
 
@@ -559,7 +574,7 @@ class ModConv2dFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w, s, d, y = ctx.saved_tensors
         geom = ctx.geom
-        need_x, need_w, need_s, need_d = ctx.needs_input_grad[:4]
+        need_x, need_w, need_s, need_d = [_needed(ctx, i) for i in range(4)]
         in_hw = (x.shape[2], x.shape[3])
         if torch.is_grad_enabled():
             # create_graph=True: the partial derivatives w.r.t. (x, w, s, d) -- each treated as an
@@ -612,6 +627,45 @@ def modconv_composite(x, w, s, d, geom, out_hw):
     if d is not None:
         y = y * d[:, :, None, None]
     return y
+
+
+# ----------------------------------------------------------------------------
+# LPIPS per-layer distance (fused normalise / diff / lin / spatial sum)
+
+class LpipsLayerFn(torch.autograd.Function):
+    """sum_{h,w} sum_c lin_c (fa_c/|fa| - fb_c/|fb|)^2 per sample, on raw VGG features (channels_last)."""
+
+    @staticmethod
+    def forward(ctx, fa, fb, lin):
+        if _is_meta(fa):
+            return torch.empty((fa.shape[0],), device='meta')
+        lib = _abi.get_plugin()
+        _require_cuda_f32(fa, fb, lin)
+        fa = nhwc(fa)
+        fb = nhwc(fb)
+        lin = lin.contiguous()
+        n, c, h, w = fa.shape
+        blocks = lib.igan_lpips_layer_blocks(n, h * w)
+        partial = torch.empty((n, blocks), device=fa.device, dtype=torch.float32)
+        _abi.check(lib.igan_lpips_layer_fwd(_stream(), _ptr(fa), _ptr(fb), _ptr(lin), _ptr(partial), n, h * w, c))
+        ctx.save_for_backward(fa, fb, lin)
+        return partial.sum(dim=1)
+
+    @staticmethod
+    def backward(ctx, g):
+        if torch.is_grad_enabled():
+            raise NotImplementedError('LPIPS distance: second-order gradients are not built (the reconstruction term is first-order)')
+        fa, fb, lin = ctx.saved_tensors
+        lib = _abi.get_plugin()
+        n, c, h, w = fa.shape
+        g = g.contiguous()
+        outs = [None, None]
+        for i, (p, q) in enumerate(((fa, fb), (fb, fa))):     # the distance is symmetric in (fa, fb)
+            if _needed(ctx, i):
+                d = torch.empty_like(p)
+                _abi.check(lib.igan_lpips_layer_bwd(_stream(), _ptr(p), _ptr(q), _ptr(lin), _ptr(g), _ptr(d), n, h * w, c))
+                outs[i] = d
+        return outs[0], outs[1], None
 
 
 # ----------------------------------------------------------------------------

@@ -62,7 +62,8 @@ def _consts(dev):
 
 
 def vgg_features(images):
-    """images: [N,3,H,W] in [0,255] -> list of 5 channel-normalised feature maps."""
+    """images: [N,3,H,W] in [0,255] -> list of the 5 raw feature maps (relu1_2 ... relu5_3); the channel
+    unit-normalisation is folded into `feature_distance`."""
     dev = images.device
     shift, scale = _consts(dev)
     x = (images / 127.5 - 1.0 - shift) / scale
@@ -73,8 +74,7 @@ def vgg_features(images):
             x = torch.nn.functional.max_pool2d(x, 2)
         for li, c in enumerate(chans):
             x = _conv_relu(x, c, '%s_%d' % (block, li + 1))
-        norm = torch.sqrt(torch.sum(x * x, dim=1, keepdim=True)) + 1e-10
-        feats.append(x / norm)
+        feats.append(x)
     return feats
 
 
@@ -86,8 +86,8 @@ def feature_distance(feats_a, feats_b):
         # seeded non-negative lin weights |N(0,1)|/c, stored as a constant
         lin = get_variable('lin%d/weight' % i, shape=[c], initializer=('normal', 1.0), trainable=False)
         lin = torch.abs(lin) / c
-        d = (fa - fb) ** 2
-        d = (d * lin.view(1, c, 1, 1)).sum(dim=1).mean(dim=(1, 2))
+        # normalise over channels, squared difference, lin weighting, spatial mean: one fused pass
+        d = hip_ops.LpipsLayerFn.apply(fa, fb, lin) / float(fa.shape[2] * fa.shape[3])
         total = d if total is None else total + d
     return total
 
