@@ -59,6 +59,7 @@ struct ConvArgs {
     int cpt;                // chunks per tap = ceil(Cin / 32)
     int Mtot;               // N*OH*OW
     int vecA, vecB, vecS;   // 16 B paths usable for x rows / w rows / in_scale rows
+    int vecY;               // 8 B output stores usable (Cout even, y / out_scale 8 B aligned)
 };
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -91,6 +92,14 @@ __device__ __forceinline__ LoadAddr make_addr(int off, int left) {
     else { a.off = (unsigned)off * 4u; a.left = left; }
     return a;
 }
+// Same, from a running BYTE offset of element 0 (the weight-gradient loaders walk pixels incrementally).
+template <bool VEC>
+__device__ __forceinline__ LoadAddr make_addr_b(unsigned byte_off, int left) {
+    LoadAddr a;
+    if constexpr (VEC) { a.off = (left > 0) ? byte_off : OOB; a.left = 0; }
+    else { a.off = byte_off; a.left = left; }
+    return a;
+}
 template <bool VEC>
 __device__ __forceinline__ float4 load4(__amdgpu_buffer_rsrc_t r, LoadAddr a) {
     if constexpr (VEC) {
@@ -109,39 +118,51 @@ __device__ __forceinline__ float4 load4(__amdgpu_buffer_rsrc_t r, LoadAddr a) {
 // One chunk of MFMAs for this wave.  A image: [m][k] (A_KMAJOR = false, pitch LDK)
 // or [k][m] (A_KMAJOR = true, pitch LDA).  B image: [k][n] (B_KMAJOR = true, pitch
 // LDB) or [n][k] (B_KMAJOR = false, pitch LDK).
+// Row -> accumulator-tile assignment inside the wave's span (any bijection is legal, the epilogue
+// undoes it through tile_row()):
+//   [m][k] image: tile t holds rows  t*32 + l31          (a lane's 16 k values: 4 x ds_read_b128)
+//   [k][m] image: tile t holds rows  T*l31 + t           (a lane's T tiles are T CONSECUTIVE floats
+//                 of one k row: one ds_read_b64 for T = 2 instead of two half-rate ds_read_b32)
+template <int T, bool KMAJOR>
+__device__ __forceinline__ int tile_row(int t, int l) { return KMAJOR ? T * l + t : t * 32 + l; }
+
+template <int T, bool KMAJOR, int LD>
+__device__ __forceinline__ void load_frag(const float* __restrict__ S, int r0, int l31, int h, float (&f)[T][16]) {
+    if constexpr (!KMAJOR) {
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            const float4* p = reinterpret_cast<const float4*>(S + (r0 + t * 32 + l31) * LDK + 16 * h);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float4 v = p[q];
+                f[t][4 * q + 0] = v.x; f[t][4 * q + 1] = v.y; f[t][4 * q + 2] = v.z; f[t][4 * q + 3] = v.w;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const float* p = S + (16 * h + j) * LD + r0 + T * l31;
+            if constexpr (T == 2) {
+                const float2 v = *reinterpret_cast<const float2*>(p);
+                f[0][j] = v.x; f[1][j] = v.y;
+            } else if constexpr (T == 4) {
+                const float4 v = *reinterpret_cast<const float4*>(p);
+                f[0][j] = v.x; f[1][j] = v.y; f[2][j] = v.z; f[3][j] = v.w;
+            } else {
+#pragma unroll
+                for (int t = 0; t < T; t++) f[t][j] = p[t];
+            }
+        }
+    }
+}
+
 template <int TM, int TN, bool A_KMAJOR, bool B_KMAJOR, int LDA, int LDB>
 __device__ __forceinline__ void mma_chunk(const float* __restrict__ As, const float* __restrict__ Bs,
                                           f32x16 (&acc)[TM][TN], int am0, int bn0, int l31, int h) {
     float af[TM][16];
     float bf[TN][16];
-#pragma unroll
-    for (int tm = 0; tm < TM; tm++) {
-        if constexpr (!A_KMAJOR) {
-            const float4* pa = reinterpret_cast<const float4*>(As + (am0 + tm * 32 + l31) * LDK + 16 * h);
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const float4 v = pa[q];
-                af[tm][4 * q + 0] = v.x; af[tm][4 * q + 1] = v.y; af[tm][4 * q + 2] = v.z; af[tm][4 * q + 3] = v.w;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 16; j++) af[tm][j] = As[(16 * h + j) * LDA + am0 + tm * 32 + l31];
-        }
-    }
-#pragma unroll
-    for (int tn = 0; tn < TN; tn++) {
-        if constexpr (!B_KMAJOR) {
-            const float4* pb = reinterpret_cast<const float4*>(Bs + (bn0 + tn * 32 + l31) * LDK + 16 * h);
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const float4 v = pb[q];
-                bf[tn][4 * q + 0] = v.x; bf[tn][4 * q + 1] = v.y; bf[tn][4 * q + 2] = v.z; bf[tn][4 * q + 3] = v.w;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 16; j++) bf[tn][j] = Bs[(16 * h + j) * LDB + bn0 + tn * 32 + l31];
-        }
-    }
+    load_frag<TM, A_KMAJOR, LDA>(As, am0, l31, h, af);
+    load_frag<TN, B_KMAJOR, LDB>(Bs, bn0, l31, h, bf);
 #pragma unroll
     for (int j = 0; j < 16; j++)
 #pragma unroll
@@ -154,7 +175,9 @@ __device__ __forceinline__ void mma_chunk(const float* __restrict__ As, const fl
 // ------------------------------------------------------------------------------
 // Forward-type kernel (conv, transposed conv, dense, and all data gradients).
 // grid = (m tiles of the largest class, n tiles, classes * splits)
-template <int BM, int BN, int WM, int WN, bool WT, bool VEC>
+// SC: an in_scale operand exists (host dispatch on the pointer) -- without it the scale loads,
+// their addresses and the multiplies are not in the loop at all.
+template <int BM, int BN, int WM, int WN, bool WT, bool VEC, bool SC>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
@@ -239,11 +262,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     int ld_cc = (c_begin < c_end) ? c_begin - ld_t0 * a.cpt : 0;
     int ld_ta = (c_begin < c_end) ? ld_t0 / nkx : 0;
     int ld_tb = (c_begin < c_end) ? ld_t0 - ld_ta * nkx : 0;
-    const bool has_in_scale = a.in_scale != nullptr;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, (unsigned)a.N * a.H * a.W * a.Cin * 4u);
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.w, (unsigned)a.KH * a.KW * a.Cin * a.Cout * 4u);
-    // absent scale: zero records -> every load is out of range (no memory access), value unused
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(has_in_scale ? a.in_scale : a.x, has_in_scale ? (unsigned)a.N * a.Cin * 4u : 0u);
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(SC ? a.in_scale : a.x, SC ? (unsigned)a.N * a.Cin * 4u : 0u);
 
     // Addresses of the NEXT prefetch are computed one stage ahead, inside the MFMA phase (pure VALU
     // that the scheduler tucks into MFMA shadows); the prefetch itself is then 3*AR.. buffer loads
@@ -260,7 +281,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
             const bool ok = live & rok[i] & (vy >= 0) & (vx >= 0) & (iy < a.H) & (ix < a.W);
             const int left = ok ? (a.Cin - ci) : 0;
             aa[i] = make_addr<VEC>(((rn[i] * a.H + iy) * a.W + ix) * a.Cin + ci, left);
-            as_[i] = make_addr<VEC>(rn[i] * a.Cin + ci, left);
+            if constexpr (SC) as_[i] = make_addr<VEC>(rn[i] * a.Cin + ci, left);
         }
         if constexpr (!WT) {
 #pragma unroll
@@ -290,7 +311,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < AR; i++) {
             ra[i] = load4<VEC>(rx, aa[i]);
-            rsa[i] = load4<VEC>(rs, as_[i]);   // multiplied in at store time (after the MFMAs)
+            if constexpr (SC) rsa[i] = load4<VEC>(rs, as_[i]);   // multiplied in at store time (after the MFMAs)
         }
 #pragma unroll
         for (int i = 0; i < BR; i++) rb[i] = load4<VEC>(rw, ab[i]);
@@ -300,7 +321,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
         float* B = Bs + buf * B_ELEMS;
 #pragma unroll
         for (int i = 0; i < AR; i++)
-            *reinterpret_cast<float4*>(A + (arow0 + 32 * i) * LDK + 4 * kvec) = f4mul(ra[i], f4sel(has_in_scale, rsa[i]));
+            *reinterpret_cast<float4*>(A + (arow0 + 32 * i) * LDK + 4 * kvec) = SC ? f4mul(ra[i], rsa[i]) : ra[i];
         if constexpr (!WT) {
 #pragma unroll
             for (int i = 0; i < BR; i++) *reinterpret_cast<float4*>(B + (krow0 + KROWS * i) * LDB + 4 * nvec) = rb[i];
@@ -341,9 +362,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*h ----
+    // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*h; tile -> column via tile_row ----
     float* out = a.y + (a.splits > 1 ? (size_t)split * a.Mtot * a.Cout : (size_t)0);
     const bool scale = (a.out_scale != nullptr) && (a.splits == 1);
+    const int cbase = n0 + wn * (BN / WN);
 #pragma unroll
     for (int tm = 0; tm < TM; tm++) {
 #pragma unroll
@@ -352,9 +374,23 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
             const int pix = row_pix[row];
             if (pix < 0) continue;
             const int nn = row_n[row];
+            if constexpr (!WT && TN == 2) {
+                if (a.vecY) {   // the lane's two tiles are adjacent channels: one 8 B store
+                    const int co = cbase + 2 * l31;
+                    if (co < a.Cout) {
+                        float2 v = make_float2(acc[tm][0][r], acc[tm][1][r]);
+                        if (scale) {
+                            const float2 sc = *reinterpret_cast<const float2*>(a.out_scale + nn * a.Cout + co);
+                            v.x *= sc.x; v.y *= sc.y;
+                        }
+                        *reinterpret_cast<float2*>(out + (size_t)pix * a.Cout + co) = v;
+                    }
+                    continue;
+                }
+            }
 #pragma unroll
             for (int tn = 0; tn < TN; tn++) {
-                const int co = n0 + wn * (BN / WN) + tn * 32 + l31;
+                const int co = cbase + tile_row<TN, !WT>(tn, l31);
                 if (co < a.Cout) {
                     float v = acc[tm][tn][r];
                     if (scale) v *= a.out_scale[nn * a.Cout + co];
@@ -397,9 +433,19 @@ struct WgradArgs {
     int pad_y, pad_x;
     int splits;
     int vecA, vecB, vecSA, vecSB;
+    int vecY;   // 8 B stores usable (Cout even, destination 8 B aligned)
 };
 
-template <int BM, int BN, int WM, int WN, bool VEC>
+// SCM (scale mode, host dispatch on the two pointers): 0 = neither in_scale nor out_scale (plain
+// convolutions: no scale loads / addresses / multiplies in the loop), 1 = both (modulated conv),
+// 2 = exactly one (the absent one is selected to 1.0).
+//
+// The reduction axis is the flattened pixel index kp <-> (n, qy, qx) of the tap's parity class.  Each
+// loader row starts from one exact decode and then WALKS: a chunk advances every row by BK = 32
+// pixels = (st_a1 samples, st_a2 rows, st_b columns), two conditional carries keep (qx, qy) in range,
+// and the running byte offsets into x / dy / the scale rows move by precomputed (uniform) deltas --
+// no integer division or multiply per chunk.
+template <int BM, int BN, int WM, int WN, bool VEC, int SCM>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
@@ -410,6 +456,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     constexpr int MV = BM / 4, NV = BN / 4;
     constexpr int AROWS = 256 / MV, BROWS = 256 / NV;  // pixel rows per pass
     constexpr int AR = BK / AROWS, BR = BK / BROWS;    // float4 per thread
+    constexpr bool SAME = (AROWS == BROWS);            // A and B loaders walk the same pixel rows
+    constexpr int WR = SAME ? 1 : BR;                  // B-side walkers when they differ
     static_assert(AR >= 1 && BR >= 1, "tile too wide");
 
     __shared__ __attribute__((aligned(16))) float As[2 * A_ELEMS];
@@ -437,70 +485,133 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 
     const int amv = tid % MV, aprow0 = tid / MV;
     const int bnv = tid % NV, bprow0 = tid / NV;
+    const int ci = m0 + 4 * amv, co = n0 + 4 * bnv;
+
+    // input sample of (qy, qx) under this tap: iy = qy*s_in + cy (for up == 2 the class parity makes
+    // py + ky - pad even, so the >> 1 of the zero-stuffed coordinate is exact)
+    const int s_in = (up == 1) ? a.stride : 1;
+    const int cy = (up == 1) ? ky - a.pad_y : (py + ky - a.pad_y) >> 1;
+    const int cx = (up == 1) ? kx - a.pad_x : (px + kx - a.pad_x) >> 1;
+    // one chunk = BK pixels = st_a1 samples + st_a2 rows + st_b columns
+    const int dQW = max(QW, 1), dQH = max(QH, 1);
+    const int st_b = BK % dQW, st_a = BK / dQW, st_a2 = st_a % dQH, st_a1 = st_a / dQH;
+    const unsigned rowA = (unsigned)a.Cin * 4u, rowB = (unsigned)a.Cout * 4u;   // bytes per pixel
+    const unsigned dA_step = (unsigned)((st_a1 * a.H + st_a2 * s_in) * a.W + st_b * s_in) * rowA;
+    const unsigned dA_cx = (unsigned)(s_in * (a.W - QW)) * rowA;           // qx -= QW, qy += 1
+    const unsigned dA_cy = (unsigned)((a.H - QH * s_in) * a.W) * rowA;     // qy -= QH, n += 1
+    const unsigned dB_step = (unsigned)((st_a1 * a.OH + st_a2 * up) * a.OW + st_b * up) * rowB;
+    const unsigned dB_cx = (unsigned)(up * (a.OW - QW)) * rowB;
+    const unsigned dB_cy = (unsigned)((a.OH - QH * up) * a.OW) * rowB;
+    const unsigned dSA_step = (unsigned)st_a1 * rowA, dSB_step = (unsigned)st_a1 * rowB;
+
+    struct Walk { int kp, qx, qy; };
+    Walk wa[AR], wb[WR];
+    unsigned offA[AR], offSA[AR], offB[BR], offSB[BR];
+    auto start = [&](int kp, Walk& w, int& nn) {
+        nn = kp / (dQH * dQW);
+        const int r = kp - nn * (dQH * dQW);
+        w.kp = kp; w.qy = r / dQW; w.qx = r - w.qy * dQW;
+    };
+    auto advance = [&](Walk& w, bool& c1, bool& c2) {
+        w.kp += BK;
+        w.qx += st_b;
+        c1 = w.qx >= QW;
+        w.qx -= c1 ? QW : 0;
+        w.qy += st_a2 + (c1 ? 1 : 0);
+        c2 = w.qy >= QH;
+        w.qy -= c2 ? QH : 0;
+    };
+#pragma unroll
+    for (int i = 0; i < AR; i++) {
+        int nn;
+        start(c_begin * BK + aprow0 + AROWS * i, wa[i], nn);
+        offA[i] = (unsigned)((nn * a.H + wa[i].qy * s_in + cy) * a.W + wa[i].qx * s_in + cx) * rowA + (unsigned)ci * 4u;
+        offSA[i] = (unsigned)nn * rowA + (unsigned)ci * 4u;
+    }
+#pragma unroll
+    for (int i = 0; i < BR; i++) {
+        int nn;
+        Walk w;
+        start(c_begin * BK + bprow0 + BROWS * i, w, nn);
+        if constexpr (!SAME) wb[i] = w;
+        offB[i] = (unsigned)((nn * a.OH + w.qy * up + py) * a.OW + w.qx * up + px) * rowB + (unsigned)co * 4u;
+        offSB[i] = (unsigned)nn * rowB + (unsigned)co * 4u;
+    }
 
     float4 ra[AR], rsa[AR], rb[BR], rsb[BR];
-
-    auto decode = [&](int kp, int& nn, int& oy, int& ox) {
-        nn = kp / (QH * QW);
-        const int r = kp - nn * (QH * QW);
-        const int qy = r / QW, qx = r - qy * QW;
-        oy = qy * up + py;
-        ox = qx * up + px;
-    };
+    constexpr bool SC = (SCM != 0);
     const bool has_in_scale = a.in_scale != nullptr, has_out_scale = a.out_scale != nullptr;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, (unsigned)a.N * a.H * a.W * a.Cin * 4u);
     const __amdgpu_buffer_rsrc_t rdy = make_rsrc(a.dy, (unsigned)a.N * a.OH * a.OW * a.Cout * 4u);
+    // an absent scale gets zero records: every load is out of range (no memory access), value unused
     const __amdgpu_buffer_rsrc_t rsi = make_rsrc(has_in_scale ? a.in_scale : a.x, has_in_scale ? (unsigned)a.N * a.Cin * 4u : 0u);
     const __amdgpu_buffer_rsrc_t rso = make_rsrc(has_out_scale ? a.out_scale : a.dy, has_out_scale ? (unsigned)a.N * a.Cout * 4u : 0u);
     LoadAddr aa[AR], as_[AR], ab[BR], abs_[BR];
-    auto prep_chunk = [&](int c, bool live) {
+    // addresses of the walkers' current chunk, then one step forward
+    auto prep_chunk = [&](bool live) {
+        bool c1a[AR], c2a[AR];
 #pragma unroll
         for (int i = 0; i < AR; i++) {
-            const int kp = c * BK + aprow0 + AROWS * i;
-            int nn = 0, oy = 0, ox = 0;
-            const bool in = live & (kp < Kpix);
-            decode(in ? kp : 0, nn, oy, ox);
-            const int vy = oy * a.stride + ky - a.pad_y, vx = ox * a.stride + kx - a.pad_x;
-            const int iy = vy >> a.up_shift, ix = vx >> a.up_shift;
-            const bool ok = in & (vy >= 0) & (vx >= 0) & (iy < a.H) & (ix < a.W);
-            const int ci = m0 + 4 * amv;
+            const int iy = __mul24(wa[i].qy, s_in) + cy, ix = __mul24(wa[i].qx, s_in) + cx;
+            const bool ok = live & (wa[i].kp < Kpix) & ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);
             const int left = ok ? (a.Cin - ci) : 0;
-            aa[i] = make_addr<VEC>(((nn * a.H + iy) * a.W + ix) * a.Cin + ci, left);
-            as_[i] = make_addr<VEC>(nn * a.Cin + ci, left);
+            aa[i] = make_addr_b<VEC>(offA[i], left);
+            if constexpr (SC) as_[i] = make_addr_b<VEC>(offSA[i], left);
+            if constexpr (SAME) {
+                const int leftb = (live & (wa[i].kp < Kpix)) ? (a.Cout - co) : 0;
+                ab[i] = make_addr_b<VEC>(offB[i], leftb);
+                if constexpr (SC) abs_[i] = make_addr_b<VEC>(offSB[i], leftb);
+            }
+            advance(wa[i], c1a[i], c2a[i]);
+            offA[i] += dA_step + (c1a[i] ? dA_cx : 0u) + (c2a[i] ? dA_cy : 0u);
+            if constexpr (SC) offSA[i] += dSA_step + (c2a[i] ? rowA : 0u);
+            if constexpr (SAME) {
+                offB[i] += dB_step + (c1a[i] ? dB_cx : 0u) + (c2a[i] ? dB_cy : 0u);
+                if constexpr (SC) offSB[i] += dSB_step + (c2a[i] ? rowB : 0u);
+            }
         }
+        if constexpr (!SAME) {
 #pragma unroll
-        for (int i = 0; i < BR; i++) {
-            const int kp = c * BK + bprow0 + BROWS * i;
-            int nn = 0, oy = 0, ox = 0;
-            const bool in = live & (kp < Kpix);
-            decode(in ? kp : 0, nn, oy, ox);
-            const int co = n0 + 4 * bnv;
-            const int left = in ? (a.Cout - co) : 0;
-            ab[i] = make_addr<VEC>(((nn * a.OH + oy) * a.OW + ox) * a.Cout + co, left);
-            abs_[i] = make_addr<VEC>(nn * a.Cout + co, left);
+            for (int i = 0; i < BR; i++) {
+                const int leftb = (live & (wb[i].kp < Kpix)) ? (a.Cout - co) : 0;
+                ab[i] = make_addr_b<VEC>(offB[i], leftb);
+                if constexpr (SC) abs_[i] = make_addr_b<VEC>(offSB[i], leftb);
+                bool c1, c2;
+                advance(wb[i], c1, c2);
+                offB[i] += dB_step + (c1 ? dB_cx : 0u) + (c2 ? dB_cy : 0u);
+                if constexpr (SC) offSB[i] += dSB_step + (c2 ? rowB : 0u);
+            }
         }
     };
     auto issue_loads = [&]() {
 #pragma unroll
         for (int i = 0; i < AR; i++) {
             ra[i] = load4<VEC>(rx, aa[i]);
-            rsa[i] = load4<VEC>(rsi, as_[i]);
+            if constexpr (SC) rsa[i] = load4<VEC>(rsi, as_[i]);
         }
 #pragma unroll
         for (int i = 0; i < BR; i++) {
             rb[i] = load4<VEC>(rdy, ab[i]);
-            rsb[i] = load4<VEC>(rso, abs_[i]);
+            if constexpr (SC) rsb[i] = load4<VEC>(rso, abs_[i]);
         }
     };
     auto store_chunk = [&](int buf) {
         float* A = As + buf * A_ELEMS;
         float* B = Bs + buf * B_ELEMS;
 #pragma unroll
-        for (int i = 0; i < AR; i++)
-            *reinterpret_cast<float4*>(A + (aprow0 + AROWS * i) * LDA + 4 * amv) = f4mul(ra[i], f4sel(has_in_scale, rsa[i]));
+        for (int i = 0; i < AR; i++) {
+            float4 v = ra[i];
+            if constexpr (SCM == 1) v = f4mul(v, rsa[i]);
+            if constexpr (SCM == 2) v = f4mul(v, f4sel(has_in_scale, rsa[i]));
+            *reinterpret_cast<float4*>(A + (aprow0 + AROWS * i) * LDA + 4 * amv) = v;
+        }
 #pragma unroll
-        for (int i = 0; i < BR; i++)
-            *reinterpret_cast<float4*>(B + (bprow0 + BROWS * i) * LDB + 4 * bnv) = f4mul(rb[i], f4sel(has_out_scale, rsb[i]));
+        for (int i = 0; i < BR; i++) {
+            float4 v = rb[i];
+            if constexpr (SCM == 1) v = f4mul(v, rsb[i]);
+            if constexpr (SCM == 2) v = f4mul(v, f4sel(has_out_scale, rsb[i]));
+            *reinterpret_cast<float4*>(B + (bprow0 + BROWS * i) * LDB + 4 * bnv) = v;
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -512,10 +623,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
             for (int r = 0; r < 16; r++) acc[tm][tn][r] = 0.0f;
 
     if (c_begin < c_end) {
-        prep_chunk(c_begin, true);
+        prep_chunk(true);
         issue_loads();
         store_chunk(0);
-        prep_chunk(c_begin + 1, c_begin + 1 < c_end);
+        prep_chunk(c_begin + 1 < c_end);
     }
     __syncthreads();
     for (int c = c_begin; c < c_end; c++) {
@@ -524,24 +635,33 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         mma_chunk<TM, TN, true, true, LDA, LDB>(As + cur * A_ELEMS, Bs + cur * B_ELEMS, acc,
                                                  wm * (BM / WM), wn * (BN / WN), l31, h);
-        prep_chunk(c + 2, c + 2 < c_end);     // pixel decode + addresses of chunk c+2 in the MFMA shadows
+        prep_chunk(c + 2 < c_end);            // walk to chunk c+2 in the MFMA shadows
         __builtin_amdgcn_sched_barrier(0);
         store_chunk(cur ^ 1);
         __syncthreads();
     }
 
+    // epilogue: tile -> (ci, co) through tile_row (K-major images interleave the tiles)
     const size_t wsize = (size_t)a.KH * a.KW * a.Cin * a.Cout;
     float* out = a.out + (a.splits > 1 ? (size_t)split * wsize : (size_t)0) + (size_t)tap * a.Cin * a.Cout;
+    const int cbase = n0 + wn * (BN / WN);
 #pragma unroll
     for (int tm = 0; tm < TM; tm++) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const int ci = m0 + wm * (BM / WM) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (ci >= a.Cin) continue;
+            const int cir = m0 + wm * (BM / WM) + tile_row<TM, true>(tm, (r & 3) + 8 * (r >> 2) + 4 * h);
+            if (cir >= a.Cin) continue;
+            if constexpr (TN == 2) {
+                if (a.vecY) {
+                    const int c2 = cbase + 2 * l31;
+                    if (c2 < a.Cout) *reinterpret_cast<float2*>(out + (size_t)cir * a.Cout + c2) = make_float2(acc[tm][0][r], acc[tm][1][r]);
+                    continue;
+                }
+            }
 #pragma unroll
             for (int tn = 0; tn < TN; tn++) {
-                const int co = n0 + wn * (BN / WN) + tn * 32 + l31;
-                if (co < a.Cout) out[(size_t)ci * a.Cout + co] = acc[tm][tn][r];
+                const int cc = cbase + tile_row<TN, true>(tn, l31);
+                if (cc < a.Cout) out[(size_t)cir * a.Cout + cc] = acc[tm][tn][r];
             }
         }
     }
@@ -590,14 +710,20 @@ void fwd_counts(const igan_conv2d_params* p, int& Mmax, int& chunks_max, int& nc
     chunks_max = ((p->KH + up - 1) / up) * ((p->KW + up - 1) / up) * cpt;
 }
 
+template <int BM, int BN, int WM, int WN, bool WT, bool VEC>
+void launch_fwd2(hipStream_t stream, const ConvArgs& a, dim3 grid) {
+    if (a.in_scale) hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, WT, VEC, true>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, WT, VEC, false>), grid, dim3(256), 0, stream, a);
+}
+
 template <int BM, int BN, int WM, int WN>
 void launch_fwd(hipStream_t stream, const ConvArgs& a, dim3 grid, bool wt, bool vec) {
     if (wt) {
-        if (vec) hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, true, true>), grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, true, false>), grid, dim3(256), 0, stream, a);
+        if (vec) launch_fwd2<BM, BN, WM, WN, true, true>(stream, a, grid);
+        else launch_fwd2<BM, BN, WM, WN, true, false>(stream, a, grid);
     } else {
-        if (vec) hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, false, true>), grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, false, false>), grid, dim3(256), 0, stream, a);
+        if (vec) launch_fwd2<BM, BN, WM, WN, false, true>(stream, a, grid);
+        else launch_fwd2<BM, BN, WM, WN, false, false>(stream, a, grid);
     }
 }
 
@@ -649,7 +775,8 @@ extern "C" int igan_conv2d_kernel_name(const igan_conv2d_params* p, char* buf, i
     int wm = 2, wn = 2;
     if (t.BM == 128 && t.BN == 32) { wm = 4; wn = 1; }
     if (t.BM == 32) { wm = 1; wn = 4; }
-    snprintf(buf, (size_t)buflen, "conv_fwd_kernel<%d, %d, %d, %d, %s, %s>", t.BM, t.BN, wm, wn, wt ? "true" : "false", vec ? "true" : "false");
+    snprintf(buf, (size_t)buflen, "conv_fwd_kernel<%d, %d, %d, %d, %s, %s, %s>", t.BM, t.BN, wm, wn, wt ? "true" : "false",
+             vec ? "true" : "false", p->in_scale ? "true" : "false");
     return IGAN_OK;
 }
 
@@ -685,6 +812,7 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
     a.vecS = (p->Cin % 4 == 0) && (((uintptr_t)p->in_scale & 15) == 0);
     if (p->w_transposed) a.vecB = (p->Cin % 4 == 0) && (((uintptr_t)p->w & 15) == 0);
     else a.vecB = (p->Cout % 4 == 0) && (((uintptr_t)p->w & 15) == 0);
+    a.vecY = (p->Cout % 2 == 0) && ((((uintptr_t)a.y | (uintptr_t)p->out_scale) & 7) == 0);
 
     dim3 grid(ceil_div(Mmax, t.BM), ceil_div(p->Cout, t.BN), nclass * splits);
     const bool wt = p->w_transposed != 0;
@@ -719,6 +847,18 @@ int wgrad_geometry_check(const igan_conv2d_wgrad_params* p) {
     IGAN_REQUIRE((long long)p->N * p->OH * p->OW * p->Cout * 4 <= 0x7FFFFFF0LL, "conv2d_wgrad: output gradient too large (2 GiB per operand)");
     IGAN_REQUIRE((long long)p->KH * p->KW * p->Cin * p->Cout <= INT32_MAX, "conv2d_wgrad: filter too large");
     return IGAN_OK;
+}
+
+template <int BM, int BN, int WM, int WN, bool VEC>
+void launch_wgrad2(hipStream_t stream, const WgradArgs& a, dim3 grid, int scm) {
+    if (scm == 0) hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, VEC, 0>), grid, dim3(256), 0, stream, a);
+    else if (scm == 1) hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, VEC, 1>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, VEC, 2>), grid, dim3(256), 0, stream, a);
+}
+template <int BM, int BN, int WM, int WN>
+void launch_wgrad(hipStream_t stream, const WgradArgs& a, dim3 grid, bool vec, int scm) {
+    if (vec) launch_wgrad2<BM, BN, WM, WN, true>(stream, a, grid, scm);
+    else launch_wgrad2<BM, BN, WM, WN, false>(stream, a, grid, scm);
 }
 
 struct WgTile { int BM, BN; };
@@ -789,19 +929,15 @@ extern "C" int igan_conv2d_wgrad(igan_stream_t stream_, const igan_conv2d_wgrad_
     a.vecSA = (p->Cin % 4 == 0) && (((uintptr_t)p->in_scale & 15) == 0);
     a.vecSB = (p->Cout % 4 == 0) && (((uintptr_t)p->out_scale & 15) == 0);
 
+    a.vecY = (p->Cout % 2 == 0) && (((uintptr_t)a.out & 7) == 0);
+
     const WgTile t = pick_wg_tile(p->Cin, p->Cout);
     dim3 grid(ceil_div(p->Cin, t.BM), ceil_div(p->Cout, t.BN), p->KH * p->KW * splits);
     const bool vec = a.vecA && a.vecB && (a.in_scale == nullptr || a.vecSA) && (a.out_scale == nullptr || a.vecSB);
-    if (t.BM == 128 && t.BN == 128) {
-        if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, true>), grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, false>), grid, dim3(256), 0, stream, a);
-    } else if (t.BM == 128 && t.BN == 32) {
-        if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<128, 32, 4, 1, true>), grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((conv_wgrad_kernel<128, 32, 4, 1, false>), grid, dim3(256), 0, stream, a);
-    } else {
-        if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 4, true>), grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 4, false>), grid, dim3(256), 0, stream, a);
-    }
+    const int scm = (a.in_scale && a.out_scale) ? 1 : ((a.in_scale || a.out_scale) ? 2 : 0);
+    if (t.BM == 128 && t.BN == 128) launch_wgrad<128, 128, 2, 2>(stream, a, grid, vec, scm);
+    else if (t.BM == 128 && t.BN == 32) launch_wgrad<128, 32, 4, 1>(stream, a, grid, vec, scm);
+    else launch_wgrad<32, 128, 1, 4>(stream, a, grid, vec, scm);
     IGAN_LAUNCH_CHECK("conv2d_wgrad launch");
     if (splits > 1) {
         const int total = (int)wsize;
