@@ -160,6 +160,8 @@ typedef struct igan_conv2d_params {
     int pad_y, pad_x;
     int w_transposed;
     int splits;
+    float alpha;            /* y is multiplied by alpha (the layers' runtime weight scale, networks_stylegan2.py:30-36,
+                             * rides here instead of in a separate w * coef pass); 1.0f for a plain convolution */
 } igan_conv2d_params;
 
 int igan_conv2d_plan(const igan_conv2d_params* p, int* splits, size_t* workspace_floats);
@@ -188,6 +190,7 @@ typedef struct igan_conv2d_wgrad_params {
     int stride, up;
     int pad_y, pad_x;
     int splits;
+    float alpha;            /* dw is multiplied by alpha (see igan_conv2d_params) */
 } igan_conv2d_wgrad_params;
 
 int igan_conv2d_wgrad_plan(const igan_conv2d_wgrad_params* p, int* splits, size_t* workspace_floats);

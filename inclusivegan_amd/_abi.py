@@ -55,8 +55,12 @@ class Conv2DParams(ctypes.Structure):
         ('KH', ctypes.c_int), ('KW', ctypes.c_int),
         ('stride', ctypes.c_int), ('up', ctypes.c_int),
         ('pad_y', ctypes.c_int), ('pad_x', ctypes.c_int),
-        ('w_transposed', ctypes.c_int), ('splits', ctypes.c_int),
+        ('w_transposed', ctypes.c_int), ('splits', ctypes.c_int), ('alpha', ctypes.c_float),
     ]
+
+    def __init__(self, *args, **kwargs):
+        kwargs.setdefault('alpha', 1.0)     # a plain convolution
+        super().__init__(*args, **kwargs)
 
 
 class Conv2DWgradParams(ctypes.Structure):
@@ -69,8 +73,12 @@ class Conv2DWgradParams(ctypes.Structure):
         ('KH', ctypes.c_int), ('KW', ctypes.c_int),
         ('stride', ctypes.c_int), ('up', ctypes.c_int),
         ('pad_y', ctypes.c_int), ('pad_x', ctypes.c_int),
-        ('splits', ctypes.c_int),
+        ('splits', ctypes.c_int), ('alpha', ctypes.c_float),
     ]
+
+    def __init__(self, *args, **kwargs):
+        kwargs.setdefault('alpha', 1.0)     # a plain convolution
+        super().__init__(*args, **kwargs)
 
 
 _I, _F, _P, _SZ = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t

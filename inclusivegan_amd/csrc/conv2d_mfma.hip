@@ -60,6 +60,7 @@ struct ConvArgs {
     int Mtot;               // N*OH*OW
     int vecA, vecB, vecS;   // 16 B paths usable for x rows / w rows / in_scale rows
     int vecY;               // 8 B output stores usable (Cout even, y / out_scale 8 B aligned)
+    float alpha;            // output multiplier (applied here when splits == 1, else by the reduce kernel)
 };
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -156,15 +157,11 @@ __device__ __forceinline__ void load_frag(const float* __restrict__ S, int r0, i
     }
 }
 
-template <int TM, int TN, bool A_KMAJOR, bool B_KMAJOR, int LDA, int LDB>
-__device__ __forceinline__ void mma_chunk(const float* __restrict__ As, const float* __restrict__ Bs,
-                                          f32x16 (&acc)[TM][TN], int am0, int bn0, int l31, int h) {
-    float af[TM][16];
-    float bf[TN][16];
-    load_frag<TM, A_KMAJOR, LDA>(As, am0, l31, h, af);
-    load_frag<TN, B_KMAJOR, LDB>(Bs, bn0, l31, h, bf);
+// MFMAs of k steps [J0, J1) of the chunk whose fragments are in af / bf.
+template <int TM, int TN, int J0, int J1>
+__device__ __forceinline__ void mma_steps(const float (&af)[TM][16], const float (&bf)[TN][16], f32x16 (&acc)[TM][TN]) {
 #pragma unroll
-    for (int j = 0; j < 16; j++)
+    for (int j = J0; j < J1; j++)
 #pragma unroll
         for (int tm = 0; tm < TM; tm++)
 #pragma unroll
@@ -178,7 +175,7 @@ __device__ __forceinline__ void mma_chunk(const float* __restrict__ As, const fl
 // SC: an in_scale operand exists (host dispatch on the pointer) -- without it the scale loads,
 // their addresses and the multiplies are not in the loop at all.
 template <int BM, int BN, int WM, int WN, bool WT, bool VEC, bool SC>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
     constexpr int LDB = WT ? LDK : BN + 4;
@@ -352,19 +349,26 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
         // last iteration, instead of branched around: the loop body stays ONE basic block).
         issue_loads();
         __builtin_amdgcn_sched_barrier(0);   // the prefetch stays AHEAD of the MFMAs ...
-        mma_chunk<TM, TN, false, !WT, LDK, LDB>(As + cur * A_ELEMS, Bs + cur * B_ELEMS, acc,
-                                                 wm * (BM / WM), wn * (BN / WN), l31, h);
+        float af[TM][16], bf[TN][16];
+        load_frag<TM, false, LDK>(As + cur * A_ELEMS, wm * (BM / WM), l31, h, af);
+        load_frag<TN, !WT, LDB>(Bs + cur * B_ELEMS, wn * (BN / WN), l31, h, bf);
+        mma_steps<TM, TN, 0, 8>(af, bf, acc);
         prep_chunk(c + 2 < c_end);           // addresses of chunk c+2: VALU only, free to interleave with the MFMAs
-        // ... and its consumers (with their s_waitcnt vmcnt) stay BEHIND them: without this fence hipcc
-        // hoists the first scale-multiply + ds_write up to the first MFMA and stalls there.
+        // ... and its consumers (with their s_waitcnt vmcnt) stay BEHIND the first half of the MFMAs:
+        // without this fence hipcc hoists the first scale-multiply + ds_write up to the first MFMA and
+        // stalls there.  Nobody reads buffer cur^1 during this iteration (every wave passed the
+        // barrier below after its last read of it), so its stores need no phase of their own: they
+        // interleave with the second half of the MFMAs, whose issue slots they fill.
         __builtin_amdgcn_sched_barrier(0);
         store_chunk(cur ^ 1);
+        mma_steps<TM, TN, 8, 16>(af, bf, acc);
         __syncthreads();
     }
 
     // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*h; tile -> column via tile_row ----
     float* out = a.y + (a.splits > 1 ? (size_t)split * a.Mtot * a.Cout : (size_t)0);
     const bool scale = (a.out_scale != nullptr) && (a.splits == 1);
+    const float alpha = (a.splits == 1) ? a.alpha : 1.0f;
     const int cbase = n0 + wn * (BN / WN);
 #pragma unroll
     for (int tm = 0; tm < TM; tm++) {
@@ -378,7 +382,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
                 if (a.vecY) {   // the lane's two tiles are adjacent channels: one 8 B store
                     const int co = cbase + 2 * l31;
                     if (co < a.Cout) {
-                        float2 v = make_float2(acc[tm][0][r], acc[tm][1][r]);
+                        float2 v = make_float2(acc[tm][0][r] * alpha, acc[tm][1][r] * alpha);
                         if (scale) {
                             const float2 sc = *reinterpret_cast<const float2*>(a.out_scale + nn * a.Cout + co);
                             v.x *= sc.x; v.y *= sc.y;
@@ -392,7 +396,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
             for (int tn = 0; tn < TN; tn++) {
                 const int co = cbase + tile_row<TN, !WT>(tn, l31);
                 if (co < a.Cout) {
-                    float v = acc[tm][tn][r];
+                    float v = acc[tm][tn][r] * alpha;
                     if (scale) v *= a.out_scale[nn * a.Cout + co];
                     out[(size_t)pix * a.Cout + co] = v;
                 }
@@ -401,12 +405,13 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     }
 }
 
-// y[i] = out_scale * sum_s ws[s][i]   (fixed order)
+// y[i] = alpha * out_scale * sum_s ws[s][i]   (fixed order)
 __global__ __launch_bounds__(256) void conv_reduce_kernel(const float* ws, float* y, const float* out_scale,
-                                                          int total, int splits, int Cout, int pix_per_n) {
+                                                          int total, int splits, int Cout, int pix_per_n, float alpha) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         float s = 0.f;
         for (int k = 0; k < splits; k++) s += ws[(size_t)k * total + i];
+        s *= alpha;
         if (out_scale) {
             const int pix = i / Cout;
             const int co = i - pix * Cout;
@@ -434,6 +439,7 @@ struct WgradArgs {
     int splits;
     int vecA, vecB, vecSA, vecSB;
     int vecY;   // 8 B stores usable (Cout even, destination 8 B aligned)
+    float alpha;  // dw multiplier (applied here when splits == 1, else by the reduce kernel)
 };
 
 // SCM (scale mode, host dispatch on the two pointers): 0 = neither in_scale nor out_scale (plain
@@ -446,7 +452,7 @@ struct WgradArgs {
 // and the running byte offsets into x / dy / the scale rows move by precomputed (uniform) deltas --
 // no integer division or multiply per chunk.
 template <int BM, int BN, int WM, int WN, bool VEC, int SCM>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
     constexpr int LDA = BM + 4;
@@ -633,11 +639,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         const int cur = (c - c_begin) & 1;
         issue_loads();                        // chunk c+1 (predicated off on the last iteration)
         __builtin_amdgcn_sched_barrier(0);
-        mma_chunk<TM, TN, true, true, LDA, LDB>(As + cur * A_ELEMS, Bs + cur * B_ELEMS, acc,
-                                                 wm * (BM / WM), wn * (BN / WN), l31, h);
+        float af[TM][16], bf[TN][16];
+        load_frag<TM, true, LDA>(As + cur * A_ELEMS, wm * (BM / WM), l31, h, af);
+        load_frag<TN, true, LDB>(Bs + cur * B_ELEMS, wn * (BN / WN), l31, h, bf);
+        mma_steps<TM, TN, 0, 8>(af, bf, acc);
         prep_chunk(c + 2 < c_end);            // walk to chunk c+2 in the MFMA shadows
         __builtin_amdgcn_sched_barrier(0);
-        store_chunk(cur ^ 1);
+        store_chunk(cur ^ 1);                 // interleaves with the second half (see conv_fwd_kernel)
+        mma_steps<TM, TN, 8, 16>(af, bf, acc);
         __syncthreads();
     }
 
@@ -645,6 +654,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const size_t wsize = (size_t)a.KH * a.KW * a.Cin * a.Cout;
     float* out = a.out + (a.splits > 1 ? (size_t)split * wsize : (size_t)0) + (size_t)tap * a.Cin * a.Cout;
     const int cbase = n0 + wn * (BN / WN);
+    const float alpha = (a.splits == 1) ? a.alpha : 1.0f;
 #pragma unroll
     for (int tm = 0; tm < TM; tm++) {
 #pragma unroll
@@ -654,24 +664,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
             if constexpr (TN == 2) {
                 if (a.vecY) {
                     const int c2 = cbase + 2 * l31;
-                    if (c2 < a.Cout) *reinterpret_cast<float2*>(out + (size_t)cir * a.Cout + c2) = make_float2(acc[tm][0][r], acc[tm][1][r]);
+                    if (c2 < a.Cout) *reinterpret_cast<float2*>(out + (size_t)cir * a.Cout + c2) = make_float2(acc[tm][0][r] * alpha, acc[tm][1][r] * alpha);
                     continue;
                 }
             }
 #pragma unroll
             for (int tn = 0; tn < TN; tn++) {
                 const int cc = cbase + tile_row<TN, true>(tn, l31);
-                if (cc < a.Cout) out[(size_t)cir * a.Cout + cc] = acc[tm][tn][r];
+                if (cc < a.Cout) out[(size_t)cir * a.Cout + cc] = acc[tm][tn][r] * alpha;
             }
         }
     }
 }
 
-__global__ __launch_bounds__(256) void plain_reduce_kernel(const float* ws, float* y, int total, int splits) {
+__global__ __launch_bounds__(256) void plain_reduce_kernel(const float* ws, float* y, int total, int splits, float alpha) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         float s = 0.f;
         for (int k = 0; k < splits; k++) s += ws[(size_t)k * total + i];
-        y[i] = s;
+        y[i] = s * alpha;
     }
 }
 
@@ -698,6 +708,18 @@ int fwd_geometry_check(const igan_conv2d_params* p) {
     IGAN_REQUIRE((long long)p->N * p->OH * p->OW * p->Cout <= INT32_MAX, "conv2d: output too large");
     IGAN_REQUIRE((long long)p->KH * p->KW * p->Cin * p->Cout * 4 <= 0x7FFFFFF0LL, "conv2d: filter too large (2 GiB per operand)");
     return IGAN_OK;
+}
+
+// 1x1 convolution on a 1x1 map = a dense layer; with at most 32 rows and no scales it goes to dense_small.hip
+bool is_small_dense(const igan_conv2d_params* p) {
+    return p->H == 1 && p->W == 1 && p->OH == 1 && p->OW == 1 && p->KH == 1 && p->KW == 1 && p->stride == 1 && p->up == 1 &&
+           p->pad_y == 0 && p->pad_x == 0 && !p->in_scale && !p->out_scale &&
+           igan::dense_small_ok(p->N, p->Cin, p->x, p->w, p->w_transposed != 0);
+}
+bool is_small_dense_wgrad(const igan_conv2d_wgrad_params* p) {
+    return p->H == 1 && p->W == 1 && p->OH == 1 && p->OW == 1 && p->KH == 1 && p->KW == 1 && p->stride == 1 && p->up == 1 &&
+           p->pad_y == 0 && p->pad_x == 0 && !p->in_scale && !p->out_scale &&
+           igan::dense_small_wgrad_ok(p->N, p->Cout, p->dy, p->dw);
 }
 
 void fwd_counts(const igan_conv2d_params* p, int& Mmax, int& chunks_max, int& nclass) {
@@ -732,6 +754,7 @@ void launch_fwd(hipStream_t stream, const ConvArgs& a, dim3 grid, bool wt, bool 
 extern "C" int igan_conv2d_plan(const igan_conv2d_params* p, int* splits, size_t* workspace_floats) {
     IGAN_REQUIRE(p && splits && workspace_floats, "conv2d_plan: null argument");
     if (int rc = fwd_geometry_check(p)) return rc;
+    if (is_small_dense(p)) { *splits = 1; *workspace_floats = 0; return IGAN_OK; }
     int Mmax, chunks_max, nclass;
     fwd_counts(p, Mmax, chunks_max, nclass);
     const FwdTile t = pick_fwd_tile(Mmax, p->Cout);
@@ -764,6 +787,10 @@ extern "C" int igan_conv2d_plan(const igan_conv2d_params* p, int* splits, size_t
 extern "C" int igan_conv2d_kernel_name(const igan_conv2d_params* p, char* buf, int buflen) {
     IGAN_REQUIRE(p && buf && buflen > 0, "conv2d_kernel_name: null argument");
     if (int rc = fwd_geometry_check(p)) return rc;
+    if (is_small_dense(p)) {
+        snprintf(buf, (size_t)buflen, "dense_small_kernel<%d, %s>", igan::dense_small_rows(p->N), p->w_transposed ? "true" : "false");
+        return IGAN_OK;
+    }
     int Mmax, chunks_max, nclass;
     fwd_counts(p, Mmax, chunks_max, nclass);
     const FwdTile t = pick_fwd_tile(Mmax, p->Cout);
@@ -785,6 +812,11 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
     hipStream_t stream = (hipStream_t)stream_;
     IGAN_REQUIRE(p != nullptr, "conv2d: null params");
     if (int rc = fwd_geometry_check(p)) return rc;
+    if (is_small_dense(p)) {
+        dense_small(stream, p->x, p->w, p->y, p->N, p->Cin, p->Cout, p->w_transposed != 0, p->alpha);
+        IGAN_LAUNCH_CHECK("conv2d dense launch");
+        return IGAN_OK;
+    }
     const int splits = std::max(1, p->splits);
     const size_t out_elems = (size_t)p->N * p->OH * p->OW * p->Cout;
     if (splits > 1) {
@@ -813,6 +845,7 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
     if (p->w_transposed) a.vecB = (p->Cin % 4 == 0) && (((uintptr_t)p->w & 15) == 0);
     else a.vecB = (p->Cout % 4 == 0) && (((uintptr_t)p->w & 15) == 0);
     a.vecY = (p->Cout % 2 == 0) && ((((uintptr_t)a.y | (uintptr_t)p->out_scale) & 7) == 0);
+    a.alpha = p->alpha;
 
     dim3 grid(ceil_div(Mmax, t.BM), ceil_div(p->Cout, t.BN), nclass * splits);
     const bool wt = p->w_transposed != 0;
@@ -827,7 +860,7 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
         const int total = (int)out_elems;
         const int rg = std::min(ceil_div(total, 256), 2048);
         hipLaunchKernelGGL(conv_reduce_kernel, dim3(rg), dim3(256), 0, stream,
-                           (const float*)p->workspace, p->y, p->out_scale, total, splits, p->Cout, p->OH * p->OW);
+                           (const float*)p->workspace, p->y, p->out_scale, total, splits, p->Cout, p->OH * p->OW, p->alpha);
         IGAN_LAUNCH_CHECK("conv2d reduce launch");
     }
     return IGAN_OK;
@@ -897,6 +930,7 @@ int wgrad_splits(const igan_conv2d_wgrad_params* p) {
 extern "C" int igan_conv2d_wgrad_plan(const igan_conv2d_wgrad_params* p, int* splits, size_t* workspace_floats) {
     IGAN_REQUIRE(p && splits && workspace_floats, "conv2d_wgrad_plan: null argument");
     if (int rc = wgrad_geometry_check(p)) return rc;
+    if (is_small_dense_wgrad(p)) { *splits = 1; *workspace_floats = 0; return IGAN_OK; }
     const int s = wgrad_splits(p);
     *splits = s;
     *workspace_floats = (s > 1) ? (size_t)s * p->KH * p->KW * p->Cin * p->Cout : 0;
@@ -908,6 +942,11 @@ extern "C" int igan_conv2d_wgrad(igan_stream_t stream_, const igan_conv2d_wgrad_
     hipStream_t stream = (hipStream_t)stream_;
     IGAN_REQUIRE(p != nullptr, "conv2d_wgrad: null params");
     if (int rc = wgrad_geometry_check(p)) return rc;
+    if (is_small_dense_wgrad(p)) {
+        dense_small_wgrad(stream, p->x, p->dy, p->dw, p->N, p->Cin, p->Cout, p->alpha);
+        IGAN_LAUNCH_CHECK("conv2d_wgrad dense launch");
+        return IGAN_OK;
+    }
     const int splits = std::max(1, p->splits);
     const size_t wsize = (size_t)p->KH * p->KW * p->Cin * p->Cout;
     if (splits > 1) {
@@ -930,6 +969,7 @@ extern "C" int igan_conv2d_wgrad(igan_stream_t stream_, const igan_conv2d_wgrad_
     a.vecSB = (p->Cout % 4 == 0) && (((uintptr_t)p->out_scale & 15) == 0);
 
     a.vecY = (p->Cout % 2 == 0) && (((uintptr_t)a.out & 7) == 0);
+    a.alpha = p->alpha;
 
     const WgTile t = pick_wg_tile(p->Cin, p->Cout);
     dim3 grid(ceil_div(p->Cin, t.BM), ceil_div(p->Cout, t.BN), p->KH * p->KW * splits);
@@ -942,7 +982,7 @@ extern "C" int igan_conv2d_wgrad(igan_stream_t stream_, const igan_conv2d_wgrad_
     if (splits > 1) {
         const int total = (int)wsize;
         const int rg = std::min(ceil_div(total, 256), 2048);
-        hipLaunchKernelGGL(plain_reduce_kernel, dim3(rg), dim3(256), 0, stream, (const float*)p->workspace, p->dw, total, splits);
+        hipLaunchKernelGGL(plain_reduce_kernel, dim3(rg), dim3(256), 0, stream, (const float*)p->workspace, p->dw, total, splits, p->alpha);
         IGAN_LAUNCH_CHECK("conv2d_wgrad reduce launch");
     }
     return IGAN_OK;

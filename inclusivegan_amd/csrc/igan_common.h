@@ -29,6 +29,13 @@ inline int check_hip(hipError_t e, const char* what) {
         if (e__ != hipSuccess) return ::igan::check_hip(e__, what); \
     } while (0)
 
+// dense_small.hip: small-batch (M <= 32 rows) dense layers, dispatched from igan_conv2d / igan_conv2d_wgrad
+bool dense_small_ok(int M, int K, const void* x, const void* w, bool wt);
+int dense_small_rows(int M);
+void dense_small(hipStream_t stream, const float* x, const float* w, float* y, int M, int K, int N, bool wt, float alpha);
+bool dense_small_wgrad_ok(int M, int N, const void* dy, const void* dw);
+void dense_small_wgrad(hipStream_t stream, const float* x, const float* dy, float* dw, int M, int K, int N, float alpha);
+
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline long long ceil_div_ll(long long a, long long b) { return (a + b - 1) / b; }
 

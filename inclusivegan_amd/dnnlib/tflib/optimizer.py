@@ -73,14 +73,30 @@ class Optimizer:
             st['flag'] = torch.zeros((1,), device=net.flat_params.device, dtype=torch.int32)
             st['overflows'] = torch.zeros((1,), device=net.flat_params.device, dtype=torch.int64)
 
+    @staticmethod
+    def _backprop_into_bucket(loss, net, accumulate):
+        """d loss / d trainables written (or added) into the flat gradient bucket.  torch.autograd.grad
+        hands the gradients back instead of running one AccumulateGrad add per variable; a multi-tensor
+        copy then places them in the bucket views (a few launches for the whole network)."""
+        params = [p for p in net.trainables.values() if p.requires_grad]
+        grads = torch.autograd.grad(loss, params, allow_unused=True)
+        dst = [p.grad for p, g in zip(params, grads) if g is not None]
+        src = [g for g in grads if g is not None]
+        if not dst:
+            return
+        with torch.no_grad():
+            if accumulate:
+                torch._foreach_add_(dst, src)
+            else:
+                torch._foreach_copy_(dst, src)
+
     def register_gradients(self, loss, net):
         """Accumulate d loss / d trainables into the network's gradient bucket.
         `net` is the Network whose trainables are optimised (the reference passes `G_gpu.trainables`)."""
         self._bind(net)
         if self._num_registered == 0:
             net.flat_grads.zero_()
-        params = [p for p in net.trainables.values() if p.requires_grad]
-        torch.autograd.backward(loss, inputs=params)
+        self._backprop_into_bucket(loss, net, accumulate=True)
         self._num_registered += 1
 
     def differentiate(self, loss, net):
@@ -89,8 +105,7 @@ class Optimizer:
         call `mark_registered(net)` and then `apply_updates()`."""
         self._bind(net)
         net.flat_grads.zero_()
-        params = [p for p in net.trainables.values() if p.requires_grad]
-        torch.autograd.backward(loss, inputs=params)
+        self._backprop_into_bucket(loss, net, accumulate=False)
 
     def mark_registered(self, net, count=1):
         self._bind(net)

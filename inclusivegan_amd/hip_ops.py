@@ -334,7 +334,7 @@ def bias_act_noise(x, b, noise, strength, act_idx, alpha, gain):
 # conv2d family
 
 # Geometry of y = conv(x, w): see include/igan_hip.h (igan_conv2d_params).
-ConvGeom = namedtuple('ConvGeom', 'kh kw stride up pad_y pad_x')
+ConvGeom = namedtuple('ConvGeom', 'kh kw stride up pad_y pad_x alpha', defaults=(1.0,))   # alpha: output multiplier (runtime weight scale)
 
 _plan_cache = {}
 _wplan_cache = {}
@@ -342,6 +342,16 @@ _wplan_cache = {}
 # Profiling hook (bench.py): when set to a list, every conv2d_raw launch is bracketed by HIP events on the
 # launch stream and logged as (kernel name, algorithmic FLOPs, start event, end event).
 launch_log = None
+shape_log = None      # tools/conv_shapes.py: (kind, shape key, flops, splits, start event, end event) per conv-family launch
+
+
+def _shape_logged(kind, key, flops, splits, launch):
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    launch()
+    e1.record()
+    shape_log.append((kind, key, flops, splits, e0, e1))
 
 
 def conv_flops(n, h, w, cin, oh, ow, cout, geom):
@@ -385,7 +395,7 @@ def conv2d_raw(x, w, geom, out_hw, cout, w_transposed=False, in_scale=None, out_
         N=n, H=h, W=wd, Cin=cin, OH=oh, OW=ow, Cout=cout,
         KH=geom.kh, KW=geom.kw, stride=geom.stride, up=geom.up,
         pad_y=geom.pad_y, pad_x=geom.pad_x,
-        w_transposed=1 if w_transposed else 0, splits=1)
+        w_transposed=1 if w_transposed else 0, splits=1, alpha=float(geom.alpha))
     key = (n, h, wd, cin, oh, ow, cout, geom)
     plan = _plan_cache.get(key)
     if plan is None:
@@ -409,6 +419,11 @@ def conv2d_raw(x, w, geom, out_hw, cout, w_transposed=False, in_scale=None, out_
         _abi.check(lib.igan_conv2d(_stream(), ctypes.byref(p)))
         e1.record()
         launch_log.append((buf.value.decode(), conv_flops(n, h, wd, cin, oh, ow, cout, geom), plan[0], e0, e1))
+        return y
+    if shape_log is not None:
+        kind = ('dgrad' if w_transposed else 'fwd') + ('+s' if in_scale is not None else '')
+        _shape_logged(kind, key, conv_flops(n, h, wd, cin, oh, ow, cout, geom), plan[0],
+                      lambda: _abi.check(lib.igan_conv2d(_stream(), ctypes.byref(p))))
         return y
     _abi.check(lib.igan_conv2d(_stream(), ctypes.byref(p)))
     return y
@@ -436,7 +451,7 @@ def conv2d_wgrad_raw(x, dy, geom, in_scale=None, out_scale=None):
         workspace=None, workspace_floats=0,
         N=n, H=h, W=wd, Cin=cin, OH=oh, OW=ow, Cout=cout,
         KH=geom.kh, KW=geom.kw, stride=geom.stride, up=geom.up,
-        pad_y=geom.pad_y, pad_x=geom.pad_x, splits=1)
+        pad_y=geom.pad_y, pad_x=geom.pad_x, splits=1, alpha=float(geom.alpha))
     key = (n, h, wd, cin, oh, ow, cout, geom)
     plan = _wplan_cache.get(key)
     if plan is None:
@@ -451,13 +466,18 @@ def conv2d_wgrad_raw(x, dy, geom, in_scale=None, out_scale=None):
         p.workspace = ws.data_ptr()
         p.workspace_floats = plan[1]
         p.splits = plan[0]
+    if shape_log is not None:
+        _shape_logged('wgrad' + ('+s' if in_scale is not None or out_scale is not None else ''), key,
+                      conv_flops(n, h, wd, cin, oh, ow, cout, geom), plan[0],
+                      lambda: _abi.check(lib.igan_conv2d_wgrad(_stream(), ctypes.byref(p))))
+        return dw
     _abi.check(lib.igan_conv2d_wgrad(_stream(), ctypes.byref(p)))
     return dw
 
 
 def dgrad_geom(g):
     """Data-gradient geometry of a forward geometry (include/igan_hip.h)."""
-    return ConvGeom(g.kh, g.kw, g.up, g.stride, g.kh - 1 - g.pad_y, g.kw - 1 - g.pad_x)
+    return ConvGeom(g.kh, g.kw, g.up, g.stride, g.kh - 1 - g.pad_y, g.kw - 1 - g.pad_x, g.alpha)
 
 
 class Conv2dFn(torch.autograd.Function):
@@ -526,10 +546,10 @@ def conv2d(x, w, geom, out_hw):
     return Conv2dFn.apply(x, w, geom, out_hw)
 
 
-def matmul(x, w):
-    """tf.matmul(x[N,in], w[in,out]) (networks_stylegan2.py:46) as a 1x1 conv on [N,in,1,1]."""
+def matmul(x, w, alpha=1.0):
+    """alpha * tf.matmul(x[N,in], w[in,out]) (networks_stylegan2.py:46) as a 1x1 conv on [N,in,1,1]."""
     n, cin = x.shape
-    y = Conv2dFn.apply(x.reshape(n, cin, 1, 1), w.reshape(1, 1, cin, w.shape[1]), ConvGeom(1, 1, 1, 1, 0, 0), (1, 1))
+    y = Conv2dFn.apply(x.reshape(n, cin, 1, 1), w.reshape(1, 1, cin, w.shape[1]), ConvGeom(1, 1, 1, 1, 0, 0, float(alpha)), (1, 1))
     return y.reshape(n, w.shape[1])
 
 

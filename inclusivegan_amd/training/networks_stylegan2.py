@@ -40,8 +40,11 @@ def get_weight(shape, gain=1, use_wscale=True, lrmul=1, weight_var='weight', ini
         init_std = he_std / lrmul
         runtime_coef = lrmul
     w = get_variable(weight_var, shape=shape, initializer=('normal', init_std * init_mul))
-    # one multiply per training op, shared by every forward pass of that op (tfutil.derived)
-    return tfutil.derived(weight_var + ':scaled', lambda: w * float(runtime_coef))
+    # The reference returns w * runtime_coef (:36).  Every consumer here is a GEMM / convolution, which is
+    # linear in w, so the coefficient rides along as the kernels' output multiplier (ConvGeom.alpha,
+    # igan_conv2d_params.alpha) -- forward, data gradient and weight gradient alike -- and no scaled copy
+    # of the weights (nor its gradient pass) exists.
+    return w, float(runtime_coef)
 
 #----------------------------------------------------------------------------
 # Fully-connected layer (:41-46).
@@ -49,8 +52,8 @@ def get_weight(shape, gain=1, use_wscale=True, lrmul=1, weight_var='weight', ini
 def dense_layer(x, fmaps, gain=1, use_wscale=True, lrmul=1, weight_var='weight', init_mul=1.0):
     if x.dim() > 2:
         x = x.reshape(x.shape[0], -1)   # logical NCHW flatten order, like tf.reshape on NCHW
-    w = get_weight([int(x.shape[1]), fmaps], gain=gain, use_wscale=use_wscale, lrmul=lrmul, weight_var=weight_var, init_mul=init_mul)
-    return hip_ops.matmul(x, w)
+    w, coef = get_weight([int(x.shape[1]), fmaps], gain=gain, use_wscale=use_wscale, lrmul=lrmul, weight_var=weight_var, init_mul=init_mul)
+    return hip_ops.matmul(x, w, alpha=coef)
 
 #----------------------------------------------------------------------------
 # Convolution layer with optional upsampling or downsampling (:51-61).
@@ -58,14 +61,14 @@ def dense_layer(x, fmaps, gain=1, use_wscale=True, lrmul=1, weight_var='weight',
 def conv2d_layer(x, fmaps, kernel, up=False, down=False, resample_kernel=None, gain=1, use_wscale=True, lrmul=1, weight_var='weight', init_mul=1.0):
     assert not (up and down)
     assert kernel >= 1 and kernel % 2 == 1
-    w = get_weight([kernel, kernel, int(x.shape[1]), fmaps], gain=gain, use_wscale=use_wscale, lrmul=lrmul, weight_var=weight_var, init_mul=init_mul)
+    w, coef = get_weight([kernel, kernel, int(x.shape[1]), fmaps], gain=gain, use_wscale=use_wscale, lrmul=lrmul, weight_var=weight_var, init_mul=init_mul)
     if up:
-        x = upsample_conv_2d(x, w, data_format='NCHW', k=resample_kernel)
+        x = upsample_conv_2d(x, w, data_format='NCHW', k=resample_kernel, gain=coef)     # gain scales the FIR taps: same product
     elif down:
-        x = conv_downsample_2d(x, w, data_format='NCHW', k=resample_kernel)
+        x = conv_downsample_2d(x, w, data_format='NCHW', k=resample_kernel, gain=coef)
     else:
         p = (kernel - 1) // 2   # SAME, stride 1, odd kernel
-        x = hip_ops.conv2d(x, w, hip_ops.ConvGeom(kernel, kernel, 1, 1, p, p), (int(x.shape[2]), int(x.shape[3])))
+        x = hip_ops.conv2d(x, w, hip_ops.ConvGeom(kernel, kernel, 1, 1, p, p, coef), (int(x.shape[2]), int(x.shape[3])))
     return x
 
 #----------------------------------------------------------------------------
@@ -94,7 +97,7 @@ def modulated_conv2d_layer(x, y, fmaps, kernel, up=False, down=False, demodulate
 
     # Get weight.
     cin = int(x.shape[1])
-    w = get_weight([kernel, kernel, cin, fmaps], gain=gain, use_wscale=use_wscale, lrmul=lrmul, weight_var=weight_var, init_mul=init_mul)
+    w, coef = get_weight([kernel, kernel, cin, fmaps], gain=gain, use_wscale=use_wscale, lrmul=lrmul, weight_var=weight_var, init_mul=init_mul)
 
     # Modulate.
     s = dense_layer(y, fmaps=cin, weight_var=mod_weight_var, init_mul=init_mul) # [BI] Transform incoming W to style.
@@ -103,13 +106,13 @@ def modulated_conv2d_layer(x, y, fmaps, kernel, up=False, down=False, demodulate
     # Demodulate: d[b,o] = rsqrt(sum_{k,k,i} (w*s)^2 + 1e-8) = rsqrt((s^2) @ (sum_kk w^2) + 1e-8).
     d = None
     if demodulate:
-        wsq = tfutil.derived(weight_var + ':sumsq', lambda: (w * w).sum(dim=(0, 1)))   # [I,O]
-        d = torch.rsqrt(hip_ops.matmul(s * s, wsq) + 1e-8) # [BO]
+        wsq = tfutil.derived(weight_var + ':sumsq', lambda: (w * w).sum(dim=(0, 1)))   # [I,O], of the raw weights
+        d = torch.rsqrt(hip_ops.matmul(s * s, wsq, alpha=coef * coef) + 1e-8) # [BO]
 
     # Convolution with optional up/downsampling; scales folded into the kernel.
     H, W = int(x.shape[2]), int(x.shape[3])
     if up:
-        geom = hip_ops.ConvGeom(kernel, kernel, 1, 2, kernel - 1, kernel - 1)
+        geom = hip_ops.ConvGeom(kernel, kernel, 1, 2, kernel - 1, kernel - 1, coef)
         out_hw = ((H - 1) * 2 + kernel, (W - 1) * 2 + kernel)
         x = hip_ops.ModConv2dFn.apply(x, w, s, d, geom, out_hw)
         # FIR after the transposed conv (upfirdn_2d.py:272-273,292)
@@ -124,11 +127,11 @@ def modulated_conv2d_layer(x, y, fmaps, kernel, up=False, down=False, demodulate
         # the FIR commutes with the per-channel input scale, so modulation stays inside the conv
         x = _simple_upfirdn_2d(x, k, pad0=(p+1)//2, pad1=p//2, data_format='NCHW')
         H, W = int(x.shape[2]), int(x.shape[3])
-        geom = hip_ops.ConvGeom(kernel, kernel, 2, 1, 0, 0)
+        geom = hip_ops.ConvGeom(kernel, kernel, 2, 1, 0, 0, coef)
         x = hip_ops.ModConv2dFn.apply(x, w, s, d, geom, ((H - kernel) // 2 + 1, (W - kernel) // 2 + 1))
     else:
         p = (kernel - 1) // 2
-        x = hip_ops.ModConv2dFn.apply(x, w, s, d, hip_ops.ConvGeom(kernel, kernel, 1, 1, p, p), (H, W))
+        x = hip_ops.ModConv2dFn.apply(x, w, s, d, hip_ops.ConvGeom(kernel, kernel, 1, 1, p, p, coef), (H, W))
     return x
 
 #----------------------------------------------------------------------------
