@@ -196,6 +196,57 @@ typedef struct igan_conv2d_wgrad_params {
 int igan_conv2d_wgrad_plan(const igan_conv2d_wgrad_params* p, int* splits, size_t* workspace_floats);
 int igan_conv2d_wgrad(igan_stream_t stream, const igan_conv2d_wgrad_params* p);
 
+/* ------------------------------------------------------------------------
+ * Small-batch dense layers with the StyleGAN2 style-path arithmetic folded in (M <= 32 rows; larger
+ * batches go through igan_conv2d as 1x1 convolutions):
+ *     y[m,n] = epi( alpha * sum_k pro(x)[m,k] * W(k,n) ),   W = w[k][n], or w[n][k] when w_transposed
+ * prologue (on x, element-wise):   NONE; SQUARE x^2; DEMOD_GRAD pro_scale * x * x2^3
+ * epilogue:  SCALE  v
+ *            BIAS   v + bias_scale * bias[n] + add_const                 (style affine + 1, networks_stylegan2.py:99-101)
+ *            RSQRT  rsqrt(v + eps)                                         (demodulation coefficients, :105-107)
+ *            STYLE_GRAD  e1[m,n] + 2 * e2[m,n] * v, and, if colsum != NULL, colsum[n] = bias_scale * sum_m y[m,n]
+ * so that, with q = s^2 . wsq and d = rsqrt(c^2 q + eps):
+ *     s  = BIAS(x=w_lat, W=A)                       d  = RSQRT(SQUARE s, W=wsq, alpha=c^2)
+ *     ds = STYLE_GRAD(DEMOD_GRAD(dd, d; pro_scale=-c^2/2), W=wsq^T, e1=ds_conv, e2=s)   [+ bias gradient]
+ * Weight-gradient form:  dw[k,n] = alpha * sum_m pro_a(a)[m,k] * pro_b(b)[m,n]   (pro_a NONE|SQUARE,
+ * pro_b NONE|DEMOD_GRAD with b2).  K % 4 == 0 (dense), N % 4 == 0 (weight gradient); x / x2 / b / b2 / dw
+ * 16-byte aligned.  Deterministic. */
+enum { IGAN_DENSE_PRO_NONE = 0, IGAN_DENSE_PRO_SQUARE = 1, IGAN_DENSE_PRO_DEMOD_GRAD = 2 };
+enum { IGAN_DENSE_EPI_SCALE = 0, IGAN_DENSE_EPI_BIAS = 1, IGAN_DENSE_EPI_RSQRT = 2, IGAN_DENSE_EPI_STYLE_GRAD = 3 };
+typedef struct igan_dense_params {
+    const float* x;         /* [M, K], row stride ldx floats (ldx % 4 == 0) */
+    const float* x2;        /* DEMOD_GRAD: [M, K] contiguous, else NULL */
+    const float* w;         /* [K, N], or [N, K] when w_transposed */
+    float* y;               /* [M, N], row stride ldy floats */
+    const float* bias;      /* BIAS: [N] */
+    const float* e1;        /* STYLE_GRAD: [M, N] contiguous or NULL (= 0) */
+    const float* e2;        /* STYLE_GRAD: [M, N] contiguous */
+    float* colsum;          /* STYLE_GRAD: [N] or NULL */
+    int ldx, ldy;
+    int M, K, N;
+    int w_transposed;
+    int prologue, epilogue;
+    float alpha, pro_scale, bias_scale, add_const, eps;
+} igan_dense_params;
+int igan_dense_small(igan_stream_t stream, const igan_dense_params* p);
+
+typedef struct igan_dense_wgrad_params {
+    const float* a;         /* [M, K], row stride lda floats */
+    const float* b;         /* [M, N] contiguous */
+    const float* b2;        /* DEMOD_GRAD: [M, N] contiguous, else NULL */
+    float* dw;              /* [K, N] */
+    int lda;
+    int M, K, N;
+    int pro_a, pro_b;
+    float alpha, pro_scale;
+} igan_dense_wgrad_params;
+int igan_dense_small_wgrad(igan_stream_t stream, const igan_dense_wgrad_params* p);
+
+/* out[i] = sum_t w[t*n + i]^2  (sum over the filter taps of the squared weights: the [Cin,Cout] matrix of the
+ * demodulation, :105) and out[t*n + i] = scale * w[t*n + i] * v[i] (its gradient back onto the filter). */
+int igan_sumsq_taps(igan_stream_t stream, const float* w, float* out, int taps, int n);
+int igan_bcast_mul_taps(igan_stream_t stream, const float* w, const float* v, float* out, int taps, int n, float scale);
+
 /* Per-sample channel dot products of two channel-minor tensors a, b [N, HW, C] (C % 4 == 0):
  *     dot[n,c] = sum_hw a[n,hw,c] * b[n,hw,c];   if out != NULL: out[n,hw,c] = b[n,hw,c] * s[n,c]
  * (out may alias b; s may be NULL = 1).  These are the style / demodulation gradients of

@@ -81,6 +81,32 @@ class Conv2DWgradParams(ctypes.Structure):
         super().__init__(*args, **kwargs)
 
 
+class DenseParams(ctypes.Structure):
+    _fields_ = [
+        ('x', ctypes.c_void_p), ('x2', ctypes.c_void_p), ('w', ctypes.c_void_p), ('y', ctypes.c_void_p),
+        ('bias', ctypes.c_void_p), ('e1', ctypes.c_void_p), ('e2', ctypes.c_void_p), ('colsum', ctypes.c_void_p),
+        ('ldx', ctypes.c_int), ('ldy', ctypes.c_int),
+        ('M', ctypes.c_int), ('K', ctypes.c_int), ('N', ctypes.c_int),
+        ('w_transposed', ctypes.c_int),
+        ('prologue', ctypes.c_int), ('epilogue', ctypes.c_int),
+        ('alpha', ctypes.c_float), ('pro_scale', ctypes.c_float), ('bias_scale', ctypes.c_float),
+        ('add_const', ctypes.c_float), ('eps', ctypes.c_float),
+    ]
+
+
+class DenseWgradParams(ctypes.Structure):
+    _fields_ = [
+        ('a', ctypes.c_void_p), ('b', ctypes.c_void_p), ('b2', ctypes.c_void_p), ('dw', ctypes.c_void_p),
+        ('lda', ctypes.c_int),
+        ('M', ctypes.c_int), ('K', ctypes.c_int), ('N', ctypes.c_int),
+        ('pro_a', ctypes.c_int), ('pro_b', ctypes.c_int),
+        ('alpha', ctypes.c_float), ('pro_scale', ctypes.c_float),
+    ]
+
+
+DENSE_PRO_NONE, DENSE_PRO_SQUARE, DENSE_PRO_DEMOD_GRAD = 0, 1, 2
+DENSE_EPI_SCALE, DENSE_EPI_BIAS, DENSE_EPI_RSQRT, DENSE_EPI_STYLE_GRAD = 0, 1, 2, 3
+
 _I, _F, _P, _SZ = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 
 # name -> (restype, argtypes): every symbol include/igan_hip.h declares.
@@ -99,6 +125,10 @@ SIGNATURES = {
     'igan_conv2d_kernel_name': (_I, [ctypes.POINTER(Conv2DParams), ctypes.c_char_p, _I]),
     'igan_conv2d_wgrad_plan': (_I, [ctypes.POINTER(Conv2DWgradParams), ctypes.POINTER(_I), ctypes.POINTER(_SZ)]),
     'igan_conv2d_wgrad': (_I, [_P, ctypes.POINTER(Conv2DWgradParams)]),
+    'igan_dense_small': (_I, [_P, ctypes.POINTER(DenseParams)]),
+    'igan_dense_small_wgrad': (_I, [_P, ctypes.POINTER(DenseWgradParams)]),
+    'igan_sumsq_taps': (_I, [_P, _P, _P, _I, _I]),
+    'igan_bcast_mul_taps': (_I, [_P, _P, _P, _P, _I, _I, _F]),
     'igan_scale_dot_workspace_floats': (_SZ, [_I, _I, _I]),
     'igan_scale_dot': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I]),
     'igan_lpips_layer_blocks': (_I, [_I, _I]),

@@ -1,104 +1,202 @@
-// Small-batch dense layers on gfx950: y[M,N] = x[M,K] . w  for M <= 32 rows (the mapping network and the
-// per-layer style / demodulation matmuls, networks_stylegan2.py:41-46,107,117: 38 of them per generator
+// Small-batch dense layers on gfx950: y[M,N] = f(x)[M,K] . w  for M <= 32 rows, with the surrounding
+// per-element arithmetic of the StyleGAN2 style path folded in (networks_stylegan2.py:41-46,99-107,117:
+// the mapping network and, per synthesis layer, the style affine  s = A(w_lat) + b + 1  and the
+// demodulation coefficients  d = rsqrt(s^2 . sum_taps(w^2) + 1e-8)  -- 38 small matmuls per generator
 // pass at batch 3..24), and their data / weight gradients.
 //
 // These are not MFMA work: 12 MFLOP against a 1 MB weight matrix.  On the implicit-GEMM path a call
-// cost a 32x128-tile kernel cut 8 ways along K plus a reduce kernel (about 13 us of launches for
-// 0.3 us of memory traffic).  Here one launch streams the weight matrix once:
-//   * a workgroup owns 8 output channels; its 256 lanes are 32 reduction groups x 8 channels, every
-//     group takes 4 consecutive k out of each 128 (so the x operand is one ds_read_b128 per row,
-//     broadcast to the 8 channel lanes, and the weights are 32 B (w[k][n]) or 16 B-per-lane (w[n][k])
-//     contiguous pieces);
-//   * x (at most 32 x 256 floats per tile) is staged in LDS once per workgroup, rows beyond M zero;
-//   * the 32 group partials meet in LDS and are added in fixed order: bit-reproducible, no atomics.
-// The weight gradient is an M-term outer product per element: one thread per 4 output channels.
-// Dispatched from igan_conv2d / igan_conv2d_wgrad when the geometry is 1x1 on a 1x1 map without
-// scales; everything else stays on the MFMA kernels.
+// cost a 32x128-tile kernel cut 8 ways along K plus a reduce kernel, and every surrounding element-wise
+// step (bias, +1, square, +eps, rsqrt, the chain-rule factors of the backward) was a launch of its
+// own: about 40 launches per modulated layer and direction.  Here one launch streams the weight
+// matrix once and applies a prologue to x and an epilogue to y:
+//   * a workgroup owns 4 output channels; its 256 lanes are 64 reduction groups x 4 channels, every
+//     group takes 4 consecutive k out of each 256 (so the x operand is one ds_read_b128 per row,
+//     broadcast to the 4 channel lanes, and the weights are 16 B pieces);
+//   * x (up to 32 rows x 512 floats per super-tile, prologue applied) is staged in LDS once per
+//     workgroup, rows beyond M zero;
+//   * the 64 group partials meet in LDS and are added in fixed order: bit-reproducible, no atomics.
+// The weight-gradient kernel is an M-term outer product per element: one thread per 4 output channels.
 #include "igan_common.h"
 
 namespace {
 
-constexpr int DS_COLS = 8;                   // output channels per workgroup
-constexpr int DS_GROUPS = 32;                // reduction groups per workgroup
-constexpr int DS_KT = 256;                   // reduction tile staged in LDS (floats)
+constexpr int DS_COLS = 4;                   // output channels per workgroup
+constexpr int DS_GROUPS = 64;                // reduction groups per workgroup
+constexpr int DS_KS = 512;                   // reduction super-tile staged in LDS at once (floats)
+constexpr int DS_NIT = DS_KS / (4 * DS_GROUPS);   // float4 k-groups per lane per super-tile
 
+__device__ __forceinline__ float pro_apply(int pro, float v, float v2, float ps) {
+    if (pro == IGAN_DENSE_PRO_SQUARE) return v * v;
+    if (pro == IGAN_DENSE_PRO_DEMOD_GRAD) return ps * v * v2 * v2 * v2;    // -1/2 c^2 dd d^3 with ps = -c^2/2
+    return v;
+}
+
+// The kernel is a latency chain, not a throughput problem (1 MB of weights over >= 128 workgroups): all of a
+// super-tile's global loads -- the lane's weights and its share of x -- are issued before anything waits, so
+// the chain is  [one round of loads] -> [LDS image of x] -> [FMAs] -> [group reduce].
 template <int MB, bool WT>
-__global__ __launch_bounds__(256) void dense_small_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                          float* __restrict__ y, int M, int K, int N, float alpha) {
-    constexpr int RSTR = MB * DS_COLS + 8;   // group stride in the partial-sum image (bank-spread)
-    __shared__ __attribute__((aligned(16))) float xs[MB * DS_KT];
+__global__ __launch_bounds__(256) void dense_small_kernel(igan_dense_params a) {
+    constexpr int RSTR = MB * DS_COLS + 4;   // group stride in the partial-sum image (bank-spread)
+    constexpr int XV = MB * (DS_KS / 4) / 256;   // float4 of x per lane per super-tile
+    __shared__ __attribute__((aligned(16))) float xs[MB * DS_KS];
     __shared__ float red[DS_GROUPS * RSTR];
+    const int M = a.M, K = a.K, N = a.N;
     const int tid = threadIdx.x, c = tid & (DS_COLS - 1), g = tid / DS_COLS;
     const int j = blockIdx.x * DS_COLS + c;
     const bool jok = j < N;
+    const float* __restrict__ w = a.w;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     float acc[MB];
 #pragma unroll
     for (int m = 0; m < MB; m++) acc[m] = 0.f;
 
-    for (int k0 = 0; k0 < K; k0 += DS_KT) {
-        for (int v = tid; v < MB * (DS_KT / 4); v += 256) {
-            const int m = v / (DS_KT / 4), kv = v - m * (DS_KT / 4);
-            const int k = k0 + 4 * kv;
-            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < M && k < K) t = *reinterpret_cast<const float4*>(x + (size_t)m * K + k);
-            *reinterpret_cast<float4*>(xs + m * DS_KT + 4 * kv) = t;
-        }
-        __syncthreads();
+    for (int k0 = 0; k0 < K; k0 += DS_KS) {
+        // weights of this lane: k = k0 + (it*GROUPS + g)*4 .. +3   (K % 4 == 0: in range together)
+        float4 wv[DS_NIT];
 #pragma unroll
-        for (int it = 0; it < DS_KT / (4 * DS_GROUPS); it++) {
-            const int i = (it * DS_GROUPS + g) * 4;
-            const int k = k0 + i;
-            float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (jok && k < K) {      // K % 4 == 0: the four k are in range together
-                if constexpr (WT) wv = *reinterpret_cast<const float4*>(w + (size_t)j * K + k);
+        for (int it = 0; it < DS_NIT; it++) {
+            const int k = k0 + (it * DS_GROUPS + g) * 4;
+            wv[it] = zero;
+            if (jok && k < K) {
+                if constexpr (WT) wv[it] = *reinterpret_cast<const float4*>(w + (size_t)j * K + k);
                 else {
-                    wv.x = w[(size_t)(k + 0) * N + j]; wv.y = w[(size_t)(k + 1) * N + j];
-                    wv.z = w[(size_t)(k + 2) * N + j]; wv.w = w[(size_t)(k + 3) * N + j];
+                    wv[it].x = w[(size_t)(k + 0) * N + j]; wv[it].y = w[(size_t)(k + 1) * N + j];
+                    wv[it].z = w[(size_t)(k + 2) * N + j]; wv[it].w = w[(size_t)(k + 3) * N + j];
                 }
             }
+        }
+        // x super-tile [MB][DS_KS], prologue applied, rows >= M and columns >= K zero
+        float4 xv[XV], xu[XV];
 #pragma unroll
-            for (int m = 0; m < MB; m++) {
-                const float4 xv = *reinterpret_cast<const float4*>(xs + m * DS_KT + i);
-                acc[m] = fmaf(xv.x, wv.x, fmaf(xv.y, wv.y, fmaf(xv.z, wv.z, fmaf(xv.w, wv.w, acc[m]))));
+        for (int q = 0; q < XV; q++) {
+            const int v = tid + 256 * q;
+            const int m = v / (DS_KS / 4), kv = v - m * (DS_KS / 4);
+            const int k = k0 + 4 * kv;
+            const bool ok = (m < M) && (k < K);
+            xv[q] = ok ? *reinterpret_cast<const float4*>(a.x + (size_t)m * a.ldx + k) : zero;
+            xu[q] = (ok && a.prologue == IGAN_DENSE_PRO_DEMOD_GRAD) ? *reinterpret_cast<const float4*>(a.x2 + (size_t)m * K + k) : zero;
+        }
+        if (k0 > 0) __syncthreads();         // the previous super-tile's readers are done with xs
+#pragma unroll
+        for (int q = 0; q < XV; q++) {
+            const int v = tid + 256 * q;
+            float4 t = xv[q];
+            if (a.prologue != IGAN_DENSE_PRO_NONE) {
+                t.x = pro_apply(a.prologue, t.x, xu[q].x, a.pro_scale); t.y = pro_apply(a.prologue, t.y, xu[q].y, a.pro_scale);
+                t.z = pro_apply(a.prologue, t.z, xu[q].z, a.pro_scale); t.w = pro_apply(a.prologue, t.w, xu[q].w, a.pro_scale);
             }
+            *reinterpret_cast<float4*>(xs + 4 * v) = t;      // v enumerates [m][kv] row-major: offset m*DS_KS + 4*kv
         }
         __syncthreads();
+#pragma unroll
+        for (int it = 0; it < DS_NIT; it++) {
+            const int i = (it * DS_GROUPS + g) * 4;
+#pragma unroll
+            for (int m = 0; m < MB; m++) {
+                const float4 t = *reinterpret_cast<const float4*>(xs + m * DS_KS + i);
+                acc[m] = fmaf(t.x, wv[it].x, fmaf(t.y, wv[it].y, fmaf(t.z, wv[it].z, fmaf(t.w, wv[it].w, acc[m]))));
+            }
+        }
     }
 #pragma unroll
     for (int m = 0; m < MB; m++) red[g * RSTR + m * DS_COLS + c] = acc[m];
     __syncthreads();
-    for (int o = tid; o < MB * DS_COLS; o += 256) {
+    float* ysum = xs;      // [MB][DS_COLS] epilogue values for the column sums (xs is free: all lanes passed the barrier)
+    if (tid < MB * DS_COLS) {
+        const int o = tid;
         const int m = o / DS_COLS, cc = o - m * DS_COLS;
         float s = 0.f;
-#pragma unroll 8
+#pragma unroll 16
         for (int gg = 0; gg < DS_GROUPS; gg++) s += red[gg * RSTR + o];
         const int jj = blockIdx.x * DS_COLS + cc;
-        if (m < M && jj < N) y[(size_t)m * N + jj] = s * alpha;
+        float v = 0.f;
+        if (m < M && jj < N) {
+            v = s * a.alpha;
+            if (a.epilogue == IGAN_DENSE_EPI_BIAS) v += a.bias_scale * a.bias[jj] + a.add_const;
+            else if (a.epilogue == IGAN_DENSE_EPI_RSQRT) v = rsqrtf(v + a.eps);
+            else if (a.epilogue == IGAN_DENSE_EPI_STYLE_GRAD) {
+                v = 2.0f * a.e2[(size_t)m * N + jj] * v;
+                if (a.e1) v += a.e1[(size_t)m * N + jj];
+            }
+            a.y[(size_t)m * a.ldy + jj] = v;
+        }
+        if (a.colsum) ysum[o] = v;
+    }
+    if (a.colsum) {        // colsum[j] = bias_scale * sum_m y[m][j]  (the bias gradient of the style affine)
+        __syncthreads();
+        if (tid < DS_COLS) {
+            const int jj = blockIdx.x * DS_COLS + tid;
+            float s = 0.f;
+            for (int m = 0; m < MB; m++) s += ysum[m * DS_COLS + tid];
+            if (jj < N) a.colsum[jj] = a.bias_scale * s;
+        }
     }
 }
 
-// dw[k][n] = sum_m x[m][k] * dy[m][n]
-__global__ __launch_bounds__(256) void dense_small_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                                float* __restrict__ dw, int M, int K, int N, float alpha) {
-    const int nv = N >> 2;
+// dw[k][n] = alpha * sum_m fa(a[m][k]) * fb(b[m][n]); rows in batches of 8 whose loads are all in flight
+// together (a serial loop over m is M dependent L2 round trips).
+__global__ __launch_bounds__(256) void dense_small_wgrad_kernel(igan_dense_wgrad_params p) {
+    const int nv = p.N >> 2;
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= K * nv) return;
+    if (idx >= p.K * nv) return;
     const int k = idx / nv, n4 = idx - k * nv;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int m = 0; m < M; m++) {
-        const float xv = x[(size_t)m * K + k];
-        const float4 d = *reinterpret_cast<const float4*>(dy + (size_t)m * N + 4 * n4);
-        acc.x = fmaf(xv, d.x, acc.x); acc.y = fmaf(xv, d.y, acc.y);
-        acc.z = fmaf(xv, d.z, acc.z); acc.w = fmaf(xv, d.w, acc.w);
+    for (int m0 = 0; m0 < p.M; m0 += 8) {
+        float xv[8];
+        float4 d[8], u[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int m = min(m0 + q, p.M - 1);      // clamped: always a valid address, masked below
+            xv[q] = p.a[(size_t)m * p.lda + k];
+            d[q] = *reinterpret_cast<const float4*>(p.b + (size_t)m * p.N + 4 * n4);
+            if (p.pro_b == IGAN_DENSE_PRO_DEMOD_GRAD) u[q] = *reinterpret_cast<const float4*>(p.b2 + (size_t)m * p.N + 4 * n4);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            float x = (m0 + q < p.M) ? xv[q] : 0.f;
+            if (p.pro_a == IGAN_DENSE_PRO_SQUARE) x *= x;
+            float4 t = d[q];
+            if (p.pro_b == IGAN_DENSE_PRO_DEMOD_GRAD) {
+                t.x = p.pro_scale * t.x * u[q].x * u[q].x * u[q].x; t.y = p.pro_scale * t.y * u[q].y * u[q].y * u[q].y;
+                t.z = p.pro_scale * t.z * u[q].z * u[q].z * u[q].z; t.w = p.pro_scale * t.w * u[q].w * u[q].w * u[q].w;
+            }
+            acc.x = fmaf(x, t.x, acc.x); acc.y = fmaf(x, t.y, acc.y);
+            acc.z = fmaf(x, t.z, acc.z); acc.w = fmaf(x, t.w, acc.w);
+        }
     }
-    *reinterpret_cast<float4*>(dw + (size_t)k * N + 4 * n4) = make_float4(acc.x * alpha, acc.y * alpha, acc.z * alpha, acc.w * alpha);
+    *reinterpret_cast<float4*>(p.dw + (size_t)k * p.N + 4 * n4) =
+        make_float4(acc.x * p.alpha, acc.y * p.alpha, acc.z * p.alpha, acc.w * p.alpha);
+}
+
+// out[i] = sum_t w[t][i]^2
+__global__ __launch_bounds__(256) void sumsq_taps_kernel(const float* __restrict__ w, float* __restrict__ out, int taps, int n4) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < taps; t++) {
+        const float4 v = reinterpret_cast<const float4*>(w)[(size_t)t * n4 + i];
+        s.x = fmaf(v.x, v.x, s.x); s.y = fmaf(v.y, v.y, s.y); s.z = fmaf(v.z, v.z, s.z); s.w = fmaf(v.w, v.w, s.w);
+    }
+    reinterpret_cast<float4*>(out)[i] = s;
+}
+
+// out[t][i] = scale * w[t][i] * v[i]
+__global__ __launch_bounds__(256) void bcast_mul_taps_kernel(const float* __restrict__ w, const float* __restrict__ v,
+                                                             float* __restrict__ out, int taps, int n4, float scale) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 m = reinterpret_cast<const float4*>(v)[i];
+    for (int t = 0; t < taps; t++) {
+        const float4 x = reinterpret_cast<const float4*>(w)[(size_t)t * n4 + i];
+        reinterpret_cast<float4*>(out)[(size_t)t * n4 + i] = make_float4(scale * x.x * m.x, scale * x.y * m.y, scale * x.z * m.z, scale * x.w * m.w);
+    }
 }
 
 template <int MB>
-void launch_dense(hipStream_t stream, const float* x, const float* w, float* y, int M, int K, int N, bool wt, float alpha) {
-    const dim3 grid(igan::ceil_div(N, DS_COLS));
-    if (wt) hipLaunchKernelGGL((dense_small_kernel<MB, true>), grid, dim3(256), 0, stream, x, w, y, M, K, N, alpha);
-    else hipLaunchKernelGGL((dense_small_kernel<MB, false>), grid, dim3(256), 0, stream, x, w, y, M, K, N, alpha);
+void launch_dense(hipStream_t stream, const igan_dense_params& a) {
+    const dim3 grid(igan::ceil_div(a.N, DS_COLS));
+    if (a.w_transposed) hipLaunchKernelGGL((dense_small_kernel<MB, true>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((dense_small_kernel<MB, false>), grid, dim3(256), 0, stream, a);
 }
 
 }  // namespace
@@ -109,13 +207,22 @@ bool dense_small_ok(int M, int K, const void* x, const void* w, bool wt) {
     return M >= 1 && M <= 32 && (K % 4) == 0 && (((uintptr_t)x) & 15) == 0 && (!wt || (((uintptr_t)w) & 15) == 0);
 }
 
-int dense_small_rows(int M) { return M <= 8 ? 8 : (M <= 16 ? 16 : 32); }
+int dense_small_rows(int M) { return M <= 8 ? 8 : (M <= 16 ? 16 : (M <= 24 ? 24 : 32)); }
+
+void dense_small_launch(hipStream_t stream, const igan_dense_params& a) {
+    const int mb = dense_small_rows(a.M);
+    if (mb == 8) launch_dense<8>(stream, a);
+    else if (mb == 16) launch_dense<16>(stream, a);
+    else if (mb == 24) launch_dense<24>(stream, a);
+    else launch_dense<32>(stream, a);
+}
 
 void dense_small(hipStream_t stream, const float* x, const float* w, float* y, int M, int K, int N, bool wt, float alpha) {
-    const int mb = dense_small_rows(M);
-    if (mb == 8) launch_dense<8>(stream, x, w, y, M, K, N, wt, alpha);
-    else if (mb == 16) launch_dense<16>(stream, x, w, y, M, K, N, wt, alpha);
-    else launch_dense<32>(stream, x, w, y, M, K, N, wt, alpha);
+    igan_dense_params a = {};
+    a.x = x; a.ldx = K; a.w = w; a.y = y; a.ldy = N;
+    a.M = M; a.K = K; a.N = N; a.w_transposed = wt ? 1 : 0;
+    a.prologue = IGAN_DENSE_PRO_NONE; a.epilogue = IGAN_DENSE_EPI_SCALE; a.alpha = alpha;
+    dense_small_launch(stream, a);
 }
 
 bool dense_small_wgrad_ok(int M, int N, const void* dy, const void* dw) {
@@ -123,8 +230,60 @@ bool dense_small_wgrad_ok(int M, int N, const void* dy, const void* dw) {
 }
 
 void dense_small_wgrad(hipStream_t stream, const float* x, const float* dy, float* dw, int M, int K, int N, float alpha) {
+    igan_dense_wgrad_params p = {};
+    p.a = x; p.lda = K; p.b = dy; p.dw = dw; p.M = M; p.K = K; p.N = N; p.alpha = alpha;
     const int total = K * (N >> 2);
-    hipLaunchKernelGGL(dense_small_wgrad_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, x, dy, dw, M, K, N, alpha);
+    hipLaunchKernelGGL(dense_small_wgrad_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, p);
 }
 
 }  // namespace igan
+
+extern "C" int igan_dense_small(igan_stream_t stream_, const igan_dense_params* p) {
+    using namespace igan;
+    IGAN_REQUIRE(p && p->x && p->w && p->y, "dense_small: null buffer");
+    IGAN_REQUIRE(p->M >= 1 && p->M <= 32, "dense_small: 1 <= M <= 32 rows (use igan_conv2d for larger batches)");
+    IGAN_REQUIRE(p->K >= 4 && p->K % 4 == 0 && p->N >= 1, "dense_small: K must be a positive multiple of 4, N positive");
+    IGAN_REQUIRE(p->ldx >= p->K && p->ldx % 4 == 0 && p->ldy >= p->N, "dense_small: bad row strides");
+    IGAN_REQUIRE((((uintptr_t)p->x) & 15) == 0 && (!p->w_transposed || (((uintptr_t)p->w) & 15) == 0), "dense_small: x (and a transposed w) must be 16-byte aligned");
+    IGAN_REQUIRE(p->prologue >= IGAN_DENSE_PRO_NONE && p->prologue <= IGAN_DENSE_PRO_DEMOD_GRAD, "dense_small: unknown prologue");
+    IGAN_REQUIRE(p->epilogue >= IGAN_DENSE_EPI_SCALE && p->epilogue <= IGAN_DENSE_EPI_STYLE_GRAD, "dense_small: unknown epilogue");
+    IGAN_REQUIRE(p->prologue != IGAN_DENSE_PRO_DEMOD_GRAD || (p->x2 && (((uintptr_t)p->x2) & 15) == 0), "dense_small: demod-gradient prologue needs an aligned x2");
+    IGAN_REQUIRE(p->epilogue != IGAN_DENSE_EPI_BIAS || p->bias, "dense_small: bias epilogue needs a bias");
+    IGAN_REQUIRE(p->epilogue != IGAN_DENSE_EPI_STYLE_GRAD || p->e2, "dense_small: style-gradient epilogue needs e2");
+    dense_small_launch((hipStream_t)stream_, *p);
+    IGAN_LAUNCH_CHECK("dense_small launch");
+    return IGAN_OK;
+}
+
+extern "C" int igan_dense_small_wgrad(igan_stream_t stream_, const igan_dense_wgrad_params* p) {
+    using namespace igan;
+    IGAN_REQUIRE(p && p->a && p->b && p->dw, "dense_small_wgrad: null buffer");
+    IGAN_REQUIRE(p->M >= 1 && p->M <= 32, "dense_small_wgrad: 1 <= M <= 32 rows");
+    IGAN_REQUIRE(p->K >= 1 && p->N >= 4 && p->N % 4 == 0 && p->lda >= p->K, "dense_small_wgrad: N must be a positive multiple of 4");
+    IGAN_REQUIRE(((((uintptr_t)p->b) | ((uintptr_t)p->dw)) & 15) == 0, "dense_small_wgrad: b and dw must be 16-byte aligned");
+    IGAN_REQUIRE(p->pro_a == IGAN_DENSE_PRO_NONE || p->pro_a == IGAN_DENSE_PRO_SQUARE, "dense_small_wgrad: unknown prologue for a");
+    IGAN_REQUIRE(p->pro_b == IGAN_DENSE_PRO_NONE || (p->pro_b == IGAN_DENSE_PRO_DEMOD_GRAD && p->b2 && (((uintptr_t)p->b2) & 15) == 0), "dense_small_wgrad: bad prologue for b");
+    IGAN_REQUIRE((long long)p->K * p->N <= INT32_MAX, "dense_small_wgrad: too large");
+    const int total = p->K * (p->N >> 2);
+    hipLaunchKernelGGL(dense_small_wgrad_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream_, *p);
+    IGAN_LAUNCH_CHECK("dense_small_wgrad launch");
+    return IGAN_OK;
+}
+
+extern "C" int igan_sumsq_taps(igan_stream_t stream_, const float* w, float* out, int taps, int n) {
+    using namespace igan;
+    IGAN_REQUIRE(w && out && taps >= 1 && n >= 4 && n % 4 == 0, "sumsq_taps: n must be a positive multiple of 4");
+    IGAN_REQUIRE(((((uintptr_t)w) | ((uintptr_t)out)) & 15) == 0, "sumsq_taps: buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(sumsq_taps_kernel, dim3(ceil_div(n / 4, 256)), dim3(256), 0, (hipStream_t)stream_, w, out, taps, n / 4);
+    IGAN_LAUNCH_CHECK("sumsq_taps launch");
+    return IGAN_OK;
+}
+
+extern "C" int igan_bcast_mul_taps(igan_stream_t stream_, const float* w, const float* v, float* out, int taps, int n, float scale) {
+    using namespace igan;
+    IGAN_REQUIRE(w && v && out && taps >= 1 && n >= 4 && n % 4 == 0, "bcast_mul_taps: n must be a positive multiple of 4");
+    IGAN_REQUIRE(((((uintptr_t)w) | ((uintptr_t)v) | ((uintptr_t)out)) & 15) == 0, "bcast_mul_taps: buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(bcast_mul_taps_kernel, dim3(ceil_div(n / 4, 256)), dim3(256), 0, (hipStream_t)stream_, w, v, out, taps, n / 4, scale);
+    IGAN_LAUNCH_CHECK("bcast_mul_taps launch");
+    return IGAN_OK;
+}

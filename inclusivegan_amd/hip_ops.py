@@ -22,6 +22,7 @@ All activations are fp32.  4-D activations are logical NCHW with
 ``torch.channels_last`` strides, i.e. physically [N, H, W, C].
 """
 import ctypes
+import os
 from collections import namedtuple
 
 import numpy as np
@@ -647,6 +648,180 @@ def modconv_composite(x, w, s, d, geom, out_hw):
     if d is not None:
         y = y * d[:, :, None, None]
     return y
+
+
+# ----------------------------------------------------------------------------
+# style path of modulated_conv2d_layer: s = A(w_lat) + b + 1, d = rsqrt(s^2 . sum_taps(w^2) + 1e-8)
+
+def _row_major(t):
+    """[M,K] with unit inner stride and a 4-float-aligned row stride (a dlatents[:, i] slice qualifies)."""
+    if t.dim() != 2 or t.stride(1) != 1 or t.stride(0) % 4 != 0 or t.stride(0) < t.shape[1] or t.data_ptr() % 16 != 0:
+        t = t.contiguous()
+    return t
+
+
+def dense_small_raw(x, w, w_transposed=False, alpha=1.0, prologue=_abi.DENSE_PRO_NONE, x2=None, pro_scale=0.0,
+                    epilogue=_abi.DENSE_EPI_SCALE, bias=None, bias_scale=1.0, add_const=0.0, eps=0.0, e1=None, e2=None,
+                    want_colsum=False):
+    """include/igan_hip.h igan_dense_small: y = epi(alpha * pro(x) . W), M <= 32 rows.  Returns y or (y, colsum)."""
+    lib = _abi.get_plugin()
+    _require_cuda_f32(x, w, x2, bias, e1, e2)
+    x = _row_major(x)
+    w = w.contiguous()
+    m, k = x.shape
+    n = w.shape[0] if w_transposed else w.shape[1]
+    y = torch.empty((m, n), device=x.device, dtype=torch.float32)
+    colsum = torch.empty((n,), device=x.device, dtype=torch.float32) if want_colsum else None
+    x2 = x2.contiguous() if x2 is not None else None
+    e1 = e1.contiguous() if e1 is not None else None
+    e2 = e2.contiguous() if e2 is not None else None
+    bias = bias.contiguous() if bias is not None else None
+    p = _abi.DenseParams(x=x.data_ptr(), x2=_ptr(x2), w=w.data_ptr(), y=y.data_ptr(), bias=_ptr(bias), e1=_ptr(e1), e2=_ptr(e2),
+                         colsum=_ptr(colsum), ldx=x.stride(0), ldy=n, M=m, K=k, N=n, w_transposed=1 if w_transposed else 0,
+                         prologue=prologue, epilogue=epilogue, alpha=float(alpha), pro_scale=float(pro_scale),
+                         bias_scale=float(bias_scale), add_const=float(add_const), eps=float(eps))
+    _abi.check(lib.igan_dense_small(_stream(), ctypes.byref(p)))
+    return (y, colsum) if want_colsum else y
+
+
+def dense_small_wgrad_raw(a, b, alpha=1.0, pro_a=_abi.DENSE_PRO_NONE, pro_b=_abi.DENSE_PRO_NONE, b2=None, pro_scale=0.0):
+    """dw[K,N] = alpha * pro_a(a)^T . pro_b(b)   (igan_dense_small_wgrad)."""
+    lib = _abi.get_plugin()
+    _require_cuda_f32(a, b, b2)
+    a = _row_major(a)
+    b = b.contiguous()
+    b2 = b2.contiguous() if b2 is not None else None
+    m, k = a.shape
+    n = b.shape[1]
+    dw = torch.empty((k, n), device=a.device, dtype=torch.float32)
+    p = _abi.DenseWgradParams(a=a.data_ptr(), b=b.data_ptr(), b2=_ptr(b2), dw=dw.data_ptr(), lda=a.stride(0), M=m, K=k, N=n,
+                              pro_a=pro_a, pro_b=pro_b, alpha=float(alpha), pro_scale=float(pro_scale))
+    _abi.check(lib.igan_dense_small_wgrad(_stream(), ctypes.byref(p)))
+    return dw
+
+
+def sumsq_taps_raw(w):
+    """[KH,KW,Cin,Cout] -> [Cin,Cout] sum over the taps of w^2."""
+    lib = _abi.get_plugin()
+    _require_cuda_f32(w)
+    w = w.contiguous()
+    out = torch.empty(tuple(w.shape[2:]), device=w.device, dtype=torch.float32)
+    _abi.check(lib.igan_sumsq_taps(_stream(), _ptr(w), _ptr(out), w.shape[0] * w.shape[1], out.numel()))
+    return out
+
+
+def bcast_mul_taps_raw(w, v, scale):
+    """scale * w[KH,KW,Cin,Cout] * v[Cin,Cout] (broadcast over the taps)."""
+    lib = _abi.get_plugin()
+    _require_cuda_f32(w, v)
+    w = w.contiguous()
+    v = v.contiguous()
+    out = torch.empty_like(w)
+    _abi.check(lib.igan_bcast_mul_taps(_stream(), _ptr(w), _ptr(v), _ptr(out), w.shape[0] * w.shape[1], v.numel(), float(scale)))
+    return out
+
+
+def style_mod_composite(y, a_w, a_b, w, c_a, c_w, demodulate):
+    """The same (s, d) from differentiable pieces (any order of differentiation; any sizes)."""
+    s = matmul(y, a_w, alpha=c_a) + a_b + 1.0
+    d = None
+    if demodulate:
+        wsq = (w * w).sum(dim=(0, 1))
+        d = torch.rsqrt(matmul(s * s, wsq, alpha=c_w * c_w) + 1e-8)
+    return s, d
+
+
+_STYLE_FUSION = os.environ.get('IGAN_STYLE_FUSION', '1') != '0'      # A/B switch for profiling
+_second_order_depth = 0
+
+
+class second_order:
+    """Context: the forward pass inside will be differentiated twice (path-length regulariser, loss.py:60-66).
+    Functions whose fused backward is first-order only take their differentiable composite form directly,
+    instead of recomputing it inside a create_graph backward."""
+
+    def __enter__(self):
+        global _second_order_depth
+        _second_order_depth += 1
+
+    def __exit__(self, *exc):
+        global _second_order_depth
+        _second_order_depth -= 1
+
+
+def style_mod_fusable(y, a_w, w, demodulate):
+    cin = a_w.shape[1]
+    ok = _STYLE_FUSION and y.is_cuda and y.dim() == 2 and y.shape[0] <= 32 and y.shape[1] % 4 == 0 and cin % 4 == 0
+    if demodulate:
+        ok = ok and w.shape[3] % 4 == 0
+    return ok
+
+
+class StyleModFn(torch.autograd.Function):
+    """(s, d) of modulated_conv2d_layer (networks_stylegan2.py:99-107) for a batch of at most 32 latents:
+        s = c_a * y . A + b + 1                      [N, Cin]
+        d = rsqrt(c_w^2 * (s^2 . wsq) + 1e-8)        [N, Cout],  wsq = sum_taps w^2 (passed in: cached per training op)
+    two launches forward; backward five (style gradient + bias gradient, d wsq, its spread onto the filter taps,
+    d latents, d A) instead of ~40 element-wise / GEMM launches.  When the backward has to be differentiated
+    itself (create_graph: path-length regulariser) it is taken through `style_mod_composite`."""
+
+    @staticmethod
+    def forward(ctx, y, a_w, a_b, w, wsq, c_a, c_w):
+        s = dense_small_raw(y, a_w, alpha=c_a, epilogue=_abi.DENSE_EPI_BIAS, bias=a_b, bias_scale=1.0, add_const=1.0)
+        d = None
+        if wsq is not None:
+            d = dense_small_raw(s, wsq, alpha=c_w * c_w, prologue=_abi.DENSE_PRO_SQUARE, epilogue=_abi.DENSE_EPI_RSQRT, eps=1e-8)
+        ctx.save_for_backward(y, a_w, a_b, w, wsq, s, d)
+        ctx.c_a, ctx.c_w = c_a, c_w
+        if d is None:
+            return s
+        return s, d
+
+    @staticmethod
+    def backward(ctx, gs, gd=None):
+        y, a_w, a_b, w, wsq, s, d = ctx.saved_tensors
+        c_a, c_w = ctx.c_a, ctx.c_w
+        need = [_needed(ctx, i) for i in range(4)]
+        if torch.is_grad_enabled():
+            with torch.enable_grad():
+                sc, dc = style_mod_composite(y, a_w, a_b, w, c_a, c_w, d is not None)
+                outs, gouts = [sc], [gs if gs is not None else torch.zeros_like(sc)]
+                if dc is not None and gd is not None:
+                    outs.append(dc); gouts.append(gd)
+                inputs = [t for t, nd in zip((y, a_w, a_b, w), need) if nd]
+                grads = list(torch.autograd.grad(outs, inputs, gouts, create_graph=True, allow_unused=True)) if inputs else []
+            res = [grads.pop(0) if nd else None for nd in need]
+            return res[0], res[1], res[2], res[3], None, None, None
+        dy = da_w = da_b = dw = None
+        if d is not None and gd is not None:
+            ps = -0.5 * c_w * c_w
+            ds, da_b = dense_small_raw(gd, wsq, w_transposed=True, prologue=_abi.DENSE_PRO_DEMOD_GRAD, x2=d, pro_scale=ps,
+                                       epilogue=_abi.DENSE_EPI_STYLE_GRAD, e1=gs, e2=s, bias_scale=1.0, want_colsum=True)
+            if need[3]:
+                dwsq = dense_small_wgrad_raw(s, gd, pro_a=_abi.DENSE_PRO_SQUARE, pro_b=_abi.DENSE_PRO_DEMOD_GRAD, b2=d, pro_scale=ps)
+                dw = bcast_mul_taps_raw(w, dwsq, 2.0)
+        else:
+            ds = gs
+            da_b = gs.sum(dim=0) if need[2] else None
+        if not need[2]:
+            da_b = None
+        if need[0]:
+            dy = dense_small_raw(ds, a_w, w_transposed=True, alpha=c_a)
+        if need[1]:
+            da_w = dense_small_wgrad_raw(y, ds, alpha=c_a)
+        return dy, da_w, da_b, dw, None, None, None
+
+
+def style_mod(y, a_w, a_b, w, wsq, c_a, c_w, demodulate):
+    """Dispatch: fused kernels when the sizes allow, the differentiable composite otherwise."""
+    if _is_meta(y):
+        s = torch.empty((y.shape[0], a_w.shape[1]), device='meta')
+        return s, (torch.empty((y.shape[0], w.shape[3]), device='meta') if demodulate else None)
+    if _second_order_depth > 0 or not style_mod_fusable(y, a_w, w, demodulate):
+        return style_mod_composite(y, a_w, a_b, w, c_a, c_w, demodulate)
+    if demodulate:
+        return StyleModFn.apply(y, a_w, a_b, w, wsq, c_a, c_w)
+    return StyleModFn.apply(y, a_w, a_b, w, None, c_a, c_w), None
 
 
 # ----------------------------------------------------------------------------

@@ -16,6 +16,7 @@ import torch.nn.functional as F
 from ..dnnlib import tflib
 from ..dnnlib.tflib import tfutil
 from ..dnnlib.tflib.autosummary import autosummary
+from .. import hip_ops
 from ..metrics import lpips as lpips_mod
 
 #----------------------------------------------------------------------------
@@ -89,7 +90,8 @@ def _G_loss_impl(G, D, lpips, training_set, minibatch_size, reals_rec_1, labels_
         pl_minibatch = minibatch_size // pl_minibatch_shrink
         pl_latents = tfutil.random_normal([pl_minibatch] + latent_shape, dev)
         pl_labels = training_set.get_random_labels_tf(pl_minibatch)
-        fake_images_out, fake_dlatents_out = G.get_output_for(pl_latents, pl_labels, is_training=True, return_dlatents=True)
+        with hip_ops.second_order():      # pl_grads below is itself differentiated
+            fake_images_out, fake_dlatents_out = G.get_output_for(pl_latents, pl_labels, is_training=True, return_dlatents=True)
 
         # Compute |J*y|.
         pl_noise = tfutil.random_normal(fake_images_out.shape, dev) / np.sqrt(np.prod(G.output_shape[2:]))

@@ -99,15 +99,17 @@ def modulated_conv2d_layer(x, y, fmaps, kernel, up=False, down=False, demodulate
     cin = int(x.shape[1])
     w, coef = get_weight([kernel, kernel, cin, fmaps], gain=gain, use_wscale=use_wscale, lrmul=lrmul, weight_var=weight_var, init_mul=init_mul)
 
-    # Modulate.
-    s = dense_layer(y, fmaps=cin, weight_var=mod_weight_var, init_mul=init_mul) # [BI] Transform incoming W to style.
-    s = apply_bias_act(s, bias_var=mod_bias_var) + 1 # [BI] Add bias (initially 1).
-
-    # Demodulate: d[b,o] = rsqrt(sum_{k,k,i} (w*s)^2 + 1e-8) = rsqrt((s^2) @ (sum_kk w^2) + 1e-8).
-    d = None
-    if demodulate:
-        wsq = tfutil.derived(weight_var + ':sumsq', lambda: (w * w).sum(dim=(0, 1)))   # [I,O], of the raw weights
-        d = torch.rsqrt(hip_ops.matmul(s * s, wsq, alpha=coef * coef) + 1e-8) # [BO]
+    # Modulate: s = A(y) + b + 1 (:99-101); demodulate: d[b,o] = rsqrt(sum_{k,k,i} (w*s)^2 + 1e-8)
+    # = rsqrt((s^2) @ (sum_kk w^2) + 1e-8) (:105-107) -- both in hip_ops.style_mod (two launches).
+    a_w, a_coef = get_weight([int(y.shape[1]), cin], weight_var=mod_weight_var, init_mul=init_mul)
+    a_b = get_variable(mod_bias_var, shape=[cin], initializer=('zeros',))
+    wsq = None
+    if demodulate and not hip_ops._is_meta(y) and hip_ops.style_mod_fusable(y, a_w, w, True):
+        def _sumsq():
+            with torch.no_grad():
+                return hip_ops.sumsq_taps_raw(w)                   # [I,O] of the raw weights, once per training op
+        wsq = tfutil.derived(weight_var + ':sumsq', _sumsq)
+    s, d = hip_ops.style_mod(y, a_w, a_b, w, wsq, a_coef, coef, demodulate)
 
     # Convolution with optional up/downsampling; scales folded into the kernel.
     H, W = int(x.shape[2]), int(x.shape[3])
@@ -317,6 +319,9 @@ def G_synthesis_stylegan2(
     assert tuple(dlatents_in.shape[1:]) == (num_layers, dlatent_size)
     dev = dlatents_in.device
     batch = int(dlatents_in.shape[0])
+    # One unbind (backward: one stack of the per-layer gradients) instead of a select per use, whose
+    # backward is a zero-filled [N, layers, 512] tensor and an add each.
+    dlatents_in = dlatents_in.unbind(dim=1)
 
     # Noise inputs (:342-346).
     noise_inputs = []
@@ -327,7 +332,7 @@ def G_synthesis_stylegan2(
 
     # Single convolution layer with all the bells and whistles (:349-357).
     def layer(x, layer_idx, fmaps, kernel, up=False):
-        x = modulated_conv2d_layer(x, dlatents_in[:, layer_idx], fmaps=fmaps, kernel=kernel, up=up, resample_kernel=resample_kernel, fused_modconv=fused_modconv, init_mul=init_mul)
+        x = modulated_conv2d_layer(x, dlatents_in[layer_idx], fmaps=fmaps, kernel=kernel, up=up, resample_kernel=resample_kernel, fused_modconv=fused_modconv, init_mul=init_mul)
         if randomize_noise:
             noise = tfutil.random_normal([batch, 1, int(x.shape[2]), int(x.shape[3])], dev)
         else:
@@ -353,7 +358,7 @@ def G_synthesis_stylegan2(
             return upsample_2d(y, k=resample_kernel)
     def torgb(x, y, res): # res = 2..resolution_log2
         with variable_scope('ToRGB'):
-            t = apply_bias_act(modulated_conv2d_layer(x, dlatents_in[:, res*2-3], fmaps=num_channels, kernel=1, demodulate=False, fused_modconv=fused_modconv, init_mul=init_mul))
+            t = apply_bias_act(modulated_conv2d_layer(x, dlatents_in[res*2-3], fmaps=num_channels, kernel=1, demodulate=False, fused_modconv=fused_modconv, init_mul=init_mul))
             return t if y is None else y + t
 
     # Early layers (:380-388).

@@ -322,6 +322,63 @@ def test_modconv_fused_scales(mode, demod, cuda_device):
         assert rel_err(c, b) < 5e-5
 
 
+# ----------------------------------------------------------------------------- style path (s, d)
+@pytest.mark.parametrize('case', [(24, 512, 512, 512, 3, True), (3, 512, 256, 128, 3, True), (6, 512, 128, 3, 1, False),
+                                  (32, 64, 36, 20, 3, True), (12, 512, 512, 256, 3, True)])
+def test_style_mod_fused_vs_oracle(case, cuda_device):
+    """s = c_a y.A + b + 1, d = rsqrt(c_w^2 s^2.sum_taps(w^2) + 1e-8) (networks_stylegan2.py:99-107): fused kernels vs
+    an fp64 evaluation, forward, first-order gradients of all four inputs, and a second-order check through the
+    differentiable backward (create_graph)."""
+    from inclusivegan_amd import hip_ops
+    N, L, Cin, Cout, K, demod = case
+    rng = np.random.RandomState(N + Cin)
+    y = rng.randn(N, 3, L)[:, 1]                      # a strided [N, L] slice like dlatents[:, i]
+    A = rng.randn(L, Cin); b = rng.randn(Cin) * 0.1; w = rng.randn(K, K, Cin, Cout)
+    c_a, c_w = 1.0 / np.sqrt(L), 1.0 / np.sqrt(K * K * Cin)
+    gs = rng.randn(N, Cin); gd = rng.randn(N, Cout)
+
+    def oracle(y, A, b, w):
+        s = c_a * (y @ A) + b + 1.0
+        d = torch.rsqrt(c_w * c_w * ((s * s) @ (w * w).sum(dim=(0, 1))) + 1e-8) if demod else None
+        return s, d
+
+    to = [torch.from_numpy(np.ascontiguousarray(t)).requires_grad_(True) for t in (y, A, b, w)]
+    so, do = oracle(*to)
+    yfull = torch.from_numpy(rng.randn(N, 3, L)).float().to(cuda_device)
+    yfull[:, 1] = torch.from_numpy(y).float().to(cuda_device)
+    yg = yfull.requires_grad_(True)
+    tg = [torch.from_numpy(np.ascontiguousarray(t)).float().to(cuda_device).requires_grad_(True) for t in (A, b, w)]
+    wsq = hip_ops.sumsq_taps_raw(tg[2].detach()) if demod else None
+    assert hip_ops.style_mod_fusable(yg[:, 1], tg[0], tg[2], demod)
+    sg, dg = hip_ops.style_mod(yg.unbind(1)[1], tg[0], tg[1], tg[2], wsq, c_a, c_w, demod)
+    assert rel_err(sg, so) < 1e-5
+    outs_o, outs_g = [so], [sg]
+    go, gg = [torch.from_numpy(gs)], [torch.from_numpy(gs).float().to(cuda_device)]
+    if demod:
+        assert rel_err(dg, do) < 1e-5
+        outs_o.append(do); outs_g.append(dg)
+        go.append(torch.from_numpy(gd)); gg.append(torch.from_numpy(gd).float().to(cuda_device))
+    ins_o = to if demod else to[:3]
+    ins_g = [yg] + (tg if demod else tg[:2])
+    grads_o = torch.autograd.grad(outs_o, ins_o, go, create_graph=True)
+    grads_g = torch.autograd.grad(outs_g, ins_g, gg, retain_graph=True)
+    assert rel_err(grads_g[0][:, 1], grads_o[0]) < 2e-5
+    assert float(grads_g[0][:, 0].abs().max()) == 0.0
+    for a_, b_ in zip(grads_g[1:], grads_o[1:]):
+        assert rel_err(a_, b_) < 2e-5
+    # second order: gradient of |d out / d y|^2 w.r.t. everything (the path-length regulariser's shape)
+    g2 = torch.autograd.grad(outs_g, ins_g, gg, create_graph=True)
+    pen_g = (g2[0] * g2[0]).sum()
+    pen_o = (grads_o[0] * grads_o[0]).sum()
+    h_g = torch.autograd.grad(pen_g, ins_g, allow_unused=True)      # without demodulation s is linear: some are unused
+    h_o = torch.autograd.grad(pen_o, ins_o, allow_unused=True)
+    for i, (a_, b_) in enumerate(zip(h_g, h_o)):
+        if b_ is None or float(b_.abs().max()) == 0.0:
+            assert a_ is None or float(a_.abs().max()) < 1e-6
+            continue
+        assert rel_err(a_[:, 1] if i == 0 else a_, b_) < 1e-4
+
+
 # ----------------------------------------------------------------------------- minibatch stddev
 @pytest.mark.parametrize('N,G', [(6, 6), (12, 6), (4, 6), (8, 4)])
 def test_mbstd(N, G, cuda_device):
