@@ -140,10 +140,11 @@ int igan_bias_act_noise_bwd(igan_stream_t stream, const float* dy, const float* 
  * implement StyleGAN2 modulation / demodulation in the non-fused form of
  * networks_stylegan2.py:112,126.
  *
- * Split-K: when splits > 1 the reduction axis (taps x Cin) is cut into `splits`
- * slices whose partial tiles go to `workspace` ([splits][N*OH*OW][Cout] floats)
- * and are summed in fixed order by a second kernel (bit-reproducible).
- * igan_conv2d_plan() suggests `splits` and the workspace size for a shape.
+ * Tail slicing: the output is a list of tiles dealt to the CUs; when the list does not fill a whole number
+ * of rounds, the last `sliced_tiles` tiles are cut into `splits` slices along the reduction axis (taps x Cin)
+ * so that the last round occupies every CU.  Their partial tiles go to `workspace` (tile-compact,
+ * sliced_tiles * splits tiles) and a fix-up kernel sums them in fixed order (bit-reproducible).
+ * igan_conv2d_plan() chooses `splits`, `sliced_tiles` and the workspace size for a shape; pass them back.
  */
 typedef struct igan_conv2d_params {
     const float* x;         /* [N, H, W, Cin] */
@@ -159,12 +160,13 @@ typedef struct igan_conv2d_params {
     int stride, up;
     int pad_y, pad_x;
     int w_transposed;
-    int splits;
+    int splits;             /* reduction slices of each sliced tile (from igan_conv2d_plan; 1 = none) */
+    int sliced_tiles;       /* how many trailing tiles of the tile list are sliced (from igan_conv2d_plan) */
     float alpha;            /* y is multiplied by alpha (the layers' runtime weight scale, networks_stylegan2.py:30-36,
                              * rides here instead of in a separate w * coef pass); 1.0f for a plain convolution */
 } igan_conv2d_params;
 
-int igan_conv2d_plan(const igan_conv2d_params* p, int* splits, size_t* workspace_floats);
+int igan_conv2d_plan(const igan_conv2d_params* p, int* splits, int* sliced_tiles, size_t* workspace_floats);
 int igan_conv2d(igan_stream_t stream, const igan_conv2d_params* p);
 /* Host-only: name of the kernel instantiation igan_conv2d() launches for these parameters (as reported
  * by rocprofv3, minus the anonymous-namespace prefix).  For profiling tools. */

@@ -55,7 +55,7 @@ class Conv2DParams(ctypes.Structure):
         ('KH', ctypes.c_int), ('KW', ctypes.c_int),
         ('stride', ctypes.c_int), ('up', ctypes.c_int),
         ('pad_y', ctypes.c_int), ('pad_x', ctypes.c_int),
-        ('w_transposed', ctypes.c_int), ('splits', ctypes.c_int), ('alpha', ctypes.c_float),
+        ('w_transposed', ctypes.c_int), ('splits', ctypes.c_int), ('sliced_tiles', ctypes.c_int), ('alpha', ctypes.c_float),
     ]
 
     def __init__(self, *args, **kwargs):
@@ -120,7 +120,7 @@ SIGNATURES = {
     'igan_bias_act_noise_workspace_floats': (_SZ, [_I, _I]),
     'igan_bias_act_noise_fwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F]),
     'igan_bias_act_noise_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F]),
-    'igan_conv2d_plan': (_I, [ctypes.POINTER(Conv2DParams), ctypes.POINTER(_I), ctypes.POINTER(_SZ)]),
+    'igan_conv2d_plan': (_I, [ctypes.POINTER(Conv2DParams), ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_SZ)]),
     'igan_conv2d': (_I, [_P, ctypes.POINTER(Conv2DParams)]),
     'igan_conv2d_kernel_name': (_I, [ctypes.POINTER(Conv2DParams), ctypes.c_char_p, _I]),
     'igan_conv2d_wgrad_plan': (_I, [ctypes.POINTER(Conv2DWgradParams), ctypes.POINTER(_I), ctypes.POINTER(_SZ)]),

@@ -31,9 +31,12 @@
 //  * StyleGAN2 modulation / demodulation ride along as per-(sample,channel)
 //    scales on the A-operand load and in the epilogue (non-fused modconv form,
 //    networks_stylegan2.py:112,126), so x*s and y*d never round-trip HBM;
-//  * small-M layers (4x4 .. 16x16, dense) are split along the reduction axis
-//    across workgroups; partial tiles go to a caller-owned workspace and a second
-//    kernel adds them in fixed order (bit-reproducible, no float atomics).
+//  * the grid is a 1-D list of tiles dealt round-robin to the 256 CUs (two resident per CU).  A layer
+//    of T tiles leaves T mod 256 tiles for a last, partly empty round (all of them, for the small
+//    4x4 .. 16x16 layers): only those tail tiles are cut along the reduction axis so that the tail
+//    occupies every CU.  Their partial tiles go to a caller-owned tile-compact workspace and a fix-up
+//    kernel adds them in fixed order (bit-reproducible, no float atomics) -- the fix-up traffic is that
+//    of the tail tiles only, not of the whole output.
 #include "igan_common.h"
 #include <cmath>
 
@@ -47,7 +50,8 @@ constexpr int LDK = BK + 4;   // row pitch of a [rows][k] LDS image (144 B: 16 B
 struct ConvArgs {
     const float* x;
     const float* w;
-    float* y;          // final output (splits == 1) or workspace (splits > 1)
+    float* y;          // workspace of the sliced tail tiles (splits > 1), else unused
+    float* out;        // final output
     const float* in_scale;
     const float* out_scale;
     int N, H, W, Cin;
@@ -55,7 +59,9 @@ struct ConvArgs {
     int KH, KW;
     int stride, up_shift;   // up == 1 << up_shift
     int pad_y, pad_x;
-    int splits;
+    int splits;             // reduction slices of each TAIL tile (1 = no workspace)
+    int full_tiles;         // leading tiles computed whole; tiles >= full_tiles are sliced
+    int nx, ny;             // m tiles (largest class) and n tiles; tile id = (cls * ny + nt) * nx + mt
     int cpt;                // chunks per tap = ceil(Cin / 32)
     int Mtot;               // N*OH*OW
     int vecA, vecB, vecS;   // 16 B paths usable for x rows / w rows / in_scale rows
@@ -196,15 +202,21 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
     const int wm = wave / WN, wn = wave % WN;
 
     const int up = 1 << a.up_shift;
-    const int cls = blockIdx.z / a.splits;
-    const int split = blockIdx.z - cls * a.splits;
+    // block -> (tile, reduction slice): whole tiles first, then the sliced tail
+    const int bid = blockIdx.x;
+    const bool sliced = bid >= a.full_tiles;
+    const int tail = bid - a.full_tiles;
+    const int tile = sliced ? a.full_tiles + tail / a.splits : bid;
+    const int split = sliced ? tail % a.splits : 0;
+    const int nsplit = sliced ? a.splits : 1;
+    const int mt = tile % a.nx, nt = (tile / a.nx) % a.ny, cls = tile / (a.nx * a.ny);
     const int py = cls >> a.up_shift, px = cls & (up - 1);
     const int QH = (a.OH - py + up - 1) >> a.up_shift;
     const int QW = (a.OW - px + up - 1) >> a.up_shift;
     const int Mcls = a.N * QH * QW;
-    const int m0 = blockIdx.x * BM;
+    const int m0 = mt * BM;
     if (m0 >= Mcls) return;  // uniform: smaller classes have fewer tiles
-    const int n0 = blockIdx.y * BN;
+    const int n0 = nt * BN;
 
     // taps of this class: ky = ky0 + up*i  (all taps when up == 1)
     int ky0 = (a.pad_y - py * a.stride) & (up - 1);
@@ -212,8 +224,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
     const int nky = (ky0 < a.KH) ? ((a.KH - ky0 + up - 1) >> a.up_shift) : 0;
     const int nkx = (kx0 < a.KW) ? ((a.KW - kx0 + up - 1) >> a.up_shift) : 0;
     const int chunks = nky * nkx * a.cpt;
-    const int c_begin = (int)(((long long)split * chunks) / a.splits);
-    const int c_end = (int)(((long long)(split + 1) * chunks) / a.splits);
+    const int c_begin = (int)(((long long)split * chunks) / nsplit);
+    const int c_end = (int)(((long long)(split + 1) * chunks) / nsplit);
 
     // ---- per-row bookkeeping ----
     if (tid < BM) {
@@ -366,9 +378,27 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
     }
 
     // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*h; tile -> column via tile_row ----
-    float* out = a.y + (a.splits > 1 ? (size_t)split * a.Mtot * a.Cout : (size_t)0);
-    const bool scale = (a.out_scale != nullptr) && (a.splits == 1);
-    const float alpha = (a.splits == 1) ? a.alpha : 1.0f;
+    if (sliced && nsplit > 1) {
+        // partial tile, raw, into its [BM][BN] slot of the workspace (a.y): slot = tail tile * splits + slice
+        float* wst = a.y + ((size_t)(tile - a.full_tiles) * a.splits + split) * (BM * BN);
+#pragma unroll
+        for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = wm * (BM / WM) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                float* wr = wst + row * BN + wn * (BN / WN);
+                if constexpr (!WT && TN == 2) {
+                    *reinterpret_cast<float2*>(wr + 2 * l31) = make_float2(acc[tm][0][r], acc[tm][1][r]);
+                } else {
+#pragma unroll
+                    for (int tn = 0; tn < TN; tn++) wr[tile_row<TN, !WT>(tn, l31)] = acc[tm][tn][r];
+                }
+            }
+        return;
+    }
+    float* out = a.out;
+    const bool scale = a.out_scale != nullptr;
+    const float alpha = a.alpha;
     const int cbase = n0 + wn * (BN / WN);
 #pragma unroll
     for (int tm = 0; tm < TM; tm++) {
@@ -405,19 +435,59 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
     }
 }
 
-// y[i] = alpha * out_scale * sum_s ws[s][i]   (fixed order)
-__global__ __launch_bounds__(256) void conv_reduce_kernel(const float* ws, float* y, const float* out_scale,
-                                                          int total, int splits, int Cout, int pix_per_n, float alpha) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int k = 0; k < splits; k++) s += ws[(size_t)k * total + i];
-        s *= alpha;
-        if (out_scale) {
-            const int pix = i / Cout;
-            const int co = i - pix * Cout;
-            s *= out_scale[(pix / pix_per_n) * Cout + co];
+// Fix-up of the sliced tail tiles: y[tile] = alpha * out_scale * sum_slices ws[tile][slice]  (fixed order).
+// grid = (tail tiles, row groups of RP rows); the partial tiles are dense [BM][BN] images, rows map to
+// output pixels exactly as in the main kernel.
+__global__ __launch_bounds__(256) void conv_fixup_kernel(ConvArgs a, int BM, int BN, int RP) {
+    __shared__ int row_pix[128];
+    __shared__ int row_n[128];
+    const int tid = threadIdx.x;
+    const int up = 1 << a.up_shift;
+    const int tile = a.full_tiles + blockIdx.x;
+    const int mt = tile % a.nx, nt = (tile / a.nx) % a.ny, cls = tile / (a.nx * a.ny);
+    const int py = cls >> a.up_shift, px = cls & (up - 1);
+    const int QH = (a.OH - py + up - 1) >> a.up_shift;
+    const int QW = (a.OW - px + up - 1) >> a.up_shift;
+    const int Mcls = a.N * QH * QW;
+    const int r0 = blockIdx.y * RP;
+    const int m0 = mt * BM, n0 = nt * BN;
+    if (m0 + r0 >= Mcls) return;
+    if (tid < RP) {
+        const int m = m0 + r0 + tid;
+        int pix = -1, nn = 0;
+        if (r0 + tid < BM && m < Mcls) {      // the last row group may overhang the tile
+            nn = m / (QH * QW);
+            const int r = m - nn * (QH * QW);
+            const int qy = r / QW, qx = r - qy * QW;
+            pix = (nn * a.OH + (qy * up + py)) * a.OW + (qx * up + px);
         }
-        y[i] = s;
+        row_pix[tid] = pix;
+        row_n[tid] = nn;
+    }
+    __syncthreads();
+    const float* wst = a.y + (size_t)blockIdx.x * a.splits * (BM * BN);
+    const int bn4 = BN >> 2;
+    for (int i = tid; i < RP * bn4; i += 256) {
+        const int rl = i / bn4, c4 = i - rl * bn4;
+        const int pix = row_pix[rl];
+        if (pix < 0) continue;
+        const int row = r0 + rl;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < a.splits; k++) {
+            const float4 v = *reinterpret_cast<const float4*>(wst + (size_t)k * (BM * BN) + row * BN + 4 * c4);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        const float v4[4] = {s.x, s.y, s.z, s.w};
+        const int nn = row_n[rl];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int co = n0 + 4 * c4 + e;
+            if (co < a.Cout) {
+                float v = v4[e] * a.alpha;
+                if (a.out_scale) v *= a.out_scale[nn * a.Cout + co];
+                a.out[(size_t)pix * a.Cout + co] = v;
+            }
+        }
     }
 }
 
@@ -751,34 +821,75 @@ void launch_fwd(hipStream_t stream, const ConvArgs& a, dim3 grid, bool wt, bool 
 
 }  // namespace
 
-extern "C" int igan_conv2d_plan(const igan_conv2d_params* p, int* splits, size_t* workspace_floats) {
-    IGAN_REQUIRE(p && splits && workspace_floats, "conv2d_plan: null argument");
+namespace {
+
+// CUs of the device: tiles are dealt to CUs round-robin, two resident per CU (LDS / VGPR).
+int device_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int n = 256, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            n = prop.multiProcessorCount;
+        (void)hipGetLastError();      // a build box without a device must not leave a sticky error behind
+        cus = n;
+    }
+    return cus;
+}
+
+// Tile list of a forward-type launch: T tiles, of which the last `rem` (the partial round) may be sliced.
+struct TileList { int nx, ny, T, rem; };
+TileList tile_list(const igan_conv2d_params* p, const FwdTile& t, int Mmax, int nclass) {
+    TileList l;
+    l.nx = igan::ceil_div(Mmax, t.BM);
+    l.ny = igan::ceil_div(p->Cout, t.BN);
+    l.T = l.nx * l.ny * nclass;
+    l.rem = l.T % device_cus();
+    return l;
+}
+
+}  // namespace
+
+extern "C" int igan_conv2d_plan(const igan_conv2d_params* p, int* splits, int* sliced_tiles, size_t* workspace_floats) {
+    IGAN_REQUIRE(p && splits && sliced_tiles && workspace_floats, "conv2d_plan: null argument");
     if (int rc = fwd_geometry_check(p)) return rc;
-    if (is_small_dense(p)) { *splits = 1; *workspace_floats = 0; return IGAN_OK; }
+    *splits = 1;
+    *sliced_tiles = 0;
+    *workspace_floats = 0;
+    if (is_small_dense(p)) return IGAN_OK;
     int Mmax, chunks_max, nclass;
     fwd_counts(p, Mmax, chunks_max, nclass);
     const FwdTile t = pick_fwd_tile(Mmax, p->Cout);
-    const long long blocks = (long long)igan::ceil_div(Mmax, t.BM) * igan::ceil_div(p->Cout, t.BN) * nclass;
-    // Split-K choice by a small cost model.  The kernel keeps 2 workgroups per CU resident = 512 slots;
-    // a grid of T tiles takes ceil(T*s/512)/s "tile times" when every tile is cut into s slices, so a
-    // 768-tile layer (1.5 rounds -> 2 tile times) runs in 1.5 with s = 2 and a 384-tile layer (0.75 of
-    // a round -> 1 tile time) in 0.75 with s = 4.  Against that stands the partial-sum traffic
-    // ((2s+1) x output bytes through HBM) of the fixed-order reduce.
-    const double slots = 512.0;
-    const double chunk_s = 4.6e-6 * (t.BM == 128 ? 1.0 : 0.4) * (t.BN / 128.0 > 0.5 ? 1.0 : 0.5);   // one chunk, 2 co-resident workgroups
-    const double out_bytes = 4.0 * p->N * p->OH * p->OW * p->Cout;
+    const TileList l = tile_list(p, t, Mmax, nclass);
+    if (l.rem == 0) return IGAN_OK;           // whole rounds: nothing to gain
+    // Which trailing tiles to slice, and how finely, by a small cost model (measured on the 128x128 tile):
+    // two co-resident workgroups finish a chunk each in 4.4 us, a lone one in 3.3 us (the matrix pipe is
+    // per SIMD, so a pair is only 1.5x as efficient as a single).  A CU that holds n blocks of a tile's
+    // work each therefore needs  pairs(n) = (n/2) * t2 + (n%2) * t1.  Slicing the partial round plus k whole
+    // rounds (k = 0: the tail only) s ways leaves F = T - rem - k*CUs whole tiles and puts
+    // ceil((T-F)*s/CUs) slices of 1/s tile on the busiest CU.  Against the gain stands the partial-tile
+    // traffic of the fix-up ((2s+1) x the sliced tiles' bytes through HBM) and its launch.
+    const int cus = device_cus();
+    const double shape = (t.BM == 128 ? 1.0 : 0.4) * (t.BN / 128.0 > 0.5 ? 1.0 : 0.5);
+    const double t2 = chunks_max * 4.4e-6 * shape, t1 = chunks_max * 3.3e-6 * shape;
+    auto pairs = [&](int n) { return (n / 2) * t2 + (n % 2) * t1; };
     const double bw = 4.0e12;
-    const int cand[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
-    int s = 1;
-    double best = 1e30;
-    for (int c : cand) {
-        if (c > 1 && c > std::max(1, chunks_max / 2)) break;
-        const double rounds = std::ceil((double)blocks * c / slots) / c;
-        double tt = rounds * chunks_max * chunk_s + (c > 1 ? (2.0 * c + 1.0) * out_bytes / bw + 4e-6 : 0.0);
-        if (tt < best * 0.90) { best = tt; s = c; }   // prefer fewer slices unless clearly (>10 %) better
+    const int cand[] = {2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 32, 48, 64};
+    int best_s = 1, best_sl = 0;
+    double best = pairs(l.T / cus + 1);       // unsliced: the busiest CU has one tile of the partial round
+    for (int k = 0; k <= std::min(l.T / cus, 3); k++) {
+        const int sl = l.rem + k * cus;       // sliced tiles
+        const int whole = (l.T - sl) / cus;   // whole tiles per CU
+        for (int c : cand) {
+            if (c > std::max(1, chunks_max / 2)) break;
+            const double tt = pairs(whole) + pairs(igan::ceil_div(sl * c, cus)) / c +
+                              (2.0 * c + 1.0) * 4.0 * sl * t.BM * t.BN / bw + 3e-6;
+            if (tt < best * 0.95) { best = tt; best_s = c; best_sl = sl; }   // prefer less slicing unless clearly (>5 %) better
+        }
     }
-    *splits = s;
-    *workspace_floats = (s > 1) ? (size_t)s * p->N * p->OH * p->OW * p->Cout : 0;
+    *splits = best_s;
+    *sliced_tiles = best_sl;
+    *workspace_floats = (best_s > 1) ? (size_t)best_sl * best_s * t.BM * t.BN : 0;
     return IGAN_OK;
 }
 
@@ -817,20 +928,23 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
         IGAN_LAUNCH_CHECK("conv2d dense launch");
         return IGAN_OK;
     }
-    const int splits = std::max(1, p->splits);
-    const size_t out_elems = (size_t)p->N * p->OH * p->OW * p->Cout;
-    if (splits > 1) {
-        IGAN_REQUIRE(p->workspace != nullptr, "conv2d: splits > 1 needs a workspace");
-        IGAN_REQUIRE(p->workspace_floats >= (size_t)splits * out_elems, "conv2d: workspace too small");
-        IGAN_REQUIRE((long long)splits * (long long)out_elems <= INT32_MAX, "conv2d: split workspace too large");
-    }
     int Mmax, chunks_max, nclass;
     fwd_counts(p, Mmax, chunks_max, nclass);
     const FwdTile t = pick_fwd_tile(Mmax, p->Cout);
+    const TileList l = tile_list(p, t, Mmax, nclass);
+    int splits = std::max(1, p->splits);
+    const int sliced = std::min(std::max(p->sliced_tiles, 0), l.T);   // trailing tiles cut along the reduction axis
+    if (sliced == 0) splits = 1;
+    if (splits > 1) {
+        IGAN_REQUIRE(p->workspace != nullptr, "conv2d: splits > 1 needs a workspace");
+        IGAN_REQUIRE(p->workspace_floats >= (size_t)sliced * splits * t.BM * t.BN, "conv2d: workspace too small");
+        IGAN_REQUIRE((((uintptr_t)p->workspace) & 15) == 0, "conv2d: workspace must be 16-byte aligned");
+    }
 
     ConvArgs a;
     a.x = p->x; a.w = p->w;
-    a.y = (splits > 1) ? p->workspace : p->y;
+    a.y = (splits > 1) ? p->workspace : nullptr;
+    a.out = p->y;
     a.in_scale = p->in_scale; a.out_scale = p->out_scale;
     a.N = p->N; a.H = p->H; a.W = p->W; a.Cin = p->Cin;
     a.OH = p->OH; a.OW = p->OW; a.Cout = p->Cout;
@@ -838,16 +952,18 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
     a.stride = p->stride; a.up_shift = (p->up == 2) ? 1 : 0;
     a.pad_y = p->pad_y; a.pad_x = p->pad_x;
     a.splits = splits;
+    a.nx = l.nx; a.ny = l.ny;
+    a.full_tiles = (splits > 1) ? l.T - sliced : l.T;
     a.cpt = ceil_div(p->Cin, BK);
     a.Mtot = p->N * p->OH * p->OW;
     a.vecA = (p->Cin % 4 == 0) && (((uintptr_t)p->x & 15) == 0);
     a.vecS = (p->Cin % 4 == 0) && (((uintptr_t)p->in_scale & 15) == 0);
     if (p->w_transposed) a.vecB = (p->Cin % 4 == 0) && (((uintptr_t)p->w & 15) == 0);
     else a.vecB = (p->Cout % 4 == 0) && (((uintptr_t)p->w & 15) == 0);
-    a.vecY = (p->Cout % 2 == 0) && ((((uintptr_t)a.y | (uintptr_t)p->out_scale) & 7) == 0);
+    a.vecY = (p->Cout % 2 == 0) && ((((uintptr_t)p->y | (uintptr_t)p->out_scale) & 7) == 0);
     a.alpha = p->alpha;
 
-    dim3 grid(ceil_div(Mmax, t.BM), ceil_div(p->Cout, t.BN), nclass * splits);
+    dim3 grid(a.full_tiles + (l.T - a.full_tiles) * splits);
     const bool wt = p->w_transposed != 0;
     const bool vec = a.vecA && a.vecB && (a.in_scale == nullptr || a.vecS);
     if (t.BM == 128 && t.BN == 128) launch_fwd<128, 128, 2, 2>(stream, a, grid, wt, vec);
@@ -857,11 +973,10 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
     IGAN_LAUNCH_CHECK("conv2d launch");
 
     if (splits > 1) {
-        const int total = (int)out_elems;
-        const int rg = std::min(ceil_div(total, 256), 2048);
-        hipLaunchKernelGGL(conv_reduce_kernel, dim3(rg), dim3(256), 0, stream,
-                           (const float*)p->workspace, p->y, p->out_scale, total, splits, p->Cout, p->OH * p->OW, p->alpha);
-        IGAN_LAUNCH_CHECK("conv2d reduce launch");
+        // enough row groups per tile that the fix-up itself fills the machine
+        const int rp = std::max(2, std::min(t.BM, t.BM / ceil_div(1024, sliced)));
+        hipLaunchKernelGGL(conv_fixup_kernel, dim3(sliced, ceil_div(t.BM, rp)), dim3(256), 0, stream, a, t.BM, t.BN, rp);
+        IGAN_LAUNCH_CHECK("conv2d fix-up launch");
     }
     return IGAN_OK;
 }

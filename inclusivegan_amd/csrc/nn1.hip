@@ -114,6 +114,7 @@ extern "C" int igan_nn1_update(igan_stream_t stream_, const float* query, const 
     p.KH = 1; p.KW = 1; p.stride = 1; p.up = 1; p.pad_y = 0; p.pad_x = 0;
     p.w_transposed = 1;  // cand is [nc][dim] == forward-layout [1][1][Cout][Cin]
     p.splits = 1;
+    p.sliced_tiles = 0;
     p.alpha = 1.0f;
     if (int rc = igan_conv2d(stream_, &p)) return rc;
     const int grid = ceil_div(nq, 4);

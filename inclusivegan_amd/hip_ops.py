@@ -401,9 +401,10 @@ def conv2d_raw(x, w, geom, out_hw, cout, w_transposed=False, in_scale=None, out_
     plan = _plan_cache.get(key)
     if plan is None:
         splits = ctypes.c_int(1)
+        sliced = ctypes.c_int(0)
         wsf = ctypes.c_size_t(0)
-        _abi.check(lib.igan_conv2d_plan(ctypes.byref(p), ctypes.byref(splits), ctypes.byref(wsf)))
-        plan = (splits.value, wsf.value)
+        _abi.check(lib.igan_conv2d_plan(ctypes.byref(p), ctypes.byref(splits), ctypes.byref(sliced), ctypes.byref(wsf)))
+        plan = (splits.value, wsf.value, sliced.value)
         _plan_cache[key] = plan
     ws = None
     if plan[0] > 1:
@@ -411,6 +412,7 @@ def conv2d_raw(x, w, geom, out_hw, cout, w_transposed=False, in_scale=None, out_
         p.workspace = ws.data_ptr()
         p.workspace_floats = plan[1]
         p.splits = plan[0]
+        p.sliced_tiles = plan[2]
     if launch_log is not None:
         buf = ctypes.create_string_buffer(128)
         _abi.check(lib.igan_conv2d_kernel_name(ctypes.byref(p), buf, 128))

@@ -75,14 +75,19 @@ def test_invalid_arguments_are_rejected_without_a_device():
 def test_plans_are_host_only():
     from inclusivegan_amd import _abi
     lib = _abi.get_plugin()
-    # 4x4 layer of config-e at batch 6: M = 96 -> must be split along K; 128x128 layer: no split
+    # Tiles are dealt to 256 CUs.  4x4 layer of config-e at batch 6: M = 96 -> 4 tiles of 128x128, all sliced
+    # along K; 128x128 layer at batch 6: 768 tiles = 3 whole rounds -> nothing to slice; a 32x32 layer at
+    # batch 18 (VGG conv3): 288 tiles -> only the 32 tiles of the second round are sliced.
     small = _abi.Conv2DParams(x=16, w=16, y=16, N=6, H=4, W=4, Cin=512, OH=4, OW=4, Cout=512, KH=3, KW=3, stride=1, up=1, pad_y=1, pad_x=1)
     big = _abi.Conv2DParams(x=16, w=16, y=16, N=6, H=128, W=128, Cin=128, OH=128, OW=128, Cout=128, KH=3, KW=3, stride=1, up=1, pad_y=1, pad_x=1)
-    s, ws = ctypes.c_int(), ctypes.c_size_t()
-    assert lib.igan_conv2d_plan(ctypes.byref(small), ctypes.byref(s), ctypes.byref(ws)) == 0
-    assert s.value > 1 and ws.value == s.value * 6 * 16 * 512
-    assert lib.igan_conv2d_plan(ctypes.byref(big), ctypes.byref(s), ctypes.byref(ws)) == 0
-    assert s.value == 1 and ws.value == 0
+    mid = _abi.Conv2DParams(x=16, w=16, y=16, N=18, H=32, W=32, Cin=256, OH=32, OW=32, Cout=256, KH=3, KW=3, stride=1, up=1, pad_y=1, pad_x=1)
+    s, sl, ws = ctypes.c_int(), ctypes.c_int(), ctypes.c_size_t()
+    assert lib.igan_conv2d_plan(ctypes.byref(small), ctypes.byref(s), ctypes.byref(sl), ctypes.byref(ws)) == 0
+    assert s.value > 1 and sl.value == 4 and ws.value == 4 * s.value * 128 * 128
+    assert lib.igan_conv2d_plan(ctypes.byref(big), ctypes.byref(s), ctypes.byref(sl), ctypes.byref(ws)) == 0
+    assert s.value == 1 and sl.value == 0 and ws.value == 0
+    assert lib.igan_conv2d_plan(ctypes.byref(mid), ctypes.byref(s), ctypes.byref(sl), ctypes.byref(ws)) == 0
+    assert s.value > 1 and sl.value in (32, 288) and ws.value == sl.value * s.value * 128 * 128
     wg = _abi.Conv2DWgradParams(x=16, dy=16, dw=16, N=6, H=128, W=128, Cin=128, OH=128, OW=128, Cout=128, KH=3, KW=3, stride=1, up=1, pad_y=1, pad_x=1)
     assert lib.igan_conv2d_wgrad_plan(ctypes.byref(wg), ctypes.byref(s), ctypes.byref(ws)) == 0
     assert s.value > 1 and ws.value == s.value * 9 * 128 * 128

@@ -235,6 +235,8 @@ CONV_CASES = [
     (5, 30, 1, 1, 16, 1, 1, 1, 0, None),     # Cin % 4 != 0: MFMA path
     (2, 3, 12, 12, 64, 3, 1, 1, 1, None),    # VGG conv1_1
     (1, 128, 32, 32, 128, 3, 1, 1, 1, None), # bigger tile grid
+    (24, 512, 8, 8, 512, 3, 1, 1, 1, None),  # 48 sliced tiles: fix-up row groups of 5 overhang the 128-row tile
+    (10, 64, 64, 64, 128, 3, 1, 1, 1, None), # 320 tiles: one whole round + a sliced tail of 64
 ]
 
 
