@@ -39,6 +39,7 @@
 //    of the tail tiles only, not of the whole output.
 #include "igan_common.h"
 #include <cmath>
+#include <cstdlib>
 
 namespace {
 
@@ -181,15 +182,17 @@ __device__ __forceinline__ void mma_steps(const float (&af)[TM][16], const float
 // SC: an in_scale operand exists (host dispatch on the pointer) -- without it the scale loads,
 // their addresses and the multiplies are not in the loop at all.
 template <int BM, int BN, int WM, int WN, bool WT, bool VEC, bool SC>
-__global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_fwd_kernel(ConvArgs a) {
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
     constexpr int LDB = WT ? LDK : BN + 4;
     constexpr int A_ELEMS = BM * LDK;
     constexpr int B_ELEMS = WT ? BN * LDK : BK * (BN + 4);
-    constexpr int AR = BM / 32;  // A rows per thread
-    constexpr int BR = BN / 32;  // B float4 per thread (both layouts)
-    static_assert(TM >= 1 && TN >= 1 && WM * WN == 4, "bad tile config");
+    constexpr int NT = WM * WN * 64;     // threads: 4 waves (one per SIMD) or 8 (two per SIMD)
+    constexpr int AROWS = NT / 8;        // tile rows covered by one pass of the loaders (8 float4 per 32-k row)
+    constexpr int AR = BM / AROWS;       // A rows per thread
+    constexpr int BR = BN / AROWS;       // B float4 per thread (both layouts: BK * BN / 4 / NT)
+    static_assert(TM >= 1 && TN >= 1 && (WM * WN == 4 || WM * WN == 8) && AR >= 1 && BR >= 1, "bad tile config");
 
     __shared__ __attribute__((aligned(16))) float As[2 * A_ELEMS];
     __shared__ __attribute__((aligned(16))) float Bs[2 * B_ELEMS];
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
     bool rok[AR];
 #pragma unroll
     for (int i = 0; i < AR; i++) {
-        const int m = m0 + arow0 + 32 * i;
+        const int m = m0 + arow0 + AROWS * i;
         rok[i] = m < Mcls;
         const int mm = rok[i] ? m : 0;
         const int nn = mm / (QH * QW);
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
     }
     // B loader coordinates
     constexpr int NV = BN / 4;            // float4 per B row (normal layout)
-    constexpr int KROWS = 256 / NV;       // k rows per pass (normal layout)
+    constexpr int KROWS = NT / NV;        // k rows per pass (normal layout)
     const int nvec = WT ? 0 : (tid % NV);
     const int krow0 = WT ? 0 : (tid / NV);
     const int brow0 = tid >> 3;           // transposed layout: n row
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
         } else {
 #pragma unroll
             for (int i = 0; i < BR; i++) {
-                const int co = n0 + brow0 + 32 * i;
+                const int co = n0 + brow0 + AROWS * i;
                 ab[i] = make_addr<VEC>((((a.KH - 1 - ky) * a.KW + (a.KW - 1 - kx)) * a.Cout + co) * a.Cin + ci, (live & (co < a.Cout)) ? (a.Cin - ci) : 0);
             }
         }
@@ -330,13 +333,13 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
         float* B = Bs + buf * B_ELEMS;
 #pragma unroll
         for (int i = 0; i < AR; i++)
-            *reinterpret_cast<float4*>(A + (arow0 + 32 * i) * LDK + 4 * kvec) = SC ? f4mul(ra[i], rsa[i]) : ra[i];
+            *reinterpret_cast<float4*>(A + (arow0 + AROWS * i) * LDK + 4 * kvec) = SC ? f4mul(ra[i], rsa[i]) : ra[i];
         if constexpr (!WT) {
 #pragma unroll
             for (int i = 0; i < BR; i++) *reinterpret_cast<float4*>(B + (krow0 + KROWS * i) * LDB + 4 * nvec) = rb[i];
         } else {
 #pragma unroll
-            for (int i = 0; i < BR; i++) *reinterpret_cast<float4*>(B + (brow0 + 32 * i) * LDK + 4 * kvec) = rb[i];
+            for (int i = 0; i < BR; i++) *reinterpret_cast<float4*>(B + (brow0 + AROWS * i) * LDK + 4 * kvec) = rb[i];
         }
     };
 
@@ -522,7 +525,7 @@ struct WgradArgs {
 // and the running byte offsets into x / dy / the scale rows move by precomputed (uniform) deltas --
 // no integer division or multiply per chunk.
 template <int BM, int BN, int WM, int WN, bool VEC, int SCM>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_wgrad_kernel(WgradArgs a) {
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
     constexpr int LDA = BM + 4;
@@ -530,7 +533,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
     constexpr int A_ELEMS = BK * LDA;
     constexpr int B_ELEMS = BK * LDB;
     constexpr int MV = BM / 4, NV = BN / 4;
-    constexpr int AROWS = 256 / MV, BROWS = 256 / NV;  // pixel rows per pass
+    constexpr int NT = WM * WN * 64;                   // threads: 4 waves (one per SIMD) or 8 (two per SIMD)
+    constexpr int AROWS = NT / MV, BROWS = NT / NV;    // pixel rows per pass
     constexpr int AR = BK / AROWS, BR = BK / BROWS;    // float4 per thread
     constexpr bool SAME = (AROWS == BROWS);            // A and B loaders walk the same pixel rows
     constexpr int WR = SAME ? 1 : BR;                  // B-side walkers when they differ
@@ -780,6 +784,15 @@ int fwd_geometry_check(const igan_conv2d_params* p) {
     return IGAN_OK;
 }
 
+// The 128x128 tile runs with 8 wavefronts (2 x 4 of 64x32 accumulators, two per SIMD, four with both resident
+// workgroups) rather than 4 (2 x 2 of 64x64): the matrix pipe of a SIMD then always has a second wave of the
+// same workgroup to issue from while one waits on LDS or the barrier (+3 % on the layer mix, more for a
+// workgroup that is alone on its CU).  IGAN_CONV_8WAVE=0 / IGAN_WGRAD_8WAVE=0 select the 4-wave form (A/B runs).
+bool eight_waves(const char* env) {
+    const char* v = getenv(env);
+    return !(v && atoi(v) == 0);
+}
+
 // 1x1 convolution on a 1x1 map = a dense layer; with at most 32 rows and no scales it goes to dense_small.hip
 bool is_small_dense(const igan_conv2d_params* p) {
     return p->H == 1 && p->W == 1 && p->OH == 1 && p->OW == 1 && p->KH == 1 && p->KW == 1 && p->stride == 1 && p->up == 1 &&
@@ -804,8 +817,8 @@ void fwd_counts(const igan_conv2d_params* p, int& Mmax, int& chunks_max, int& nc
 
 template <int BM, int BN, int WM, int WN, bool WT, bool VEC>
 void launch_fwd2(hipStream_t stream, const ConvArgs& a, dim3 grid) {
-    if (a.in_scale) hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, WT, VEC, true>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, WT, VEC, false>), grid, dim3(256), 0, stream, a);
+    if (a.in_scale) hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, WT, VEC, true>), grid, dim3(WM * WN * 64), 0, stream, a);
+    else hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, WT, VEC, false>), grid, dim3(WM * WN * 64), 0, stream, a);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -911,6 +924,7 @@ extern "C" int igan_conv2d_kernel_name(const igan_conv2d_params* p, char* buf, i
     const bool vecB = ((wt ? p->Cin : p->Cout) % 4 == 0) && (((uintptr_t)p->w & 15) == 0);
     const bool vec = vecA && vecB && (p->in_scale == nullptr || vecS);
     int wm = 2, wn = 2;
+    if (t.BM == 128 && t.BN == 128 && eight_waves("IGAN_CONV_8WAVE")) wn = 4;
     if (t.BM == 128 && t.BN == 32) { wm = 4; wn = 1; }
     if (t.BM == 32) { wm = 1; wn = 4; }
     snprintf(buf, (size_t)buflen, "conv_fwd_kernel<%d, %d, %d, %d, %s, %s, %s>", t.BM, t.BN, wm, wn, wt ? "true" : "false",
@@ -966,7 +980,8 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
     dim3 grid(a.full_tiles + (l.T - a.full_tiles) * splits);
     const bool wt = p->w_transposed != 0;
     const bool vec = a.vecA && a.vecB && (a.in_scale == nullptr || a.vecS);
-    if (t.BM == 128 && t.BN == 128) launch_fwd<128, 128, 2, 2>(stream, a, grid, wt, vec);
+    if (t.BM == 128 && t.BN == 128 && eight_waves("IGAN_CONV_8WAVE")) launch_fwd<128, 128, 2, 4>(stream, a, grid, wt, vec);
+    else if (t.BM == 128 && t.BN == 128) launch_fwd<128, 128, 2, 2>(stream, a, grid, wt, vec);
     else if (t.BM == 128 && t.BN == 64) launch_fwd<128, 64, 2, 2>(stream, a, grid, wt, vec);
     else if (t.BM == 128 && t.BN == 32) launch_fwd<128, 32, 4, 1>(stream, a, grid, wt, vec);
     else launch_fwd<32, 128, 1, 4>(stream, a, grid, wt, vec);
@@ -999,9 +1014,9 @@ int wgrad_geometry_check(const igan_conv2d_wgrad_params* p) {
 
 template <int BM, int BN, int WM, int WN, bool VEC>
 void launch_wgrad2(hipStream_t stream, const WgradArgs& a, dim3 grid, int scm) {
-    if (scm == 0) hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, VEC, 0>), grid, dim3(256), 0, stream, a);
-    else if (scm == 1) hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, VEC, 1>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, VEC, 2>), grid, dim3(256), 0, stream, a);
+    if (scm == 0) hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, VEC, 0>), grid, dim3(WM * WN * 64), 0, stream, a);
+    else if (scm == 1) hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, VEC, 1>), grid, dim3(WM * WN * 64), 0, stream, a);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, VEC, 2>), grid, dim3(WM * WN * 64), 0, stream, a);
 }
 template <int BM, int BN, int WM, int WN>
 void launch_wgrad(hipStream_t stream, const WgradArgs& a, dim3 grid, bool vec, int scm) {
@@ -1090,7 +1105,8 @@ extern "C" int igan_conv2d_wgrad(igan_stream_t stream_, const igan_conv2d_wgrad_
     dim3 grid(ceil_div(p->Cin, t.BM), ceil_div(p->Cout, t.BN), p->KH * p->KW * splits);
     const bool vec = a.vecA && a.vecB && (a.in_scale == nullptr || a.vecSA) && (a.out_scale == nullptr || a.vecSB);
     const int scm = (a.in_scale && a.out_scale) ? 1 : ((a.in_scale || a.out_scale) ? 2 : 0);
-    if (t.BM == 128 && t.BN == 128) launch_wgrad<128, 128, 2, 2>(stream, a, grid, vec, scm);
+    if (t.BM == 128 && t.BN == 128 && eight_waves("IGAN_WGRAD_8WAVE")) launch_wgrad<128, 128, 2, 4>(stream, a, grid, vec, scm);
+    else if (t.BM == 128 && t.BN == 128) launch_wgrad<128, 128, 2, 2>(stream, a, grid, vec, scm);
     else if (t.BM == 128 && t.BN == 32) launch_wgrad<128, 32, 4, 1>(stream, a, grid, vec, scm);
     else launch_wgrad<32, 128, 1, 4>(stream, a, grid, vec, scm);
     IGAN_LAUNCH_CHECK("conv2d_wgrad launch");
