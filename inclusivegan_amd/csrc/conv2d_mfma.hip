@@ -784,7 +784,7 @@ int fwd_geometry_check(const igan_conv2d_params* p) {
     return IGAN_OK;
 }
 
-// The 128x128 tile runs with 8 wavefronts (2 x 4 of 64x32 accumulators, two per SIMD, four with both resident
+// The 128x128 (and 128x64) tile runs with 8 wavefronts (2 x 4 of 64x32 accumulators, two per SIMD, four with both resident
 // workgroups) rather than 4 (2 x 2 of 64x64): the matrix pipe of a SIMD then always has a second wave of the
 // same workgroup to issue from while one waits on LDS or the barrier (+3 % on the layer mix, more for a
 // workgroup that is alone on its CU).  IGAN_CONV_8WAVE=0 / IGAN_WGRAD_8WAVE=0 select the 4-wave form (A/B runs).
@@ -925,6 +925,7 @@ extern "C" int igan_conv2d_kernel_name(const igan_conv2d_params* p, char* buf, i
     const bool vec = vecA && vecB && (p->in_scale == nullptr || vecS);
     int wm = 2, wn = 2;
     if (t.BM == 128 && t.BN == 128 && eight_waves("IGAN_CONV_8WAVE")) wn = 4;
+    if (t.BM == 128 && t.BN == 64 && eight_waves("IGAN_CONV_8WAVE")) { wm = 4; wn = 2; }
     if (t.BM == 128 && t.BN == 32) { wm = 4; wn = 1; }
     if (t.BM == 32) { wm = 1; wn = 4; }
     snprintf(buf, (size_t)buflen, "conv_fwd_kernel<%d, %d, %d, %d, %s, %s, %s>", t.BM, t.BN, wm, wn, wt ? "true" : "false",
@@ -982,6 +983,7 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
     const bool vec = a.vecA && a.vecB && (a.in_scale == nullptr || a.vecS);
     if (t.BM == 128 && t.BN == 128 && eight_waves("IGAN_CONV_8WAVE")) launch_fwd<128, 128, 2, 4>(stream, a, grid, wt, vec);
     else if (t.BM == 128 && t.BN == 128) launch_fwd<128, 128, 2, 2>(stream, a, grid, wt, vec);
+    else if (t.BM == 128 && t.BN == 64 && eight_waves("IGAN_CONV_8WAVE")) launch_fwd<128, 64, 4, 2>(stream, a, grid, wt, vec);
     else if (t.BM == 128 && t.BN == 64) launch_fwd<128, 64, 2, 2>(stream, a, grid, wt, vec);
     else if (t.BM == 128 && t.BN == 32) launch_fwd<128, 32, 4, 1>(stream, a, grid, wt, vec);
     else launch_fwd<32, 128, 1, 4>(stream, a, grid, wt, vec);
