@@ -751,11 +751,19 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_wgr
     }
 }
 
+// y[i] = alpha * sum_k ws[k][i], fixed order.  Four partial sums so that four loads are in flight per lane (a single
+// running sum is `splits` dependent L2 round trips: 256 slices took 200 us for a 1.5 KB result).
 __global__ __launch_bounds__(256) void plain_reduce_kernel(const float* ws, float* y, int total, int splits, float alpha) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int k = 0; k < splits; k++) s += ws[(size_t)k * total + i];
-        y[i] = s * alpha;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int k = 0;
+        for (; k + 4 <= splits; k += 4) {
+            const float a0 = ws[(size_t)k * total + i], a1 = ws[(size_t)(k + 1) * total + i];
+            const float a2 = ws[(size_t)(k + 2) * total + i], a3 = ws[(size_t)(k + 3) * total + i];
+            s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+        }
+        for (; k < splits; k++) s0 += ws[(size_t)k * total + i];
+        y[i] = ((s0 + s1) + (s2 + s3)) * alpha;
     }
 }
 
@@ -869,7 +877,7 @@ extern "C" int igan_conv2d_plan(const igan_conv2d_params* p, int* splits, int* s
     *splits = 1;
     *sliced_tiles = 0;
     *workspace_floats = 0;
-    if (is_small_dense(p)) return IGAN_OK;
+    if (is_small_dense(p) || igan::thin_conv_kind(p)) return IGAN_OK;
     int Mmax, chunks_max, nclass;
     fwd_counts(p, Mmax, chunks_max, nclass);
     const FwdTile t = pick_fwd_tile(Mmax, p->Cout);
@@ -915,6 +923,10 @@ extern "C" int igan_conv2d_kernel_name(const igan_conv2d_params* p, char* buf, i
         snprintf(buf, (size_t)buflen, "dense_small_kernel<%d, %s>", igan::dense_small_rows(p->N), p->w_transposed ? "true" : "false");
         return IGAN_OK;
     }
+    if (const int kind = igan::thin_conv_kind(p)) {
+        snprintf(buf, (size_t)buflen, "%s<%d>", kind == 1 ? "thin_out_kernel" : "thin_in_kernel", p->KH * p->KW);
+        return IGAN_OK;
+    }
     int Mmax, chunks_max, nclass;
     fwd_counts(p, Mmax, chunks_max, nclass);
     const FwdTile t = pick_fwd_tile(Mmax, p->Cout);
@@ -941,6 +953,11 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
     if (is_small_dense(p)) {
         dense_small(stream, p->x, p->w, p->y, p->N, p->Cin, p->Cout, p->w_transposed != 0, p->alpha);
         IGAN_LAUNCH_CHECK("conv2d dense launch");
+        return IGAN_OK;
+    }
+    if (const int kind = thin_conv_kind(p)) {
+        thin_conv(stream, p, kind);
+        IGAN_LAUNCH_CHECK("conv2d thin-channel launch");
         return IGAN_OK;
     }
     int Mmax, chunks_max, nclass;
@@ -1063,6 +1080,11 @@ extern "C" int igan_conv2d_wgrad_plan(const igan_conv2d_wgrad_params* p, int* sp
     IGAN_REQUIRE(p && splits && workspace_floats, "conv2d_wgrad_plan: null argument");
     if (int rc = wgrad_geometry_check(p)) return rc;
     if (is_small_dense_wgrad(p)) { *splits = 1; *workspace_floats = 0; return IGAN_OK; }
+    if (const int kind = igan::thin_wgrad_kind(p)) {
+        *splits = 2;                           // "uses the workspace"; the pixel blocking is internal
+        *workspace_floats = igan::thin_wgrad_workspace(p, kind);
+        return IGAN_OK;
+    }
     const int s = wgrad_splits(p);
     *splits = s;
     *workspace_floats = (s > 1) ? (size_t)s * p->KH * p->KW * p->Cin * p->Cout : 0;
@@ -1078,6 +1100,13 @@ extern "C" int igan_conv2d_wgrad(igan_stream_t stream_, const igan_conv2d_wgrad_
         dense_small_wgrad(stream, p->x, p->dy, p->dw, p->N, p->Cin, p->Cout, p->alpha);
         IGAN_LAUNCH_CHECK("conv2d_wgrad dense launch");
         return IGAN_OK;
+    }
+    if (const int kind = thin_wgrad_kind(p)) {
+        if (p->workspace && p->workspace_floats >= thin_wgrad_workspace(p, kind) && (((uintptr_t)p->workspace) & 15) == 0) {
+            thin_wgrad(stream, p, kind);
+            IGAN_LAUNCH_CHECK("conv2d_wgrad thin-channel launch");
+            return IGAN_OK;
+        }
     }
     const int splits = std::max(1, p->splits);
     const size_t wsize = (size_t)p->KH * p->KW * p->Cin * p->Cout;

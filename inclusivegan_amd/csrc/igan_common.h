@@ -37,6 +37,13 @@ void dense_small(hipStream_t stream, const float* x, const float* w, float* y, i
 bool dense_small_wgrad_ok(int M, int N, const void* dy, const void* dw);
 void dense_small_wgrad(hipStream_t stream, const float* x, const float* dy, float* dw, int M, int K, int N, float alpha);
 
+// thin_conv.hip: layers with <= 4 channels on one side (ToRGB, FromRGB, VGG conv1_1), dispatched from igan_conv2d / _wgrad
+int thin_conv_kind(const igan_conv2d_params* p);
+void thin_conv(hipStream_t stream, const igan_conv2d_params* p, int kind);
+int thin_wgrad_kind(const igan_conv2d_wgrad_params* p);
+size_t thin_wgrad_workspace(const igan_conv2d_wgrad_params* p, int kind);
+void thin_wgrad(hipStream_t stream, const igan_conv2d_wgrad_params* p, int kind);
+
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline long long ceil_div_ll(long long a, long long b) { return (a + b - 1) / b; }
 

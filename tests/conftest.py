@@ -18,3 +18,12 @@ def cuda_device():
     if not torch.cuda.is_available():
         pytest.skip('no ROCm device')
     return torch.device('cuda', 0)
+
+
+@pytest.fixture(autouse=True)
+def _seed_torch():
+    """Every test starts from the same host and device RNG state: the parity tests record the device draws of the
+    HIP path and replay them into the oracle, so an unseeded run compares a different random problem each time."""
+    import torch
+    torch.manual_seed(20261002)
+    yield

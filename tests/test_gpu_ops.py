@@ -233,7 +233,12 @@ CONV_CASES = [
     (32, 20, 1, 1, 3, 1, 1, 1, 0, None),     # 32 rows, Cout = 3 (weight gradient falls back to the MFMA path)
     (33, 64, 1, 1, 64, 1, 1, 1, 0, None),    # 33 rows: too many for the dense kernels
     (5, 30, 1, 1, 16, 1, 1, 1, 0, None),     # Cin % 4 != 0: MFMA path
-    (2, 3, 12, 12, 64, 3, 1, 1, 1, None),    # VGG conv1_1
+    (2, 3, 12, 12, 64, 3, 1, 1, 1, None),    # VGG conv1_1 (thin-input kernel; its data gradient: thin-output 3x3)
+    (3, 128, 9, 7, 3, 1, 1, 1, 0, None),     # ToRGB at a thin-kernel size: 32 lanes per pixel, ragged pixel count
+    (2, 512, 4, 4, 3, 1, 1, 1, 0, None),     # ToRGB of the 512-channel layers: two channel blocks per lane
+    (2, 64, 5, 5, 4, 3, 1, 1, 1, None),      # thin output with 4 channels, 3x3
+    (2, 4, 6, 6, 16, 1, 1, 1, 0, None),      # thin input with 4 channels
+    (5, 3, 16, 16, 512, 1, 1, 1, 0, None),   # FromRGB into 512 channels: two channel blocks
     (1, 128, 32, 32, 128, 3, 1, 1, 1, None), # bigger tile grid
     (24, 512, 8, 8, 512, 3, 1, 1, 1, None),  # 48 sliced tiles: fix-up row groups of 5 overhang the 128-row tile
     (10, 64, 64, 64, 128, 3, 1, 1, 1, None), # 320 tiles: one whole round + a sliced tail of 64
@@ -322,6 +327,30 @@ def test_modconv_fused_scales(mode, demod, cuda_device):
     for a, b, c in zip(g1, g2, g3):
         assert rel_err(a, b) < 5e-5
         assert rel_err(c, b) < 5e-5
+
+
+@pytest.mark.parametrize('cin', [128, 512])
+def test_modconv_torgb_thin_kernels(cin, cuda_device):
+    """ToRGB (1x1, Cout = 3, modulated, no demodulation, alpha != 1) runs on the thin-channel kernels: forward,
+    data gradient (thin input, transposed weights), weight gradient (per-sample scale) and style gradient vs the composite."""
+    from inclusivegan_amd import hip_ops
+    rng = np.random.RandomState(cin)
+    N, H = 3, 10
+    geom = hip_ops.ConvGeom(1, 1, 1, 1, 0, 0, 0.37)
+    x = torch.from_numpy(rng.randn(N, cin, H, H).astype(np.float32))
+    w = torch.from_numpy(rng.randn(1, 1, cin, 3).astype(np.float32))
+    s = torch.from_numpy((rng.randn(N, cin) * 0.3 + 1).astype(np.float32))
+    dy = torch.from_numpy(rng.randn(N, 3, H, H).astype(np.float32))
+    outs = []
+    for fn in (hip_ops.ModConv2dFn.apply, hip_ops.modconv_composite):
+        xs = to_nhwc_cuda(x, cuda_device).requires_grad_(True); ws = w.to(cuda_device).requires_grad_(True)
+        ss = s.to(cuda_device).requires_grad_(True)
+        y = fn(xs, ws, ss, None, geom, (H, H))
+        outs.append((y,) + torch.autograd.grad(y, [xs, ws, ss], to_nhwc_cuda(dy, cuda_device)))
+    yo = torch.einsum('nchw,co->nohw', x.double() * s.double()[:, :, None, None], w.double()[0, 0]) * 0.37
+    assert rel_err(outs[0][0], yo) < 2e-5
+    for a_, b_ in zip(outs[0], outs[1]):
+        assert rel_err(a_, b_) < 3e-5
 
 
 # ----------------------------------------------------------------------------- style path (s, d)

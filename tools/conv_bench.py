@@ -54,7 +54,7 @@ def main():
         w = torch.randn(K, K, Cin, Cout, device=dev) / (K * K * Cin) ** 0.5
         dy = torch.randn(N, Cout, out, out, device=dev).contiguous(memory_format=torch.channels_last)
         s = torch.rand(N, Cin, device=dev) + 0.5 if scales else None
-        d = torch.rand(N, Cout, device=dev) + 0.5 if scales else None
+        d = torch.rand(N, Cout, device=dev) + 0.5 if (scales and Cout > 4) else None    # ToRGB: demodulate=False
         # algorithmic MACs: every (output pixel, tap) pair that hits a real input sample (or zero padding)
         taps = K * K if up == 1 else ((K + 1) // 2) ** 2 + 2 * ((K + 1) // 2) * (K // 2) + (K // 2) ** 2   # summed over the 4 parity classes
         pix = out * out if up == 1 else ((out + 1) // 2) ** 2  # per class (approx for odd out)
