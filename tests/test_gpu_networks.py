@@ -176,6 +176,53 @@ def test_losses_and_gradients_match_oracle(cuda_device):
         assert errs[worst] < 5e-3, (phase, worst, errs[worst])
 
 
+def test_training_ops_are_bit_reproducible(cuda_device):
+    """The device work of the G and D steps (loss + backward into the flat bucket), run twice from the same RNG state
+    on the same inputs, gives bit-identical gradients: every kernel on the path reduces in a fixed order."""
+    from inclusivegan_amd.dnnlib import tflib
+    from inclusivegan_amd.training import loss as PL
+    from inclusivegan_amd.training.dataset import SyntheticDataset
+    dev = cuda_device
+    G, D = _nets(dev)
+    lp = tflib.Network('lpips', func_name='inclusivegan_amd.metrics.lpips.vgg16_zhang_perceptual', resolution=RES, device=dev, seed=13)
+    ts = SyntheticDataset(resolution=RES, label_size=0, data_size=24, device=dev)
+    B = 6
+    g = torch.Generator().manual_seed(7)
+    cl = lambda t: t.to(dev).contiguous(memory_format=torch.channels_last)
+    r1 = cl(torch.rand(B, 3, RES, RES, generator=g) * 2 - 1); r2 = cl(torch.rand(B, 3, RES, RES, generator=g) * 2 - 1)
+    z1 = torch.nn.functional.normalize(torch.randn(B, 512, generator=g), dim=1).to(dev)
+    z2 = torch.nn.functional.normalize(torch.randn(B, 512, generator=g), dim=1).to(dev)
+    reals = cl(torch.rand(2 * B, 3, RES, RES, generator=g) * 2 - 1)
+    lab = torch.zeros(B, 0, device=dev); lab2 = torch.zeros(2 * B, 0, device=dev)
+
+    def g_step(phase):
+        G.zero_grad(); D.requires_grad_(False)
+        G.pl_mean_var = torch.zeros((), device=dev)
+        loss, reg = PL.G_logistic_ns_rec_interp_arb_pathreg(G, D, lp, ts, B, r1, lab, z1, r2, lab, z2, NN_rec_lpips_weight=2.5, phase=phase)
+        torch.autograd.backward((loss if phase == 'loss' else reg).mean(), inputs=list(G.trainables.values()))
+        D.requires_grad_(True)
+        return G.flat_grads.clone()
+
+    def d_step(phase):
+        D.zero_grad(); G.requires_grad_(False)
+        loss, reg = PL.D_logistic_r1(G, D, ts, B, reals, lab2, gamma=100, phase=phase)
+        torch.autograd.backward((loss if phase == 'loss' else reg).mean(), inputs=list(D.trainables.values()))
+        G.requires_grad_(True)
+        return D.flat_grads.clone()
+
+    avg0 = G.vars['dlatent_avg'].detach().clone()
+    for step in (g_step, d_step):
+        for phase in ('loss', 'reg'):
+            outs = []
+            for _ in range(2):
+                torch.manual_seed(99)
+                with torch.no_grad():
+                    G.vars['dlatent_avg'].copy_(avg0)       # the G pass moves it (networks_stylegan2.py:203-209)
+                outs.append(step(phase))
+            assert torch.equal(outs[0], outs[1]), (step.__name__, phase)
+            assert float(outs[0].abs().max()) > 0
+
+
 def test_optimizer_step_and_ema_match_oracle(cuda_device):
     """Optimizer.register_gradients/apply_updates (flat bucket, finite check, Adam with lazy-reg
     beta scaling, shared slots) and Gs EMA against the NumPy SimpleAdam restatement."""

@@ -275,6 +275,32 @@ def test_conv2d_forward_dgrad_wgrad(case, cuda_device):
     assert rel_err(gwg, gwo) < 3e-5
 
 
+@pytest.mark.parametrize('case', [(6, 128, 32, 32, 128, 3, 1, 1, 1, 32), (18, 64, 32, 32, 64, 3, 1, 1, 1, 32), (6, 512, 8, 8, 512, 3, 1, 1, 1, 8),
+                                  (4, 64, 16, 16, 64, 3, 1, 2, 2, 33), (6, 128, 64, 64, 3, 1, 1, 1, 0, 64), (6, 3, 64, 64, 128, 1, 1, 1, 0, 64),
+                                  (24, 512, 1, 1, 512, 1, 1, 1, 0, 1)])
+def test_conv_family_is_bit_reproducible(case, cuda_device):
+    """Every reduction in the conv family has a fixed order (sliced tails, split weight gradients, thin-channel and
+    dense kernels): two runs on the same inputs must agree bit for bit -- this is also the race detector."""
+    from inclusivegan_amd import hip_ops
+    N, Cin, H, W, Cout, K, stride, up, pad, out = case
+    g = torch.Generator(device='cpu').manual_seed(N * 131 + Cin)
+    x = to_nhwc_cuda(torch.randn(N, Cin, H, W, generator=g), cuda_device)
+    w = (torch.randn(K, K, Cin, Cout, generator=g) / (K * K * Cin) ** 0.5).to(cuda_device)
+    dy = to_nhwc_cuda(torch.randn(N, Cout, out, out, generator=g), cuda_device)
+    s = (torch.rand(N, Cin, generator=g) + 0.5).to(cuda_device)
+    geom = hip_ops.ConvGeom(K, K, stride, up, pad, pad, 0.5)
+    runs = []
+    for _ in range(3):
+        y = hip_ops.conv2d_raw(x, w, geom, (out, out), Cout, in_scale=s)
+        dx = hip_ops.conv2d_raw(dy, w, hip_ops.dgrad_geom(geom), (H, W), Cin, w_transposed=True)
+        dw = hip_ops.conv2d_wgrad_raw(x, dy, geom, in_scale=s)
+        runs.append((y, dx, dw))
+        torch.empty(1 << 22, device=cuda_device).normal_()     # churn the allocator / caches between runs
+    for r in runs[1:]:
+        for a_, b_ in zip(r, runs[0]):
+            assert torch.equal(a_, b_)
+
+
 def test_conv2d_double_backward(cuda_device):
     """R1-style penalty through conv (needs d(dgrad)/dw and d(dgrad)/d(dy))."""
     from inclusivegan_amd import hip_ops
