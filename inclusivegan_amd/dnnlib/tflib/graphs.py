@@ -44,7 +44,10 @@ class GraphedStep:
         if self.graph is None:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=GraphedStep._pool):
+            # With a process group up, RCCL's watchdog thread polls events while we capture: in the default
+            # "global" mode that foreign call would invalidate the capture; only this thread's calls matter here.
+            dist_up = torch.distributed.is_available() and torch.distributed.is_initialized()
+            with torch.cuda.graph(g, pool=GraphedStep._pool, capture_error_mode='thread_local' if dist_up else 'global'):
                 self.out = self.fn()
             if GraphedStep._pool is None:
                 GraphedStep._pool = g.pool()

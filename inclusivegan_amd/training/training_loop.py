@@ -113,6 +113,9 @@ def combine_best_(best, world):
     non-negative int64, so an element-wise all-reduce(min) keeps, for every real, the closest candidate
     over all ranks' shards (ties -> lowest index)."""
     if world > 1:
+        # the kernels compare the words as unsigned; the collective compares int64: the "nothing yet" word (all ones =
+        # -1) of a rank that had no candidate batch must lose, not win
+        best.copy_(torch.where(best < 0, torch.full_like(best, torch.iinfo(torch.int64).max), best))
         torch.distributed.all_reduce(best, op=torch.distributed.ReduceOp.MIN)
     return best
 

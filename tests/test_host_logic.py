@@ -150,6 +150,10 @@ def _dp_worker(rank, world, port, out):
     best = (d.view(torch.int32).to(torch.int64) << 32) | idx
     combine_best_(best, world)
     bi, bd = unpack_best(best)
+    # a rank without any candidate batch still holds the "nothing yet" word (all ones): it must lose the exchange
+    lone = torch.full((3,), -1, dtype=torch.int64) if rank == 1 else best.clone()
+    combine_best_(lone, world)
+    assert torch.equal(lone, best)
     # identical host-side streams on every rank (np seed) -> identical shuffles / candidate latents
     np.random.seed(1000)
     order = np.arange(12); np.random.shuffle(order)

@@ -14,11 +14,8 @@ from inclusivegan_amd.training import loss as L  # noqa: E402
 from inclusivegan_amd.training.dataset import SyntheticDataset  # noqa: E402
 
 
-def main():
-    op = sys.argv[1] if len(sys.argv) > 1 else 'G_train'
-    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-    res = int(sys.argv[3]) if len(sys.argv) > 3 else 128
-    B = int(sys.argv[4]) if len(sys.argv) > 4 else 6
+def build(op, res=128, B=6):
+    """Networks + inputs of one training op; returns a zero-argument function that runs its device work once."""
     dev = torch.device('cuda', 0)
     kw = dict(num_channels=3, resolution=res, label_size=0, fmap_base=8192, device=dev)
     G = tflib.Network('G', func_name='inclusivegan_amd.training.networks_stylegan2.G_main', architecture='skip', seed=1, **kw)
@@ -48,6 +45,15 @@ def main():
             torch.autograd.backward(v.mean(), inputs=list(D.trainables.values()))
             G.requires_grad_(True)
 
+    return run
+
+
+def main():
+    op = sys.argv[1] if len(sys.argv) > 1 else 'G_train'
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    res = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+    B = int(sys.argv[4]) if len(sys.argv) > 4 else 6
+    run = build(op, res, B)
     run()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
