@@ -17,6 +17,7 @@
 //   * the 64 group partials meet in LDS and are added in fixed order: bit-reproducible, no atomics.
 // The weight-gradient kernel is an M-term outer product per element: one thread per 4 output channels.
 #include "igan_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -204,6 +205,10 @@ void launch_dense(hipStream_t stream, const igan_dense_params& a) {
 namespace igan {
 
 bool dense_small_ok(int M, int K, const void* x, const void* w, bool wt) {
+    // w[k][n] is streamed in 16 B pieces per k row: fine while the matrix is small and L2-resident, 4x read
+    // amplification from HBM for a long reduction axis (D's 8192 -> 512 layer): that one goes to the MFMA tiles.
+    static const int maxk = getenv("IGAN_DENSE_MAXK") ? atoi(getenv("IGAN_DENSE_MAXK")) : 2048;
+    if (!wt && K > maxk) return false;
     return M >= 1 && M <= 32 && (K % 4) == 0 && (((uintptr_t)x) & 15) == 0 && (!wt || (((uintptr_t)w) & 15) == 0);
 }
 
