@@ -883,6 +883,10 @@ extern "C" int igan_conv2d_plan(const igan_conv2d_params* p, int* splits, int* s
     const FwdTile t = pick_fwd_tile(Mmax, p->Cout);
     const TileList l = tile_list(p, t, Mmax, nclass);
     if (l.rem == 0) return IGAN_OK;           // whole rounds: nothing to gain
+    {   // A/B switch: IGAN_SLICE_BIG=0 leaves layers with at least one whole round unsliced
+        static const bool big = !(getenv("IGAN_SLICE_BIG") && atoi(getenv("IGAN_SLICE_BIG")) == 0);
+        if (!big && l.T >= device_cus()) return IGAN_OK;
+    }
     // Which trailing tiles to slice, and how finely, by a small cost model (measured on the 128x128 tile):
     // two co-resident workgroups finish a chunk each in 4.4 us, a lone one in 3.3 us (the matrix pipe is
     // per SIMD, so a pair is only 1.5x as efficient as a single).  A CU that holds n blocks of a tile's
