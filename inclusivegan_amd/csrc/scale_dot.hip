@@ -43,12 +43,24 @@ __global__ __launch_bounds__(256) void scale_dot_kernel(SdArgs p) {
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
     if (active && p.s) sc = *reinterpret_cast<const float4*>(p.s + (size_t)n * p.C + (size_t)col * 4);
     if (active) {
-        for (int r = r0 + lane_r; r < r1; r += rl) {
-            const size_t i = (size_t)r * cv + col;
-            const float4 x = a4[i];
-            const float4 g = b4[i];
-            acc.x += x.x * g.x; acc.y += x.y * g.y; acc.z += x.z * g.z; acc.w += x.w * g.w;
-            if (o4) o4[i] = make_float4(g.x * sc.x, g.y * sc.y, g.z * sc.z, g.w * sc.w);
+        // 4 rows per iteration with their 8 loads in flight together (a single row per iteration leaves too few bytes in
+        // flight per CU to reach HBM speed); the sum keeps its row order.
+        for (int rb = r0 + lane_r; rb < r1; rb += 4 * rl) {
+            float4 x[4], g[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const size_t i = (size_t)min(rb + u * rl, r1 - 1) * cv + col;     // clamped, masked below
+                x[u] = a4[i];
+                g[u] = b4[i];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int r = rb + u * rl;
+                if (r < r1) {
+                    acc.x += x[u].x * g[u].x; acc.y += x[u].y * g[u].y; acc.z += x[u].z * g[u].z; acc.w += x[u].w * g[u].w;
+                    if (o4) o4[(size_t)r * cv + col] = make_float4(g[u].x * sc.x, g[u].y * sc.y, g[u].z * sc.z, g[u].w * sc.w);
+                }
+            }
         }
     }
     red[threadIdx.x] = acc;
@@ -71,8 +83,18 @@ __global__ __launch_bounds__(256) void scale_dot_final_kernel(const float* parti
     const int grp = threadIdx.x >> 4;
     const int n = blockIdx.y;
     float s = 0.f;
-    if (c < C)
-        for (int j = grp; j < blocks; j += 16) s += partial[((size_t)n * blocks + j) * C + c];
+    if (c < C) {
+        // four independent partial sums: four loads in flight per lane instead of a chain of dependent L2 round trips
+        const float* q = partial + (size_t)n * blocks * C + c;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int j = grp;
+        for (; j + 48 < blocks; j += 64) {
+            s0 += q[(size_t)j * C];        s1 += q[(size_t)(j + 16) * C];
+            s2 += q[(size_t)(j + 32) * C]; s3 += q[(size_t)(j + 48) * C];
+        }
+        for (; j < blocks; j += 16) s0 += q[(size_t)j * C];
+        s = (s0 + s1) + (s2 + s3);
+    }
     red[threadIdx.x] = s;
     __syncthreads();
     if (grp == 0 && c < C) {

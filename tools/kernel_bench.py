@@ -64,6 +64,12 @@ def main():
         dy = torch.randn_like(x)
         ms = time_ms(lambda: hip_ops.bias_act_noise_bwd_raw(dy, y, noise, 3, 0.2, 2 ** 0.5, True), reps)
         print('epilogue bwd  [B,128,128,128] %7.1f us  %7.1f GB/s' % (ms * 1e3, 3 * x.numel() * 4 / ms / 1e6))
+        sc = torch.rand(B, 128, device=dev) + 0.5
+        dxs = torch.randn_like(x)
+        ms = time_ms(lambda: hip_ops.scale_dot_raw(x, dxs, sc, want_scaled=True), reps)
+        print('scale_dot     [B,128,128,128] %7.1f us  %7.1f GB/s  (2 reads + 1 write)' % (ms * 1e3, 3 * x.numel() * 4 / ms / 1e6))
+        ms = time_ms(lambda: hip_ops.scale_dot_raw(x, dxs), reps)
+        print('channel dot   [B,128,128,128] %7.1f us  %7.1f GB/s  (2 reads)' % (ms * 1e3, 2 * x.numel() * 4 / ms / 1e6))
     else:
         raise SystemExit(__doc__)
 
