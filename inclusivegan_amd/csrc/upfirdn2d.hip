@@ -14,6 +14,7 @@
 // consecutive float4 = 1 KiB of one or more adjacent pixels, so global loads and
 // stores are fully coalesced.
 #include "igan_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -77,50 +78,57 @@ __global__ __launch_bounds__(256) void upfirdn2d_generic_kernel(UpfirdnArgs a, F
 
 // Fast path: up = down = 1, taps zero-extended to 4x4, minorDim % 4 == 0.
 //   y[m,oy,ox,c] = sum_{ky,kx<4} x[m, oy+ky-pady0, ox+kx-padx0, c] * kf[ky][kx]
-template <int TY>
+template <int TY, int TX>
 __global__ __launch_bounds__(256) void upfirdn2d_fir4_kernel(UpfirdnArgs a, FirTaps taps) {
+    // a lane owns TY output rows x TX adjacent output columns of one channel quad: (TY+3) x (TX+3) input loads feed
+    // TY*TX outputs (5.5 loads per output at 8x1, 3.4 at 8x2: the kernel is L1-request bound, not HBM bound)
     const int cvecs = a.minorDim >> 2;
     const int strips = (a.outH + TY - 1) / TY;
-    const long long total = (long long)a.majorDim * strips * a.outW * cvecs;
+    const int xgroups = (a.outW + TX - 1) / TX;
+    const long long total = (long long)a.majorDim * strips * xgroups * cvecs;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     long long t = idx;
     const int cv = (int)(t % cvecs); t /= cvecs;
-    const int ox = (int)(t % a.outW); t /= a.outW;
+    const int ox0 = (int)(t % xgroups) * TX; t /= xgroups;
     const int strip = (int)(t % strips); t /= strips;
     const int m = (int)t;
     const int oy0 = strip * TY;
 
-    float4 acc[TY];
+    float4 acc[TY][TX];
 #pragma unroll
-    for (int i = 0; i < TY; i++) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < TY; i++)
+#pragma unroll
+        for (int j = 0; j < TX; j++) acc[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    const int ix0 = ox - a.padx0;
+    const int ix0 = ox0 - a.padx0;
     const float4* xbase = reinterpret_cast<const float4*>(a.x) + (long long)m * a.inH * a.inW * cvecs + cv;
 
 #pragma unroll
     for (int r = 0; r < TY + 3; r++) {
         const int iy = oy0 + r - a.pady0;
-        float4 v[4];
+        float4 v[TX + 3];
         const bool rowok = (iy >= 0) & (iy < a.inH);
 #pragma unroll
-        for (int kx = 0; kx < 4; kx++) {
-            const int ix = ix0 + kx;
+        for (int c = 0; c < TX + 3; c++) {
+            const int ix = ix0 + c;
             const bool ok = rowok & (ix >= 0) & (ix < a.inW);
-            v[kx] = ok ? xbase[((long long)iy * a.inW + ix) * cvecs] : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[c] = ok ? xbase[((long long)iy * a.inW + ix) * cvecs] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int ky = 0; ky < 4; ky++) {
             const int o = r - ky;  // output row (relative) fed by this input row via tap ky
             if (o >= 0 && o < TY) {
 #pragma unroll
-                for (int kx = 0; kx < 4; kx++) {
-                    const float kv = taps.k[ky * 4 + kx];
-                    acc[o].x += v[kx].x * kv;
-                    acc[o].y += v[kx].y * kv;
-                    acc[o].z += v[kx].z * kv;
-                    acc[o].w += v[kx].w * kv;
-                }
+                for (int j = 0; j < TX; j++)
+#pragma unroll
+                    for (int kx = 0; kx < 4; kx++) {
+                        const float kv = taps.k[ky * 4 + kx];
+                        acc[o][j].x += v[j + kx].x * kv;
+                        acc[o][j].y += v[j + kx].y * kv;
+                        acc[o][j].z += v[j + kx].z * kv;
+                        acc[o][j].w += v[j + kx].w * kv;
+                    }
             }
         }
     }
@@ -129,7 +137,9 @@ __global__ __launch_bounds__(256) void upfirdn2d_fir4_kernel(UpfirdnArgs a, FirT
 #pragma unroll
     for (int i = 0; i < TY; i++) {
         const int oy = oy0 + i;
-        if (oy < a.outH) ybase[((long long)oy * a.outW + ox) * cvecs] = acc[i];
+#pragma unroll
+        for (int j = 0; j < TX; j++)
+            if (oy < a.outH && ox0 + j < a.outW) ybase[((long long)oy * a.outW + ox0 + j) * cvecs] = acc[i][j];
     }
 }
 
@@ -177,14 +187,16 @@ extern "C" int igan_upfirdn2d(igan_stream_t stream_, const igan_upfirdn2d_params
             for (int kx = 0; kx < p->kernelW; kx++)
                 taps.k[ky * 4 + kx] = p->k[(p->kernelH - 1 - ky) * p->kernelW + (p->kernelW - 1 - kx)];
         const int cvecs = p->minorDim / 4;
-        if (outH >= 8) {
+        static const int tx = getenv("IGAN_FIR_TX") ? atoi(getenv("IGAN_FIR_TX")) : 2;   // A/B switch
+        if (outH >= 8 && outW >= 16 && tx >= 2) {        // 8x2 outputs per lane (8x4 and 4x4 were slower: registers)
+            const long long total = (long long)p->majorDim * ceil_div(outH, 8) * ceil_div(outW, 2) * cvecs;
+            hipLaunchKernelGGL((upfirdn2d_fir4_kernel<8, 2>), dim3((int)ceil_div_ll(total, 256)), dim3(256), 0, stream, a, taps);
+        } else if (outH >= 8) {
             const long long total = (long long)p->majorDim * ceil_div(outH, 8) * outW * cvecs;
-            const int grid = (int)ceil_div_ll(total, 256);
-            hipLaunchKernelGGL(upfirdn2d_fir4_kernel<8>, dim3(grid), dim3(256), 0, stream, a, taps);
+            hipLaunchKernelGGL((upfirdn2d_fir4_kernel<8, 1>), dim3((int)ceil_div_ll(total, 256)), dim3(256), 0, stream, a, taps);
         } else {
             const long long total = (long long)p->majorDim * ceil_div(outH, 2) * outW * cvecs;
-            const int grid = (int)ceil_div_ll(total, 256);
-            hipLaunchKernelGGL(upfirdn2d_fir4_kernel<2>, dim3(grid), dim3(256), 0, stream, a, taps);
+            hipLaunchKernelGGL((upfirdn2d_fir4_kernel<2, 1>), dim3((int)ceil_div_ll(total, 256)), dim3(256), 0, stream, a, taps);
         }
     } else {
         for (int ky = 0; ky < p->kernelH; ky++)
