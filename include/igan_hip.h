@@ -274,10 +274,12 @@ int igan_lpips_layer_bwd(igan_stream_t stream, const float* fa, const float* fb,
  * minibatch_stddev_layer statistics (networks_stylegan2.py:132-144), NHWC input
  * x[N, H, W, C], group size G (N % G == 0, M = N / G, num_new_features = 1):
  *   stat[m] = mean_{c,h,w} sqrt( mean_g (x[g*M+m] - mean_g x)^2 + 1e-8 )
- * fwd writes y[N, H, W, C+1] = concat(x, stat[n % M]) in one pass.
+ * fwd writes y[N, H, W, C+1] = concat(x, stat[n % M]); the statistic is reduced over position slices through
+ * `workspace` (igan_mbstd_workspace_floats(N,H,W,C,G) floats, fixed order).
  * bwd takes dy[N,H,W,C+1] and returns dx[N,H,W,C] (pass-through + statistic path).
  */
-int igan_mbstd_fwd(igan_stream_t stream, const float* x, float* y, float* stat,
+size_t igan_mbstd_workspace_floats(int N, int H, int W, int C, int G);
+int igan_mbstd_fwd(igan_stream_t stream, const float* x, float* y, float* workspace,
                    int N, int H, int W, int C, int G);
 int igan_mbstd_bwd(igan_stream_t stream, const float* x, const float* dy, float* dx,
                    int N, int H, int W, int C, int G);

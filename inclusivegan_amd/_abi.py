@@ -134,6 +134,7 @@ SIGNATURES = {
     'igan_lpips_layer_blocks': (_I, [_I, _I]),
     'igan_lpips_layer_fwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I]),
     'igan_lpips_layer_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I]),
+    'igan_mbstd_workspace_floats': (_SZ, [_I, _I, _I, _I, _I]),
     'igan_mbstd_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I]),
     'igan_mbstd_bwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I]),
     'igan_row_sqnorm': (_I, [_P, _P, _P, _I, _I]),

@@ -890,7 +890,7 @@ def mbstd_fwd_raw(x, g):
     x = nhwc(x)
     n, c, h, w = x.shape
     y = empty_nchw(n, c + 1, h, w, x)
-    stat = torch.empty((n // g,), device=x.device, dtype=torch.float32)
+    stat = torch.empty((int(lib.igan_mbstd_workspace_floats(n, h, w, c, g)),), device=x.device, dtype=torch.float32)
     _abi.check(lib.igan_mbstd_fwd(_stream(), _ptr(x), _ptr(y), _ptr(stat), n, h, w, c, g))
     return y
 
