@@ -475,11 +475,19 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(ConvArgs a, int BM, int
         const int pix = row_pix[rl];
         if (pix < 0) continue;
         const int row = r0 + rl;
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int k = 0; k < a.splits; k++) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f), s2 = make_float4(0.f, 0.f, 0.f, 0.f);
+        int k = 0;
+        for (; k + 2 <= a.splits; k += 2) {     // two slices per step: their loads are in flight together (fixed order)
+            const float4 v = *reinterpret_cast<const float4*>(wst + (size_t)k * (BM * BN) + row * BN + 4 * c4);
+            const float4 u = *reinterpret_cast<const float4*>(wst + (size_t)(k + 1) * (BM * BN) + row * BN + 4 * c4);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            s2.x += u.x; s2.y += u.y; s2.z += u.z; s2.w += u.w;
+        }
+        if (k < a.splits) {
             const float4 v = *reinterpret_cast<const float4*>(wst + (size_t)k * (BM * BN) + row * BN + 4 * c4);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
+        s.x += s2.x; s.y += s2.y; s.z += s2.z; s.w += s2.w;
         const float v4[4] = {s.x, s.y, s.z, s.w};
         const int nn = row_n[rl];
 #pragma unroll
