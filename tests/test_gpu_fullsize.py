@@ -1,0 +1,133 @@
+"""Parity at the FULL sizes of the bench configuration (CelebA 128x128, config-e, minibatch_gpu 6), where the fp64 oracle
+would take minutes: size-independent properties instead of element-wise comparison with the oracle.
+
+  * adjointness  <conv(x; w), dy> == <x, dgrad(dy; w)> == <w, wgrad(x, dy)>   (the three kernels are independent
+    implementations of one bilinear form -- forward, data-gradient and weight-gradient kernels, sliced tails, thin and
+    dense special cases all have to agree on it);
+  * linearity in each argument;
+  * fused == composite (a different kernel path through the same library);
+  * upfirdn: <upfirdn(x), y> == <x, upfirdn_grad(y)>;
+  * 1-NN against torch.cdist on a slice of the queries; idempotence of the running minimum.
+Inner products are accumulated in fp64; tolerance 2e-4 relative to the magnitude sum |a||b| (fp32 kernels, K up to 4608)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dot(a, b):
+    return float((a.detach().double() * b.detach().double()).sum())
+
+
+def _close(u, v, scale, tol=2e-4):
+    assert abs(u - v) <= tol * scale, (u, v, scale)
+
+
+# (name, N, Cin, H, Cout, K, stride, up, pad, out, scales) -- the layers of config-e @128 (tools/conv_bench.py)
+LAYERS = [
+    ('G 128 Conv1', 6, 128, 128, 128, 3, 1, 1, 1, 128, True),
+    ('G 128 Conv0_up', 6, 256, 64, 128, 3, 1, 2, 2, 129, True),
+    ('G 32 Conv1 (4 calls)', 24, 512, 32, 512, 3, 1, 1, 1, 32, True),
+    ('G 4x4 Conv', 24, 512, 4, 512, 3, 1, 1, 1, 4, True),
+    ('G 128 ToRGB', 24, 128, 128, 3, 1, 1, 1, 0, 128, 'in'),
+    ('D 128 Conv0', 12, 128, 128, 128, 3, 1, 1, 1, 128, False),
+    ('D 128 Conv1_down', 12, 128, 131, 256, 3, 2, 1, 0, 65, False),
+    ('D 128 Skip', 12, 128, 129, 256, 1, 2, 1, 0, 65, False),
+    ('D 128 FromRGB', 12, 3, 128, 128, 1, 1, 1, 0, 128, False),
+    ('VGG conv1_1', 18, 3, 128, 64, 3, 1, 1, 1, 128, False),
+    ('VGG conv3_2', 18, 256, 32, 256, 3, 1, 1, 1, 32, False),
+    ('mapping dense', 24, 512, 1, 512, 1, 1, 1, 0, 1, False),
+    ('D dense 8192', 12, 8192, 1, 512, 1, 1, 1, 0, 1, False),
+]
+
+
+@pytest.mark.parametrize('layer', LAYERS, ids=[l[0] for l in LAYERS])
+def test_conv_adjointness_and_linearity_full_size(layer, cuda_device):
+    from inclusivegan_amd import hip_ops
+    name, N, Cin, H, Cout, K, stride, up, pad, out, scales = layer
+    g = torch.Generator(device='cpu').manual_seed(len(name) * 977 + N)
+    dev = cuda_device
+    cl = lambda t: t.to(dev).contiguous(memory_format=torch.channels_last)
+    x = cl(torch.randn(N, Cin, H, H, generator=g)); x2 = cl(torch.randn(N, Cin, H, H, generator=g))
+    w = (torch.randn(K, K, Cin, Cout, generator=g) / (K * K * Cin) ** 0.5).to(dev)
+    dy = cl(torch.randn(N, Cout, out, out, generator=g))
+    s = (torch.rand(N, Cin, generator=g) + 0.5).to(dev) if scales else None
+    d = (torch.rand(N, Cout, generator=g) + 0.5).to(dev) if scales is True else None
+    geom = hip_ops.ConvGeom(K, K, stride, up, pad, pad, 0.61)
+    y = hip_ops.conv2d_raw(x, w, geom, (out, out), Cout, in_scale=s, out_scale=d)
+    assert tuple(y.shape) == (N, Cout, out, out) and bool(torch.isfinite(y).all())
+    # the adjoint kernels of the same bilinear form  y = alpha * d * conv(x * s, w)
+    dyd = dy * d[:, :, None, None] if d is not None else dy
+    dxs = hip_ops.conv2d_raw(dyd, w, hip_ops.dgrad_geom(geom), (H, H), Cin, w_transposed=True)
+    dx = dxs * s[:, :, None, None] if s is not None else dxs
+    dw = hip_ops.conv2d_wgrad_raw(x, dy, geom, in_scale=s, out_scale=d)
+    lhs = _dot(y, dy)
+    scale = float(y.double().norm() * dy.double().norm())
+    _close(lhs, _dot(x, dx), scale)
+    _close(lhs, _dot(w, dw), scale)
+    # linearity in x (same weights, scales): conv(2x - 3x2) = 2 conv(x) - 3 conv(x2)
+    y2 = hip_ops.conv2d_raw(x2, w, geom, (out, out), Cout, in_scale=s, out_scale=d)
+    y3 = hip_ops.conv2d_raw(2.0 * x - 3.0 * x2, w, geom, (out, out), Cout, in_scale=s, out_scale=d)
+    err = float((y3 - (2.0 * y - 3.0 * y2)).abs().max() / (y3.abs().max() + 1e-30))
+    assert err < 5e-5, err
+    # fused scales == scales applied outside the kernel (a different path through the same kernels)
+    if s is not None:
+        yc = hip_ops.conv2d_raw(x * s[:, :, None, None], w, geom, (out, out), Cout)
+        if d is not None:
+            yc = yc * d[:, :, None, None]
+        assert float((y - yc).abs().max() / (yc.abs().max() + 1e-30)) < 5e-5
+
+
+def test_torgb_and_dense_against_torch_einsum_full_size(cuda_device):
+    """The thin-channel and small-batch dense kernels against torch's own matmul on the device (fp32, same inputs)."""
+    from inclusivegan_amd import hip_ops
+    dev = cuda_device
+    g = torch.Generator(device='cpu').manual_seed(3)
+    x = torch.randn(24, 128, 128, 128, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(1, 1, 128, 3, generator=g) / 128 ** 0.5).to(dev)
+    s = (torch.rand(24, 128, generator=g) + 0.5).to(dev)
+    y = hip_ops.conv2d_raw(x, w, hip_ops.ConvGeom(1, 1, 1, 1, 0, 0), (128, 128), 3, in_scale=s)
+    ref = torch.einsum('nchw,co->nohw', x.double() * s.double()[:, :, None, None], w.double()[0, 0])
+    assert float((y.double() - ref).abs().max() / ref.abs().max()) < 1e-5
+    z = torch.randn(24, 512, generator=g).to(dev); a = (torch.randn(512, 512, generator=g) / 512 ** 0.5).to(dev)
+    assert float((hip_ops.matmul(z, a, alpha=0.5).double() - 0.5 * z.double() @ a.double()).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize('case', [(6, 129, 128, 1, 1, 1, 1), (12, 128, 128, 1, 1, 2, 2), (6, 64, 3, 2, 1, 2, 1), (6, 128, 3, 1, 2, 1, 2)])
+def test_upfirdn_adjoint_full_size(case, cuda_device):
+    """<upfirdn(x), y> == <x, d upfirdn(x) / dx applied to y> at the 128x128 call sites (FIR after the up-conv, before the
+    strided convs, RGB up / down sampling)."""
+    from inclusivegan_amd.dnnlib.tflib.ops.upfirdn_2d import _setup_kernel, _simple_upfirdn_2d
+    B, H, C, up, down, p0, p1 = case
+    dev = cuda_device
+    g = torch.Generator(device='cpu').manual_seed(H + C)
+    x = torch.randn(B, C, H, H, generator=g).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    k = _setup_kernel([1, 3, 3, 1]) * (up ** 2)
+    y = _simple_upfirdn_2d(x, k, up=up, down=down, pad0=p0, pad1=p1, data_format='NCHW')
+    dy = torch.randn(y.shape, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    (dx,) = torch.autograd.grad(y, x, dy)
+    _close(_dot(y, dy), _dot(x.detach(), dx), float(y.double().norm() * dy.double().norm()), 1e-5)
+
+
+def test_nn1_against_cdist_and_idempotence(cuda_device):
+    """CelebA-sized rows (49 152 dims): the streaming 1-NN equals torch.cdist's argmin on a slice of the queries, and
+    folding the same candidates twice leaves the running minimum unchanged."""
+    from inclusivegan_amd import hip_ops
+    from inclusivegan_amd.dci_code.dci import unpack_best
+    dev = cuda_device
+    g = torch.Generator(device='cpu').manual_seed(11)
+    dim, nq, nc = 49152, 1024, 512
+    q = torch.rand(nq, dim, generator=g).to(dev) * 2 - 1
+    c = torch.rand(nc, dim, generator=g).to(dev) * 2 - 1
+    qn = hip_ops.row_sqnorm_raw(q); cn = hip_ops.row_sqnorm_raw(c)
+    best = torch.full((nq,), -1, device=dev, dtype=torch.int64)
+    hip_ops.nn1_update_raw(q, qn, c, cn, best, 0)
+    once = best.clone()
+    hip_ops.nn1_update_raw(q, qn, c, cn, best, 0)
+    assert torch.equal(best, once)
+    idx, dist = unpack_best(best)
+    ref = torch.cdist(q[:128].double(), c.double())
+    rd, ri = ref.min(dim=1)
+    assert torch.equal(idx[:128].cpu(), ri.cpu())
+    assert float((dist[:128].double().cpu() - rd.cpu()).abs().max() / rd.max()) < 1e-5
