@@ -27,8 +27,8 @@ def fused_bias_act(x, b=None, axis=1, act='linear', alpha=None, gain=None, impl=
     """y = act(x + b) * gain with `b` broadcast along `axis`.  First-order gradients for every
     activation; second-order gradients for the piecewise-linear ones (linear / relu / lrelu), which
     is what R1 and path-length regularisation need."""
-    if impl != 'hip':
-        raise ValueError("impl must be 'hip' (got %r); the CPU reference lives in oracle/ and is not a product path" % (impl,))
+    if impl not in ('hip', 'cuda'):     # 'cuda' = the reference's name for the device kernel (fused_bias_act.py:34,61-64)
+        raise ValueError("impl must be 'hip' (or the reference's 'cuda'; got %r); the CPU reference lives in oracle/ and is not a product path" % (impl,))
     spec = activation_funcs[act]
     if b is not None:
         if b.dim() != 1:

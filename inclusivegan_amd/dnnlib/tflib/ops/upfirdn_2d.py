@@ -19,12 +19,12 @@ import torch
 
 from .... import hip_ops
 
-_IMPLS = ('hip',)
+_IMPLS = ('hip', 'cuda')    # 'cuda' is the reference's name for "the device kernel" (upfirdn_2d.py:19,57-60): same path here
 
 
 def _check_impl(impl):
     if impl not in _IMPLS:
-        raise ValueError("impl must be 'hip' (got %r); the CPU reference lives in oracle/ and is not a product path" % (impl,))
+        raise ValueError("impl must be 'hip' (or the reference's 'cuda'; got %r); the CPU reference lives in oracle/ and is not a product path" % (impl,))
 
 #----------------------------------------------------------------------------
 
