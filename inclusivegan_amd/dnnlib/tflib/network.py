@@ -247,8 +247,52 @@ class Network:
         self._derived.clear()     # cached derived tensors carry the old requires_grad state
         return self
 
-    def get_var(self, name):
-        return self.vars[name]
+    def get_var_local_name(self, var_or_global_name):
+        """Local name of a variable given the tensor itself or its name (network.py:236-241)."""
+        if torch.is_tensor(var_or_global_name):
+            for name, v in self.vars.items():
+                if v is var_or_global_name:
+                    return name
+            raise KeyError('tensor is not a variable of network %r' % self.name)
+        name = str(var_or_global_name)
+        prefix = self.name + '/'
+        return name[len(prefix):] if name.startswith(prefix) else name
+
+    def find_var(self, var_or_local_name):
+        """The variable tensor for a local name (or the tensor itself) (network.py:243-246)."""
+        return var_or_local_name if torch.is_tensor(var_or_local_name) else self.vars[self.get_var_local_name(var_or_local_name)]
+
+    def get_var(self, var_or_local_name):
+        """Value of a variable as a NumPy array (network.py:248-250 evaluates the variable)."""
+        return self.find_var(var_or_local_name).detach().cpu().numpy()
+
+    def set_var(self, var_or_local_name, new_value):
+        """Overwrite a variable in place (network.py:252-255); cached weight-derived tensors are dropped."""
+        var = self.find_var(var_or_local_name)
+        with torch.no_grad():
+            var.copy_(torch.as_tensor(np.asarray(new_value), dtype=var.dtype).to(var.device).reshape(var.shape))
+        self.invalidate_derived()
+
+    def _reset(self, names):
+        """Re-run the initialisers of the given variables from the network's seed (network.py:223-233)."""
+        rng = np.random.RandomState(self.seed)
+        with torch.no_grad():
+            for name, (shape, init, trainable) in self._specs.items():
+                # draw for every variable so that a partial reset reproduces the values of a full one
+                val = (rng.standard_normal(shape) * init[1]).astype(np.float32) if init[0] == 'normal' else \
+                      np.full(shape, init[1] if init[0] == 'const' else 0.0, dtype=np.float32)
+                if name in names:
+                    self.vars[name].copy_(torch.from_numpy(val).to(self.vars[name].device).reshape(self.vars[name].shape))
+        self.invalidate_derived()
+
+    def reset_own_vars(self):
+        self._reset(set(self.vars))      # components are part of this network's bucket: same as reset_vars here
+
+    def reset_vars(self):
+        self._reset(set(self.vars))
+
+    def reset_trainables(self):
+        self._reset(set(self.trainables))
 
     def num_params(self):
         return sum(int(np.prod(v.shape)) if v.dim() else 1 for v in self.trainables.values())
@@ -256,7 +300,8 @@ class Network:
     def zero_grad(self):
         self.flat_grads.zero_()
 
-    def copy_vars_from(self, src):
+    def copy_vars_from(self, src_net):
+        src = src_net
         assert self._root is self and src._root is src
         same = list(self._offsets.items()) == list(src._offsets.items())
         self._derived.clear()
@@ -266,6 +311,18 @@ class Network:
             for name, var in self.vars.items():
                 if name in src.vars and (not same or not self._specs[name][2]):
                     var.copy_(src.vars[name])
+
+    def copy_own_vars_from(self, src_net):
+        """network.py:316-319 (components live in the same bucket here: all shared names are copied)."""
+        self.copy_vars_from(src_net)
+
+    def copy_trainables_from(self, src_net):
+        """Copy the values of all trainables present in both networks (network.py:326-329)."""
+        self._derived.clear()
+        with torch.no_grad():
+            for name, var in self.trainables.items():
+                if name in src_net.trainables:
+                    var.copy_(src_net.trainables[name])
 
     def clone(self, name=None, **new_static_kwargs):
         """network.py:301-314: same build function, same variable values."""

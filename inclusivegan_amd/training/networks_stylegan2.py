@@ -88,6 +88,18 @@ def apply_bias_act(x, act='linear', alpha=None, gain=None, lrmul=1, bias_var='bi
     return fused_bias_act(x, b=b, act=act, alpha=alpha, gain=gain)
 
 #----------------------------------------------------------------------------
+# Naive upsampling (nearest neighbor) and downsampling (average pooling) (:73-84).  Not used by config-e/f
+# (the resample_kernel paths above are); kept for the operator surface.
+
+def naive_upsample_2d(x, factor=2):
+    n, c, h, w = x.shape
+    return x.reshape(n, c, h, 1, w, 1).expand(n, c, h, factor, w, factor).reshape(n, c, h * factor, w * factor)
+
+def naive_downsample_2d(x, factor=2):
+    n, c, h, w = x.shape
+    return x.reshape(n, c, h // factor, factor, w // factor, factor).mean(dim=(3, 5))
+
+#----------------------------------------------------------------------------
 # Modulated convolution layer (:89-127).
 
 def modulated_conv2d_layer(x, y, fmaps, kernel, up=False, down=False, demodulate=True, resample_kernel=None, gain=1, use_wscale=True, lrmul=1, fused_modconv=True, weight_var='weight', mod_weight_var='mod_weight', mod_bias_var='mod_bias', init_mul=1.0):

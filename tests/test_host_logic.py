@@ -123,6 +123,31 @@ def test_random_tape_is_strict():
             tfutil.random_uniform([1], 'cpu')      # exhausted
 
 
+def test_network_variable_api_matches_reference_surface():
+    """find_var / get_var / set_var / reset_* / copy_* (dnnlib/tflib/network.py:223-255,316-329) on a CPU-built network
+    (no kernel runs: only the variable store) and the naive resamplers (networks_stylegan2.py:73-84)."""
+    from inclusivegan_amd.dnnlib import tflib
+    from inclusivegan_amd.training import networks_stylegan2 as N
+    kw = dict(num_channels=3, resolution=8, label_size=0, fmap_base=64, device='cpu')
+    D = tflib.Network('D', func_name='inclusivegan_amd.training.networks_stylegan2.D_stylegan2_feature', architecture='resnet', seed=4, **kw)
+    D2 = D.clone('D2')
+    name = next(iter(D.trainables))
+    assert D.get_var_local_name('D/' + name) == name and D.find_var(name) is D.vars[name]
+    v0 = D.get_var(name).copy()
+    D.set_var(name, v0 * 0 + 3.0)
+    assert float(D.get_var(name).mean()) == 3.0 and float(D2.get_var(name).reshape(-1)[0]) == float(v0.reshape(-1)[0])
+    D2.copy_trainables_from(D)
+    assert float(D2.get_var(name).mean()) == 3.0
+    D.reset_trainables()
+    np.testing.assert_array_equal(D.get_var(name), v0)          # same seed -> the original initial values
+    D2.copy_own_vars_from(D)
+    np.testing.assert_array_equal(D2.get_var(name), v0)
+    x = torch.arange(2 * 3 * 4 * 4, dtype=torch.float32).reshape(2, 3, 4, 4)
+    up = N.naive_upsample_2d(x)
+    assert up.shape == (2, 3, 8, 8) and torch.equal(up[:, :, ::2, ::2], x) and torch.equal(up[:, :, 1::2, 1::2], x)
+    assert torch.equal(N.naive_downsample_2d(up), x)
+
+
 # ----------------------------------------------------------------------------- world_size 2 under gloo
 def _free_port():
     s = socket.socket()
