@@ -57,6 +57,11 @@ class DCI(object):
     def num_levels(self):
         return 0 if self._data is None else 1
 
+    @property
+    def proj_vec(self):
+        """The reference exposes its random projection directions (dci.py:93-105); the exact search keeps none."""
+        raise AttributeError('this DCI is an exact on-GPU 1-NN search: it has no projection vectors')
+
     def _check_numpy(self, arr):
         if arr.ndim != 2 or arr.shape[1] != self.dim:
             raise ValueError('mismatch between array dimension (%s) and the declared dimension of this DCI instance (%d)' % (arr.shape[1:] , self.dim))
