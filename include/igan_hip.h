@@ -244,10 +244,26 @@ typedef struct igan_dense_wgrad_params {
 } igan_dense_wgrad_params;
 int igan_dense_small_wgrad(igan_stream_t stream, const igan_dense_wgrad_params* p);
 
+/* Grouped forms: `count` (<= IGAN_DENSE_MAX_GROUPS) independent problems in ONE launch -- the 18 style affines, the 12
+ * demodulations, and each stage of their backward, of one generator pass.  The groups of a dense launch share
+ * `w_transposed`; sizes may differ per group. */
+#define IGAN_DENSE_MAX_GROUPS 24
+int igan_dense_small_grouped(igan_stream_t stream, const igan_dense_params* groups, int count);
+int igan_dense_small_wgrad_grouped(igan_stream_t stream, const igan_dense_wgrad_params* groups, int count);
+
 /* out[i] = sum_t w[t*n + i]^2  (sum over the filter taps of the squared weights: the [Cin,Cout] matrix of the
  * demodulation, :105) and out[t*n + i] = scale * w[t*n + i] * v[i] (its gradient back onto the filter). */
 int igan_sumsq_taps(igan_stream_t stream, const float* w, float* out, int taps, int n);
 int igan_bcast_mul_taps(igan_stream_t stream, const float* w, const float* v, float* out, int taps, int n, float scale);
+typedef struct igan_taps_params {
+    const float* w;         /* [taps, n] */
+    const float* v;         /* bcast_mul: [n]; sumsq: unused (NULL) */
+    float* out;             /* sumsq: [n]; bcast_mul: [taps, n] */
+    int taps, n;
+    float scale;            /* bcast_mul only */
+} igan_taps_params;
+int igan_sumsq_taps_grouped(igan_stream_t stream, const igan_taps_params* groups, int count);
+int igan_bcast_mul_taps_grouped(igan_stream_t stream, const igan_taps_params* groups, int count);
 
 /* Per-sample channel dot products of two channel-minor tensors a, b [N, HW, C] (C % 4 == 0):
  *     dot[n,c] = sum_hw a[n,hw,c] * b[n,hw,c];   if out != NULL: out[n,hw,c] = b[n,hw,c] * s[n,c]

@@ -104,6 +104,12 @@ class DenseWgradParams(ctypes.Structure):
     ]
 
 
+class TapsParams(ctypes.Structure):
+    _fields_ = [('w', ctypes.c_void_p), ('v', ctypes.c_void_p), ('out', ctypes.c_void_p),
+                ('taps', ctypes.c_int), ('n', ctypes.c_int), ('scale', ctypes.c_float)]
+
+
+DENSE_MAX_GROUPS = 24
 DENSE_PRO_NONE, DENSE_PRO_SQUARE, DENSE_PRO_DEMOD_GRAD = 0, 1, 2
 DENSE_EPI_SCALE, DENSE_EPI_BIAS, DENSE_EPI_RSQRT, DENSE_EPI_STYLE_GRAD = 0, 1, 2, 3
 
@@ -127,6 +133,10 @@ SIGNATURES = {
     'igan_conv2d_wgrad': (_I, [_P, ctypes.POINTER(Conv2DWgradParams)]),
     'igan_dense_small': (_I, [_P, ctypes.POINTER(DenseParams)]),
     'igan_dense_small_wgrad': (_I, [_P, ctypes.POINTER(DenseWgradParams)]),
+    'igan_dense_small_grouped': (_I, [_P, ctypes.POINTER(DenseParams), _I]),
+    'igan_dense_small_wgrad_grouped': (_I, [_P, ctypes.POINTER(DenseWgradParams), _I]),
+    'igan_sumsq_taps_grouped': (_I, [_P, ctypes.POINTER(TapsParams), _I]),
+    'igan_bcast_mul_taps_grouped': (_I, [_P, ctypes.POINTER(TapsParams), _I]),
     'igan_sumsq_taps': (_I, [_P, _P, _P, _I, _I]),
     'igan_bcast_mul_taps': (_I, [_P, _P, _P, _P, _I, _I, _F]),
     'igan_scale_dot_workspace_floats': (_SZ, [_I, _I, _I]),

@@ -35,8 +35,16 @@ __device__ __forceinline__ float pro_apply(int pro, float v, float v2, float ps)
 // The kernel is a latency chain, not a throughput problem (1 MB of weights over >= 128 workgroups): all of a
 // super-tile's global loads -- the lane's weights and its share of x -- are issued before anything waits, so
 // the chain is  [one round of loads] -> [LDS image of x] -> [FMAs] -> [group reduce].
+// Up to IGAN_DENSE_MAX_GROUPS independent problems per launch (blockIdx.y): the 18 style affines / 12 demodulations
+// of one generator pass are one launch instead of 30.
+struct DenseGroups { igan_dense_params g[IGAN_DENSE_MAX_GROUPS]; };
+struct WgradGroups { igan_dense_wgrad_params g[IGAN_DENSE_MAX_GROUPS]; };
+struct TapsGroups { igan_taps_params g[IGAN_DENSE_MAX_GROUPS]; };
+
 template <int MB, bool WT>
-__global__ __launch_bounds__(256) void dense_small_kernel(igan_dense_params a) {
+__global__ __launch_bounds__(256) void dense_small_kernel(DenseGroups G) {
+    const igan_dense_params a = G.g[blockIdx.y];
+    if ((int)blockIdx.x * DS_COLS >= a.N) return;      // groups differ in width (uniform per workgroup)
     constexpr int RSTR = MB * DS_COLS + 4;   // group stride in the partial-sum image (bank-spread)
     constexpr int XV = MB * (DS_KS / 4) / 256;   // float4 of x per lane per super-tile
     __shared__ __attribute__((aligned(16))) float xs[MB * DS_KS];
@@ -136,7 +144,8 @@ __global__ __launch_bounds__(256) void dense_small_kernel(igan_dense_params a) {
 
 // dw[k][n] = alpha * sum_m fa(a[m][k]) * fb(b[m][n]); rows in batches of 8 whose loads are all in flight
 // together (a serial loop over m is M dependent L2 round trips).
-__global__ __launch_bounds__(256) void dense_small_wgrad_kernel(igan_dense_wgrad_params p) {
+__global__ __launch_bounds__(256) void dense_small_wgrad_kernel(WgradGroups G) {
+    const igan_dense_wgrad_params p = G.g[blockIdx.y];
     const int nv = p.N >> 2;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= p.K * nv) return;
@@ -170,7 +179,11 @@ __global__ __launch_bounds__(256) void dense_small_wgrad_kernel(igan_dense_wgrad
 }
 
 // out[i] = sum_t w[t][i]^2
-__global__ __launch_bounds__(256) void sumsq_taps_kernel(const float* __restrict__ w, float* __restrict__ out, int taps, int n4) {
+__global__ __launch_bounds__(256) void sumsq_taps_kernel(TapsGroups G) {
+    const igan_taps_params q = G.g[blockIdx.y];
+    const float* __restrict__ w = q.w;
+    float* __restrict__ out = q.out;
+    const int taps = q.taps, n4 = q.n >> 2;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -182,8 +195,13 @@ __global__ __launch_bounds__(256) void sumsq_taps_kernel(const float* __restrict
 }
 
 // out[t][i] = scale * w[t][i] * v[i]
-__global__ __launch_bounds__(256) void bcast_mul_taps_kernel(const float* __restrict__ w, const float* __restrict__ v,
-                                                             float* __restrict__ out, int taps, int n4, float scale) {
+__global__ __launch_bounds__(256) void bcast_mul_taps_kernel(TapsGroups G) {
+    const igan_taps_params q = G.g[blockIdx.y];
+    const float* __restrict__ w = q.w;
+    const float* __restrict__ v = q.v;
+    float* __restrict__ out = q.out;
+    const int taps = q.taps, n4 = q.n >> 2;
+    const float scale = q.scale;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     const float4 m = reinterpret_cast<const float4*>(v)[i];
@@ -194,10 +212,41 @@ __global__ __launch_bounds__(256) void bcast_mul_taps_kernel(const float* __rest
 }
 
 template <int MB>
-void launch_dense(hipStream_t stream, const igan_dense_params& a) {
-    const dim3 grid(igan::ceil_div(a.N, DS_COLS));
-    if (a.w_transposed) hipLaunchKernelGGL((dense_small_kernel<MB, true>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((dense_small_kernel<MB, false>), grid, dim3(256), 0, stream, a);
+void launch_dense(hipStream_t stream, const DenseGroups& G, int count, int maxN, bool wt) {
+    const dim3 grid(igan::ceil_div(maxN, DS_COLS), count);
+    if (wt) hipLaunchKernelGGL((dense_small_kernel<MB, true>), grid, dim3(256), 0, stream, G);
+    else hipLaunchKernelGGL((dense_small_kernel<MB, false>), grid, dim3(256), 0, stream, G);
+}
+
+int dense_check(const igan_dense_params* p) {
+    IGAN_REQUIRE(p->x && p->w && p->y, "dense_small: null buffer");
+    IGAN_REQUIRE(p->M >= 1 && p->M <= 32, "dense_small: 1 <= M <= 32 rows (use igan_conv2d for larger batches)");
+    IGAN_REQUIRE(p->K >= 4 && p->K % 4 == 0 && p->N >= 1, "dense_small: K must be a positive multiple of 4, N positive");
+    IGAN_REQUIRE(p->ldx >= p->K && p->ldx % 4 == 0 && p->ldy >= p->N, "dense_small: bad row strides");
+    IGAN_REQUIRE((((uintptr_t)p->x) & 15) == 0 && (!p->w_transposed || (((uintptr_t)p->w) & 15) == 0), "dense_small: x (and a transposed w) must be 16-byte aligned");
+    IGAN_REQUIRE(p->prologue >= IGAN_DENSE_PRO_NONE && p->prologue <= IGAN_DENSE_PRO_DEMOD_GRAD, "dense_small: unknown prologue");
+    IGAN_REQUIRE(p->epilogue >= IGAN_DENSE_EPI_SCALE && p->epilogue <= IGAN_DENSE_EPI_STYLE_GRAD, "dense_small: unknown epilogue");
+    IGAN_REQUIRE(p->prologue != IGAN_DENSE_PRO_DEMOD_GRAD || (p->x2 && (((uintptr_t)p->x2) & 15) == 0), "dense_small: demod-gradient prologue needs an aligned x2");
+    IGAN_REQUIRE(p->epilogue != IGAN_DENSE_EPI_BIAS || p->bias, "dense_small: bias epilogue needs a bias");
+    IGAN_REQUIRE(p->epilogue != IGAN_DENSE_EPI_STYLE_GRAD || p->e2, "dense_small: style-gradient epilogue needs e2");
+    return IGAN_OK;
+}
+
+int wgrad_check(const igan_dense_wgrad_params* p) {
+    IGAN_REQUIRE(p->a && p->b && p->dw, "dense_small_wgrad: null buffer");
+    IGAN_REQUIRE(p->M >= 1 && p->M <= 32, "dense_small_wgrad: 1 <= M <= 32 rows");
+    IGAN_REQUIRE(p->K >= 1 && p->N >= 4 && p->N % 4 == 0 && p->lda >= p->K, "dense_small_wgrad: N must be a positive multiple of 4");
+    IGAN_REQUIRE(((((uintptr_t)p->b) | ((uintptr_t)p->dw)) & 15) == 0, "dense_small_wgrad: b and dw must be 16-byte aligned");
+    IGAN_REQUIRE(p->pro_a == IGAN_DENSE_PRO_NONE || p->pro_a == IGAN_DENSE_PRO_SQUARE, "dense_small_wgrad: unknown prologue for a");
+    IGAN_REQUIRE(p->pro_b == IGAN_DENSE_PRO_NONE || (p->pro_b == IGAN_DENSE_PRO_DEMOD_GRAD && p->b2 && (((uintptr_t)p->b2) & 15) == 0), "dense_small_wgrad: bad prologue for b");
+    IGAN_REQUIRE((long long)p->K * p->N <= INT32_MAX, "dense_small_wgrad: too large");
+    return IGAN_OK;
+}
+
+int taps_check(const igan_taps_params* q, bool need_v, const char* who) {
+    IGAN_REQUIRE(q->w && q->out && (!need_v || q->v) && q->taps >= 1 && q->n >= 4 && q->n % 4 == 0, "%s: n must be a positive multiple of 4", who);
+    IGAN_REQUIRE(((((uintptr_t)q->w) | ((uintptr_t)q->v) | ((uintptr_t)q->out)) & 15) == 0, "%s: buffers must be 16-byte aligned", who);
+    return IGAN_OK;
 }
 
 }  // namespace
@@ -214,13 +263,20 @@ bool dense_small_ok(int M, int K, const void* x, const void* w, bool wt) {
 
 int dense_small_rows(int M) { return M <= 8 ? 8 : (M <= 16 ? 16 : (M <= 24 ? 24 : 32)); }
 
-void dense_small_launch(hipStream_t stream, const igan_dense_params& a) {
-    const int mb = dense_small_rows(a.M);
-    if (mb == 8) launch_dense<8>(stream, a);
-    else if (mb == 16) launch_dense<16>(stream, a);
-    else if (mb == 24) launch_dense<24>(stream, a);
-    else launch_dense<32>(stream, a);
+// all groups of one launch share the weight layout (w_transposed) and the row-count bucket
+void dense_small_launch_groups(hipStream_t stream, const igan_dense_params* groups, int count) {
+    DenseGroups G;
+    int maxM = 1, maxN = 1;
+    for (int i = 0; i < count; i++) { G.g[i] = groups[i]; maxM = std::max(maxM, groups[i].M); maxN = std::max(maxN, groups[i].N); }
+    const int mb = dense_small_rows(maxM);
+    const bool wt = groups[0].w_transposed != 0;
+    if (mb == 8) launch_dense<8>(stream, G, count, maxN, wt);
+    else if (mb == 16) launch_dense<16>(stream, G, count, maxN, wt);
+    else if (mb == 24) launch_dense<24>(stream, G, count, maxN, wt);
+    else launch_dense<32>(stream, G, count, maxN, wt);
 }
+
+void dense_small_launch(hipStream_t stream, const igan_dense_params& a) { dense_small_launch_groups(stream, &a, 1); }
 
 void dense_small(hipStream_t stream, const float* x, const float* w, float* y, int M, int K, int N, bool wt, float alpha) {
     igan_dense_params a = {};
@@ -234,61 +290,82 @@ bool dense_small_wgrad_ok(int M, int N, const void* dy, const void* dw) {
     return M >= 1 && M <= 32 && (N % 4) == 0 && ((((uintptr_t)dy) | ((uintptr_t)dw)) & 15) == 0;
 }
 
+void dense_small_wgrad_groups(hipStream_t stream, const igan_dense_wgrad_params* groups, int count) {
+    WgradGroups G;
+    int maxTotal = 1;
+    for (int i = 0; i < count; i++) { G.g[i] = groups[i]; maxTotal = std::max(maxTotal, groups[i].K * (groups[i].N >> 2)); }
+    hipLaunchKernelGGL(dense_small_wgrad_kernel, dim3(ceil_div(maxTotal, 256), count), dim3(256), 0, stream, G);
+}
+
 void dense_small_wgrad(hipStream_t stream, const float* x, const float* dy, float* dw, int M, int K, int N, float alpha) {
     igan_dense_wgrad_params p = {};
     p.a = x; p.lda = K; p.b = dy; p.dw = dw; p.M = M; p.K = K; p.N = N; p.alpha = alpha;
-    const int total = K * (N >> 2);
-    hipLaunchKernelGGL(dense_small_wgrad_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, p);
+    dense_small_wgrad_groups(stream, &p, 1);
 }
 
 }  // namespace igan
 
 extern "C" int igan_dense_small(igan_stream_t stream_, const igan_dense_params* p) {
+    return igan_dense_small_grouped(stream_, p, 1);
+}
+
+extern "C" int igan_dense_small_grouped(igan_stream_t stream_, const igan_dense_params* groups, int count) {
     using namespace igan;
-    IGAN_REQUIRE(p && p->x && p->w && p->y, "dense_small: null buffer");
-    IGAN_REQUIRE(p->M >= 1 && p->M <= 32, "dense_small: 1 <= M <= 32 rows (use igan_conv2d for larger batches)");
-    IGAN_REQUIRE(p->K >= 4 && p->K % 4 == 0 && p->N >= 1, "dense_small: K must be a positive multiple of 4, N positive");
-    IGAN_REQUIRE(p->ldx >= p->K && p->ldx % 4 == 0 && p->ldy >= p->N, "dense_small: bad row strides");
-    IGAN_REQUIRE((((uintptr_t)p->x) & 15) == 0 && (!p->w_transposed || (((uintptr_t)p->w) & 15) == 0), "dense_small: x (and a transposed w) must be 16-byte aligned");
-    IGAN_REQUIRE(p->prologue >= IGAN_DENSE_PRO_NONE && p->prologue <= IGAN_DENSE_PRO_DEMOD_GRAD, "dense_small: unknown prologue");
-    IGAN_REQUIRE(p->epilogue >= IGAN_DENSE_EPI_SCALE && p->epilogue <= IGAN_DENSE_EPI_STYLE_GRAD, "dense_small: unknown epilogue");
-    IGAN_REQUIRE(p->prologue != IGAN_DENSE_PRO_DEMOD_GRAD || (p->x2 && (((uintptr_t)p->x2) & 15) == 0), "dense_small: demod-gradient prologue needs an aligned x2");
-    IGAN_REQUIRE(p->epilogue != IGAN_DENSE_EPI_BIAS || p->bias, "dense_small: bias epilogue needs a bias");
-    IGAN_REQUIRE(p->epilogue != IGAN_DENSE_EPI_STYLE_GRAD || p->e2, "dense_small: style-gradient epilogue needs e2");
-    dense_small_launch((hipStream_t)stream_, *p);
+    IGAN_REQUIRE(groups && count >= 1 && count <= IGAN_DENSE_MAX_GROUPS, "dense_small: 1 <= count <= %d groups", IGAN_DENSE_MAX_GROUPS);
+    for (int i = 0; i < count; i++) {
+        if (int rc = dense_check(&groups[i])) return rc;
+        IGAN_REQUIRE((groups[i].w_transposed != 0) == (groups[0].w_transposed != 0), "dense_small: the groups of one launch share w_transposed");
+    }
+    dense_small_launch_groups((hipStream_t)stream_, groups, count);
     IGAN_LAUNCH_CHECK("dense_small launch");
     return IGAN_OK;
 }
 
 extern "C" int igan_dense_small_wgrad(igan_stream_t stream_, const igan_dense_wgrad_params* p) {
+    return igan_dense_small_wgrad_grouped(stream_, p, 1);
+}
+
+extern "C" int igan_dense_small_wgrad_grouped(igan_stream_t stream_, const igan_dense_wgrad_params* groups, int count) {
     using namespace igan;
-    IGAN_REQUIRE(p && p->a && p->b && p->dw, "dense_small_wgrad: null buffer");
-    IGAN_REQUIRE(p->M >= 1 && p->M <= 32, "dense_small_wgrad: 1 <= M <= 32 rows");
-    IGAN_REQUIRE(p->K >= 1 && p->N >= 4 && p->N % 4 == 0 && p->lda >= p->K, "dense_small_wgrad: N must be a positive multiple of 4");
-    IGAN_REQUIRE(((((uintptr_t)p->b) | ((uintptr_t)p->dw)) & 15) == 0, "dense_small_wgrad: b and dw must be 16-byte aligned");
-    IGAN_REQUIRE(p->pro_a == IGAN_DENSE_PRO_NONE || p->pro_a == IGAN_DENSE_PRO_SQUARE, "dense_small_wgrad: unknown prologue for a");
-    IGAN_REQUIRE(p->pro_b == IGAN_DENSE_PRO_NONE || (p->pro_b == IGAN_DENSE_PRO_DEMOD_GRAD && p->b2 && (((uintptr_t)p->b2) & 15) == 0), "dense_small_wgrad: bad prologue for b");
-    IGAN_REQUIRE((long long)p->K * p->N <= INT32_MAX, "dense_small_wgrad: too large");
-    const int total = p->K * (p->N >> 2);
-    hipLaunchKernelGGL(dense_small_wgrad_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream_, *p);
+    IGAN_REQUIRE(groups && count >= 1 && count <= IGAN_DENSE_MAX_GROUPS, "dense_small_wgrad: 1 <= count <= %d groups", IGAN_DENSE_MAX_GROUPS);
+    for (int i = 0; i < count; i++)
+        if (int rc = wgrad_check(&groups[i])) return rc;
+    dense_small_wgrad_groups((hipStream_t)stream_, groups, count);
     IGAN_LAUNCH_CHECK("dense_small_wgrad launch");
     return IGAN_OK;
 }
 
-extern "C" int igan_sumsq_taps(igan_stream_t stream_, const float* w, float* out, int taps, int n) {
+static int taps_launch(igan_stream_t stream_, const igan_taps_params* groups, int count, bool mul, const char* who) {
     using namespace igan;
-    IGAN_REQUIRE(w && out && taps >= 1 && n >= 4 && n % 4 == 0, "sumsq_taps: n must be a positive multiple of 4");
-    IGAN_REQUIRE(((((uintptr_t)w) | ((uintptr_t)out)) & 15) == 0, "sumsq_taps: buffers must be 16-byte aligned");
-    hipLaunchKernelGGL(sumsq_taps_kernel, dim3(ceil_div(n / 4, 256)), dim3(256), 0, (hipStream_t)stream_, w, out, taps, n / 4);
-    IGAN_LAUNCH_CHECK("sumsq_taps launch");
+    IGAN_REQUIRE(groups && count >= 1 && count <= IGAN_DENSE_MAX_GROUPS, "%s: 1 <= count <= %d groups", who, IGAN_DENSE_MAX_GROUPS);
+    TapsGroups G;
+    int maxn4 = 1;
+    for (int i = 0; i < count; i++) {
+        if (int rc = taps_check(&groups[i], mul, who)) return rc;
+        G.g[i] = groups[i];
+        maxn4 = std::max(maxn4, groups[i].n / 4);
+    }
+    const dim3 grid(ceil_div(maxn4, 256), count);
+    if (mul) hipLaunchKernelGGL(bcast_mul_taps_kernel, grid, dim3(256), 0, (hipStream_t)stream_, G);
+    else hipLaunchKernelGGL(sumsq_taps_kernel, grid, dim3(256), 0, (hipStream_t)stream_, G);
+    IGAN_LAUNCH_CHECK(who);
     return IGAN_OK;
 }
 
+extern "C" int igan_sumsq_taps(igan_stream_t stream_, const float* w, float* out, int taps, int n) {
+    igan_taps_params q = {w, nullptr, out, taps, n, 1.0f};
+    return taps_launch(stream_, &q, 1, false, "sumsq_taps");
+}
+
 extern "C" int igan_bcast_mul_taps(igan_stream_t stream_, const float* w, const float* v, float* out, int taps, int n, float scale) {
-    using namespace igan;
-    IGAN_REQUIRE(w && v && out && taps >= 1 && n >= 4 && n % 4 == 0, "bcast_mul_taps: n must be a positive multiple of 4");
-    IGAN_REQUIRE(((((uintptr_t)w) | ((uintptr_t)v) | ((uintptr_t)out)) & 15) == 0, "bcast_mul_taps: buffers must be 16-byte aligned");
-    hipLaunchKernelGGL(bcast_mul_taps_kernel, dim3(ceil_div(n / 4, 256)), dim3(256), 0, (hipStream_t)stream_, w, v, out, taps, n / 4, scale);
-    IGAN_LAUNCH_CHECK("bcast_mul_taps launch");
-    return IGAN_OK;
+    igan_taps_params q = {w, v, out, taps, n, scale};
+    return taps_launch(stream_, &q, 1, true, "bcast_mul_taps");
+}
+
+extern "C" int igan_sumsq_taps_grouped(igan_stream_t stream_, const igan_taps_params* groups, int count) {
+    return taps_launch(stream_, groups, count, false, "sumsq_taps");
+}
+
+extern "C" int igan_bcast_mul_taps_grouped(igan_stream_t stream_, const igan_taps_params* groups, int count) {
+    return taps_launch(stream_, groups, count, true, "bcast_mul_taps");
 }

@@ -138,6 +138,19 @@ class Network:
             root._derived[k] = v
         return v
 
+    def derived_many(self, keys, fn_many):
+        """`derived` for several keys at once: `fn_many(indices)` computes the missing ones together (one grouped
+        launch for the sum-of-squares matrices of all modulated layers)."""
+        root = self._root
+        if root._derived_depth == 0 or root._templating or root.device.type == 'meta':
+            return fn_many(list(range(len(keys))))
+        ks = [(self._prefix, k, torch.is_grad_enabled()) for k in keys]
+        missing = [i for i, k in enumerate(ks) if root._derived.get(k) is None]
+        if missing:
+            for i, v in zip(missing, fn_many(missing)):
+                root._derived[ks[i]] = v
+        return [root._derived[k] for k in ks]
+
     def derived_scope(self):
         """Context manager delimiting one training op: variables must not change inside it."""
         import contextlib

@@ -85,6 +85,13 @@ def derived(key, fn):
         return fn()
     return st.store.derived('/'.join(st.scopes + [key]), fn)
 
+def derived_many(keys, fn_many):
+    """Several `derived` entries at once (see Network.derived_many); keys are relative to the current scope."""
+    st = _stack()
+    if st.store is None:
+        return fn_many(list(range(len(keys))))
+    return st.store.derived_many(['/'.join(st.scopes + [k]) for k in keys], fn_many)
+
 #----------------------------------------------------------------------------
 # Random source.  Default: torch device generator.  Tests install a RandomTape that replays
 # recorded tensors in call order, and can record what the default source produced.

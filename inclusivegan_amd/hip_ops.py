@@ -814,6 +814,175 @@ class StyleModFn(torch.autograd.Function):
         return dy, da_w, da_b, dw, None, None, None
 
 
+def _dense_group(x, w, y, w_transposed=False, alpha=1.0, prologue=_abi.DENSE_PRO_NONE, x2=None, pro_scale=0.0,
+                 epilogue=_abi.DENSE_EPI_SCALE, bias=None, bias_scale=1.0, add_const=0.0, eps=0.0, e1=None, e2=None, colsum=None):
+    m, k = x.shape
+    n = y.shape[1]
+    return _abi.DenseParams(x=x.data_ptr(), x2=_ptr(x2), w=w.data_ptr(), y=y.data_ptr(), bias=_ptr(bias), e1=_ptr(e1), e2=_ptr(e2),
+                            colsum=_ptr(colsum), ldx=x.stride(0), ldy=n, M=m, K=k, N=n, w_transposed=1 if w_transposed else 0,
+                            prologue=prologue, epilogue=epilogue, alpha=float(alpha), pro_scale=float(pro_scale),
+                            bias_scale=float(bias_scale), add_const=float(add_const), eps=float(eps))
+
+
+def dense_small_grouped_raw(groups):
+    """One launch for a list of igan_dense_params (include/igan_hip.h igan_dense_small_grouped)."""
+    lib = _abi.get_plugin()
+    arr = (_abi.DenseParams * len(groups))(*groups)
+    _abi.check(lib.igan_dense_small_grouped(_stream(), arr, len(groups)))
+
+
+def _wgrad_group(a, b, dw, alpha=1.0, pro_a=_abi.DENSE_PRO_NONE, pro_b=_abi.DENSE_PRO_NONE, b2=None, pro_scale=0.0):
+    m, k = a.shape
+    return _abi.DenseWgradParams(a=a.data_ptr(), b=b.data_ptr(), b2=_ptr(b2), dw=dw.data_ptr(), lda=a.stride(0), M=m, K=k, N=b.shape[1],
+                                 pro_a=pro_a, pro_b=pro_b, alpha=float(alpha), pro_scale=float(pro_scale))
+
+
+def dense_small_wgrad_grouped_raw(groups):
+    lib = _abi.get_plugin()
+    arr = (_abi.DenseWgradParams * len(groups))(*groups)
+    _abi.check(lib.igan_dense_small_wgrad_grouped(_stream(), arr, len(groups)))
+
+
+def sumsq_taps_grouped_raw(ws):
+    """[KH,KW,Cin,Cout] -> [Cin,Cout] for a list of filters, one launch."""
+    lib = _abi.get_plugin()
+    ws = [w.contiguous() for w in ws]
+    outs = [torch.empty(tuple(w.shape[2:]), device=w.device, dtype=torch.float32) for w in ws]
+    arr = (_abi.TapsParams * len(ws))(*[_abi.TapsParams(w=w.data_ptr(), v=None, out=o.data_ptr(), taps=w.shape[0] * w.shape[1], n=o.numel(), scale=1.0)
+                                         for w, o in zip(ws, outs)])
+    _abi.check(lib.igan_sumsq_taps_grouped(_stream(), arr, len(ws)))
+    return outs
+
+
+def bcast_mul_taps_grouped_raw(ws, vs, scale):
+    lib = _abi.get_plugin()
+    ws = [w.contiguous() for w in ws]
+    outs = [torch.empty_like(w) for w in ws]
+    arr = (_abi.TapsParams * len(ws))(*[_abi.TapsParams(w=w.data_ptr(), v=v.data_ptr(), out=o.data_ptr(), taps=w.shape[0] * w.shape[1], n=v.numel(), scale=float(scale))
+                                         for w, v, o in zip(ws, vs, outs)])
+    _abi.check(lib.igan_bcast_mul_taps_grouped(_stream(), arr, len(ws)))
+    return outs
+
+
+class StyleModAllFn(torch.autograd.Function):
+    """StyleModFn for ALL modulated layers of one synthesis pass at once (they depend on the latents and the weights only,
+    not on the activations): forward = one grouped launch for the style affines + one for the demodulations, backward = five
+    grouped launches, instead of 2 and 5 per layer.  `cfg` is a list of (c_a, c_w, demodulate) per layer; the tensor
+    arguments are, per layer, (y, a_w, a_b, w, wsq) with w / wsq None where there is no demodulation.  Returns the
+    styles of all layers followed by the demodulation coefficients of the demodulated ones."""
+
+    @staticmethod
+    def forward(ctx, cfg, *tensors):
+        L = len(cfg)
+        layers = [tensors[5 * i:5 * i + 5] for i in range(L)]
+        ys = [_row_major(t[0]) for t in layers]
+        dev = ys[0].device
+        ss = [torch.empty((ys[i].shape[0], layers[i][1].shape[1]), device=dev, dtype=torch.float32) for i in range(L)]
+        a_ws = [t[1].contiguous() for t in layers]
+        a_bs = [t[2].contiguous() for t in layers]
+        dense_small_grouped_raw([_dense_group(ys[i], a_ws[i], ss[i], alpha=cfg[i][0], epilogue=_abi.DENSE_EPI_BIAS, bias=a_bs[i], add_const=1.0)
+                                 for i in range(L)])
+        dem = [i for i in range(L) if cfg[i][2]]
+        ds = {i: torch.empty((ys[i].shape[0], layers[i][3].shape[3]), device=dev, dtype=torch.float32) for i in dem}
+        if dem:
+            dense_small_grouped_raw([_dense_group(ss[i], layers[i][4], ds[i], alpha=cfg[i][1] ** 2, prologue=_abi.DENSE_PRO_SQUARE,
+                                                  epilogue=_abi.DENSE_EPI_RSQRT, eps=1e-8) for i in dem])
+        ctx.cfg, ctx.dem = cfg, dem
+        ctx.save_for_backward(*tensors, *ss, *[ds[i] for i in dem])
+        return tuple(ss) + tuple(ds[i] for i in dem)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        cfg, dem = ctx.cfg, ctx.dem
+        L = len(cfg)
+        saved = ctx.saved_tensors
+        layers = [saved[5 * i:5 * i + 5] for i in range(L)]
+        ss = saved[5 * L:6 * L]
+        dmap = {i: saved[6 * L + j] for j, i in enumerate(dem)}
+        gss = list(grads[:L])
+        gds = {i: grads[L + j] for j, i in enumerate(dem)}
+        out = [None] * (5 * L)
+        if torch.is_grad_enabled():
+            # differentiable per-layer composite (second-order gradients)
+            for i in range(L):
+                y, a_w, a_b, w, _ = layers[i]
+                need = [_needed(ctx, 1 + 5 * i + j) for j in range(4)]
+                need[3] = need[3] and cfg[i][2]
+                if not any(need) or (gss[i] is None and gds.get(i) is None):
+                    continue
+                with torch.enable_grad():
+                    sc, dc = style_mod_composite(y, a_w, a_b, w, cfg[i][0], cfg[i][1], cfg[i][2])
+                    outs, gouts = [sc], [gss[i] if gss[i] is not None else torch.zeros_like(sc)]
+                    if dc is not None and gds.get(i) is not None:
+                        outs.append(dc); gouts.append(gds[i])
+                    ins = [t for t, nd in zip((y, a_w, a_b, w), need) if nd]
+                    gr = list(torch.autograd.grad(outs, ins, gouts, create_graph=True, allow_unused=True))
+                for j in range(4):
+                    if need[j]:
+                        out[5 * i + j] = gr.pop(0)
+            return (None, *out)
+        dev = ss[0].device
+        m = ss[0].shape[0]
+        gss = [g.contiguous() if g is not None else torch.zeros_like(ss[i]) for i, g in enumerate(gss)]
+        # 1. style gradients through the demodulation (+ bias gradients as column sums)
+        dss = list(gss)
+        dbs = [None] * L
+        act = [i for i in dem if gds.get(i) is not None]
+        if act:
+            groups = []
+            for i in act:
+                dss[i] = torch.empty_like(ss[i])
+                dbs[i] = torch.empty((ss[i].shape[1],), device=dev, dtype=torch.float32)
+                groups.append(_dense_group(gds[i].contiguous(), layers[i][4], dss[i], w_transposed=True, prologue=_abi.DENSE_PRO_DEMOD_GRAD,
+                                           x2=dmap[i], pro_scale=-0.5 * cfg[i][1] ** 2, epilogue=_abi.DENSE_EPI_STYLE_GRAD, e1=gss[i], e2=ss[i],
+                                           bias_scale=1.0, colsum=dbs[i]))
+            dense_small_grouped_raw(groups)
+            # 2./3. d wsq and its spread onto the filter taps
+            dwsqs = [torch.empty_like(layers[i][4]) for i in act]
+            dense_small_wgrad_grouped_raw([_wgrad_group(ss[i], gds[i].contiguous(), dwsqs[j], pro_a=_abi.DENSE_PRO_SQUARE, pro_b=_abi.DENSE_PRO_DEMOD_GRAD,
+                                                        b2=dmap[i], pro_scale=-0.5 * cfg[i][1] ** 2) for j, i in enumerate(act)])
+            dws = bcast_mul_taps_grouped_raw([layers[i][3] for i in act], dwsqs, 2.0)
+            for j, i in enumerate(act):
+                out[5 * i + 3] = dws[j]
+        for i in range(L):
+            if dbs[i] is None:
+                dbs[i] = dss[i].sum(dim=0)
+            out[5 * i + 2] = dbs[i]
+        # 4. latent gradients, 5. affine weight gradients
+        ys = [_row_major(layers[i][0]) for i in range(L)]
+        dys = [torch.empty((m, ys[i].shape[1]), device=dev, dtype=torch.float32) for i in range(L)]
+        a_ws = [layers[i][1].contiguous() for i in range(L)]
+        dense_small_grouped_raw([_dense_group(dss[i], a_ws[i], dys[i], w_transposed=True, alpha=cfg[i][0]) for i in range(L)])
+        das = [torch.empty_like(a_ws[i]) for i in range(L)]
+        dense_small_wgrad_grouped_raw([_wgrad_group(ys[i], dss[i], das[i], alpha=cfg[i][0]) for i in range(L)])
+        for i in range(L):
+            out[5 * i + 0] = dys[i]
+            out[5 * i + 1] = das[i]
+        return (None, *out)
+
+
+_STYLE_GROUPED = os.environ.get('IGAN_STYLE_GROUPED', '1') != '0'      # A/B switch
+
+
+def style_mod_all(layers):
+    """layers: list of dicts (y, a_w, a_b, w, wsq, c_a, c_w, demodulate).  Returns a list of (s, d) or None when the grouped
+    kernels do not apply (sizes, second-order context, more than IGAN_DENSE_MAX_GROUPS layers)."""
+    if not _STYLE_GROUPED or _second_order_depth > 0 or not layers or len(layers) > _abi.DENSE_MAX_GROUPS:
+        return None
+    for l in layers:
+        if _is_meta(l['y']) or not style_mod_fusable(l['y'], l['a_w'], l['w'], l['demodulate']):
+            return None
+    cfg = [(l['c_a'], l['c_w'], bool(l['demodulate'])) for l in layers]
+    flat = []
+    for l in layers:
+        flat += [l['y'], l['a_w'], l['a_b'], l['w'] if l['demodulate'] else None, l['wsq'] if l['demodulate'] else None]
+    res = StyleModAllFn.apply(cfg, *flat)
+    L = len(layers)
+    dem = [i for i in range(L) if cfg[i][2]]
+    dmap = {i: res[L + j] for j, i in enumerate(dem)}
+    return [(res[i], dmap.get(i)) for i in range(L)]
+
+
 def style_mod(y, a_w, a_b, w, wsq, c_a, c_w, demodulate):
     """Dispatch: fused kernels when the sizes allow, the differentiable composite otherwise."""
     if _is_meta(y):

@@ -100,6 +100,43 @@ def naive_downsample_2d(x, factor=2):
     return x.reshape(n, c, h // factor, factor, w // factor, factor).mean(dim=(3, 5))
 
 #----------------------------------------------------------------------------
+# Styles of a whole synthesis pass.  s = A(w_lat) + b + 1 and d = rsqrt(s^2 . sum_kk w^2 + 1e-8) of every modulated layer
+# (:99-107) depend on the latents and the weights only, so G_synthesis computes them for all its layers up front in grouped
+# launches (hip_ops.style_mod_all) and the layers pick theirs up by variable scope.
+
+_STYLE_CACHE = []       # stack of {scope: (s, d)} of the synthesis passes being built
+
+def _precompute_styles(specs, dlatents, init_mul):
+    """specs: list of (scope path, layer index, cin, fmaps, kernel, demodulate) in call order."""
+    layers = []
+    for scope, idx, cin, fmaps, kernel, demod in specs:
+        names = scope.split('/')
+        ctxs = [variable_scope(n) for n in names]
+        for c in ctxs:
+            c.__enter__()
+        try:
+            w, coef = get_weight([kernel, kernel, cin, fmaps], init_mul=init_mul)
+            a_w, a_coef = get_weight([int(dlatents[idx].shape[1]), cin], weight_var='mod_weight', init_mul=init_mul)
+            a_b = get_variable('mod_bias', shape=[cin], initializer=('zeros',))
+        finally:
+            for c in reversed(ctxs):
+                c.__exit__(None, None, None)
+        layers.append(dict(scope=scope, y=dlatents[idx], a_w=a_w, a_b=a_b, w=w, wsq=None, c_a=a_coef, c_w=coef, demodulate=demod))
+    if any(hip_ops._is_meta(l['y']) or not hip_ops.style_mod_fusable(l['y'], l['a_w'], l['w'], l['demodulate']) for l in layers):
+        return None
+    dem = [l for l in layers if l['demodulate']]
+    if dem:
+        def _sumsq_many(missing):
+            with torch.no_grad():
+                return hip_ops.sumsq_taps_grouped_raw([dem[i]['w'] for i in missing])
+        for l, v in zip(dem, tfutil.derived_many([l['scope'] + '/weight:sumsq' for l in dem], _sumsq_many)):
+            l['wsq'] = v
+    res = hip_ops.style_mod_all(layers)
+    if res is None:
+        return None
+    return {l['scope']: sd for l, sd in zip(layers, res)}
+
+#----------------------------------------------------------------------------
 # Modulated convolution layer (:89-127).
 
 def modulated_conv2d_layer(x, y, fmaps, kernel, up=False, down=False, demodulate=True, resample_kernel=None, gain=1, use_wscale=True, lrmul=1, fused_modconv=True, weight_var='weight', mod_weight_var='mod_weight', mod_bias_var='mod_bias', init_mul=1.0):
@@ -113,15 +150,19 @@ def modulated_conv2d_layer(x, y, fmaps, kernel, up=False, down=False, demodulate
 
     # Modulate: s = A(y) + b + 1 (:99-101); demodulate: d[b,o] = rsqrt(sum_{k,k,i} (w*s)^2 + 1e-8)
     # = rsqrt((s^2) @ (sum_kk w^2) + 1e-8) (:105-107) -- both in hip_ops.style_mod (two launches).
-    a_w, a_coef = get_weight([int(y.shape[1]), cin], weight_var=mod_weight_var, init_mul=init_mul)
-    a_b = get_variable(mod_bias_var, shape=[cin], initializer=('zeros',))
-    wsq = None
-    if demodulate and not hip_ops._is_meta(y) and hip_ops.style_mod_fusable(y, a_w, w, True):
-        def _sumsq():
-            with torch.no_grad():
-                return hip_ops.sumsq_taps_raw(w)                   # [I,O] of the raw weights, once per training op
-        wsq = tfutil.derived(weight_var + ':sumsq', _sumsq)
-    s, d = hip_ops.style_mod(y, a_w, a_b, w, wsq, a_coef, coef, demodulate)
+    pre = _STYLE_CACHE[-1].get(tfutil.current_scope()) if _STYLE_CACHE else None
+    if pre is not None:
+        s, d = pre                      # computed for all layers of this synthesis pass in grouped launches
+    else:
+        a_w, a_coef = get_weight([int(y.shape[1]), cin], weight_var=mod_weight_var, init_mul=init_mul)
+        a_b = get_variable(mod_bias_var, shape=[cin], initializer=('zeros',))
+        wsq = None
+        if demodulate and not hip_ops._is_meta(y) and hip_ops.style_mod_fusable(y, a_w, w, True):
+            def _sumsq():
+                with torch.no_grad():
+                    return hip_ops.sumsq_taps_raw(w)                   # [I,O] of the raw weights, once per training op
+            wsq = tfutil.derived(weight_var + ':sumsq', _sumsq)
+        s, d = hip_ops.style_mod(y, a_w, a_b, w, wsq, a_coef, coef, demodulate)
 
     # Convolution with optional up/downsampling; scales folded into the kernel.
     H, W = int(x.shape[2]), int(x.shape[3])
@@ -373,25 +414,42 @@ def G_synthesis_stylegan2(
             t = apply_bias_act(modulated_conv2d_layer(x, dlatents_in[res*2-3], fmaps=num_channels, kernel=1, demodulate=False, fused_modconv=fused_modconv, init_mul=init_mul))
             return t if y is None else y + t
 
-    # Early layers (:380-388).
-    y = None
-    with variable_scope('4x4'):
-        with variable_scope('Const'):
-            x = get_variable('const', shape=[1, nf(1), 4, 4], initializer=('normal', 1.0))
-            x = x.expand(batch, -1, -1, -1)
-        with variable_scope('Conv'):
-            x = layer(x, layer_idx=0, fmaps=nf(1), kernel=3)
+    # Styles of all layers in grouped launches (skipped for the template pass and where the kernels do not apply).
+    styles = None
+    if not hip_ops._is_meta(dlatents_in[0]) and dlatents_in[0].is_cuda:
+        specs = [('4x4/Conv', 0, nf(1), nf(1), 3, True)]
         if architecture == 'skip':
-            y = torgb(x, y, 2)
-
-    # Main layers (:391-398).
-    for res in range(3, resolution_log2 + 1):
-        with variable_scope('%dx%d' % (2**res, 2**res)):
-            x = block(x, res)
-            if architecture == 'skip':
-                y = upsample(y)
+            specs.append(('4x4/ToRGB', 1, nf(1), num_channels, 1, False))
+        for res in range(3, resolution_log2 + 1):
+            r = '%dx%d' % (2**res, 2**res)
+            specs.append((r + '/Conv0_up', res*2-5, nf(res-2), nf(res-1), 3, True))
+            specs.append((r + '/Conv1', res*2-4, nf(res-1), nf(res-1), 3, True))
             if architecture == 'skip' or res == resolution_log2:
-                y = torgb(x, y, res)
+                specs.append((r + '/ToRGB', res*2-3, nf(res-1), num_channels, 1, False))
+        styles = _precompute_styles(specs, dlatents_in, init_mul)
+    _STYLE_CACHE.append(styles or {})
+    try:
+        # Early layers (:380-388).
+        y = None
+        with variable_scope('4x4'):
+            with variable_scope('Const'):
+                x = get_variable('const', shape=[1, nf(1), 4, 4], initializer=('normal', 1.0))
+                x = x.expand(batch, -1, -1, -1)
+            with variable_scope('Conv'):
+                x = layer(x, layer_idx=0, fmaps=nf(1), kernel=3)
+            if architecture == 'skip':
+                y = torgb(x, y, 2)
+
+        # Main layers (:391-398).
+        for res in range(3, resolution_log2 + 1):
+            with variable_scope('%dx%d' % (2**res, 2**res)):
+                x = block(x, res)
+                if architecture == 'skip':
+                    y = upsample(y)
+                if architecture == 'skip' or res == resolution_log2:
+                    y = torgb(x, y, res)
+    finally:
+        _STYLE_CACHE.pop()
     images_out = y
     return images_out
 

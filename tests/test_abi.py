@@ -32,7 +32,8 @@ def test_struct_layouts_match_header_field_order():
     text = open(os.path.join(ROOT, 'include', 'igan_hip.h')).read()
     for cname, cls in [('igan_upfirdn2d_params', _abi.UpFirDn2DParams), ('igan_fused_bias_act_params', _abi.FusedBiasActParams),
                        ('igan_conv2d_params', _abi.Conv2DParams), ('igan_conv2d_wgrad_params', _abi.Conv2DWgradParams),
-                       ('igan_dense_params', _abi.DenseParams), ('igan_dense_wgrad_params', _abi.DenseWgradParams)]:
+                       ('igan_dense_params', _abi.DenseParams), ('igan_dense_wgrad_params', _abi.DenseWgradParams),
+                       ('igan_taps_params', _abi.TapsParams)]:
         body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (cname, cname), text, flags=re.S).group(1)
         body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
         names = []
@@ -46,6 +47,7 @@ def test_struct_layouts_match_header_field_order():
     # the enums the dense entry points switch on
     for name, val in re.findall(r'(IGAN_DENSE_[A-Z_]+) = (\d+)', text):
         assert getattr(_abi, name[len('IGAN_'):]) == int(val), name
+    assert _abi.DENSE_MAX_GROUPS == int(re.search(r'#define IGAN_DENSE_MAX_GROUPS (\d+)', text).group(1))
 
 
 def test_invalid_arguments_are_rejected_without_a_device():
