@@ -199,7 +199,7 @@ int igan_conv2d_wgrad_plan(const igan_conv2d_wgrad_params* p, int* splits, size_
 int igan_conv2d_wgrad(igan_stream_t stream, const igan_conv2d_wgrad_params* p);
 
 /* ------------------------------------------------------------------------
- * Small-batch dense layers with the StyleGAN2 style-path arithmetic folded in (M <= 32 rows; larger
+ * Small-batch dense layers with the StyleGAN2 style-path arithmetic folded in (M <= 64 rows; larger
  * batches go through igan_conv2d as 1x1 convolutions):
  *     y[m,n] = epi( alpha * sum_k pro(x)[m,k] * W(k,n) ),   W = w[k][n], or w[n][k] when w_transposed
  * prologue (on x, element-wise):   NONE; SQUARE x^2; DEMOD_GRAD pro_scale * x * x2^3
@@ -248,6 +248,7 @@ int igan_dense_small_wgrad(igan_stream_t stream, const igan_dense_wgrad_params* 
  * demodulations, and each stage of their backward, of one generator pass.  The groups of a dense launch share
  * `w_transposed`; sizes may differ per group. */
 #define IGAN_DENSE_MAX_GROUPS 24
+#define IGAN_DENSE_MAX_ROWS 64
 int igan_dense_small_grouped(igan_stream_t stream, const igan_dense_params* groups, int count);
 int igan_dense_small_wgrad_grouped(igan_stream_t stream, const igan_dense_wgrad_params* groups, int count);
 

@@ -1,4 +1,4 @@
-// Small-batch dense layers on gfx950: y[M,N] = f(x)[M,K] . w  for M <= 32 rows, with the surrounding
+// Small-batch dense layers on gfx950: y[M,N] = f(x)[M,K] . w  for M <= 64 rows, with the surrounding
 // per-element arithmetic of the StyleGAN2 style path folded in (networks_stylegan2.py:41-46,99-107,117:
 // the mapping network and, per synthesis layer, the style affine  s = A(w_lat) + b + 1  and the
 // demodulation coefficients  d = rsqrt(s^2 . sum_taps(w^2) + 1e-8)  -- 38 small matmuls per generator
@@ -23,8 +23,8 @@ namespace {
 
 constexpr int DS_COLS = 4;                   // output channels per workgroup
 constexpr int DS_GROUPS = 64;                // reduction groups per workgroup
-constexpr int DS_KS = 512;                   // reduction super-tile staged in LDS at once (floats)
-constexpr int DS_NIT = DS_KS / (4 * DS_GROUPS);   // float4 k-groups per lane per super-tile
+// reduction super-tile staged in LDS at once (floats): 512 for up to 32 rows, 256 for 48 / 64 rows (64 KB of LDS either way)
+__host__ __device__ constexpr int ds_ks(int MB) { return MB > 32 ? 256 : 512; }
 
 __device__ __forceinline__ float pro_apply(int pro, float v, float v2, float ps) {
     if (pro == IGAN_DENSE_PRO_SQUARE) return v * v;
@@ -45,6 +45,8 @@ template <int MB, bool WT>
 __global__ __launch_bounds__(256) void dense_small_kernel(DenseGroups G) {
     const igan_dense_params a = G.g[blockIdx.y];
     if ((int)blockIdx.x * DS_COLS >= a.N) return;      // groups differ in width (uniform per workgroup)
+    constexpr int DS_KS = ds_ks(MB);
+    constexpr int DS_NIT = DS_KS / (4 * DS_GROUPS);   // float4 k-groups per lane per super-tile
     constexpr int RSTR = MB * DS_COLS + 4;   // group stride in the partial-sum image (bank-spread)
     constexpr int XV = MB * (DS_KS / 4) / 256;   // float4 of x per lane per super-tile
     __shared__ __attribute__((aligned(16))) float xs[MB * DS_KS];
@@ -220,7 +222,7 @@ void launch_dense(hipStream_t stream, const DenseGroups& G, int count, int maxN,
 
 int dense_check(const igan_dense_params* p) {
     IGAN_REQUIRE(p->x && p->w && p->y, "dense_small: null buffer");
-    IGAN_REQUIRE(p->M >= 1 && p->M <= 32, "dense_small: 1 <= M <= 32 rows (use igan_conv2d for larger batches)");
+    IGAN_REQUIRE(p->M >= 1 && p->M <= IGAN_DENSE_MAX_ROWS, "dense_small: 1 <= M <= %d rows (use igan_conv2d for larger batches)", IGAN_DENSE_MAX_ROWS);
     IGAN_REQUIRE(p->K >= 4 && p->K % 4 == 0 && p->N >= 1, "dense_small: K must be a positive multiple of 4, N positive");
     IGAN_REQUIRE(p->ldx >= p->K && p->ldx % 4 == 0 && p->ldy >= p->N, "dense_small: bad row strides");
     IGAN_REQUIRE((((uintptr_t)p->x) & 15) == 0 && (!p->w_transposed || (((uintptr_t)p->w) & 15) == 0), "dense_small: x (and a transposed w) must be 16-byte aligned");
@@ -234,7 +236,7 @@ int dense_check(const igan_dense_params* p) {
 
 int wgrad_check(const igan_dense_wgrad_params* p) {
     IGAN_REQUIRE(p->a && p->b && p->dw, "dense_small_wgrad: null buffer");
-    IGAN_REQUIRE(p->M >= 1 && p->M <= 32, "dense_small_wgrad: 1 <= M <= 32 rows");
+    IGAN_REQUIRE(p->M >= 1 && p->M <= IGAN_DENSE_MAX_ROWS, "dense_small_wgrad: 1 <= M <= %d rows", IGAN_DENSE_MAX_ROWS);
     IGAN_REQUIRE(p->K >= 1 && p->N >= 4 && p->N % 4 == 0 && p->lda >= p->K, "dense_small_wgrad: N must be a positive multiple of 4");
     IGAN_REQUIRE(((((uintptr_t)p->b) | ((uintptr_t)p->dw)) & 15) == 0, "dense_small_wgrad: b and dw must be 16-byte aligned");
     IGAN_REQUIRE(p->pro_a == IGAN_DENSE_PRO_NONE || p->pro_a == IGAN_DENSE_PRO_SQUARE, "dense_small_wgrad: unknown prologue for a");
@@ -258,10 +260,10 @@ bool dense_small_ok(int M, int K, const void* x, const void* w, bool wt) {
     // amplification from HBM for a long reduction axis (D's 8192 -> 512 layer): that one goes to the MFMA tiles.
     static const int maxk = getenv("IGAN_DENSE_MAXK") ? atoi(getenv("IGAN_DENSE_MAXK")) : 2048;
     if (!wt && K > maxk) return false;
-    return M >= 1 && M <= 32 && (K % 4) == 0 && (((uintptr_t)x) & 15) == 0 && (!wt || (((uintptr_t)w) & 15) == 0);
+    return M >= 1 && M <= IGAN_DENSE_MAX_ROWS && (K % 4) == 0 && (((uintptr_t)x) & 15) == 0 && (!wt || (((uintptr_t)w) & 15) == 0);
 }
 
-int dense_small_rows(int M) { return M <= 8 ? 8 : (M <= 16 ? 16 : (M <= 24 ? 24 : 32)); }
+int dense_small_rows(int M) { return M <= 8 ? 8 : (M <= 16 ? 16 : (M <= 24 ? 24 : (M <= 32 ? 32 : (M <= 48 ? 48 : 64)))); }
 
 // all groups of one launch share the weight layout (w_transposed) and the row-count bucket
 void dense_small_launch_groups(hipStream_t stream, const igan_dense_params* groups, int count) {
@@ -273,7 +275,9 @@ void dense_small_launch_groups(hipStream_t stream, const igan_dense_params* grou
     if (mb == 8) launch_dense<8>(stream, G, count, maxN, wt);
     else if (mb == 16) launch_dense<16>(stream, G, count, maxN, wt);
     else if (mb == 24) launch_dense<24>(stream, G, count, maxN, wt);
-    else launch_dense<32>(stream, G, count, maxN, wt);
+    else if (mb == 32) launch_dense<32>(stream, G, count, maxN, wt);
+    else if (mb == 48) launch_dense<48>(stream, G, count, maxN, wt);
+    else launch_dense<64>(stream, G, count, maxN, wt);
 }
 
 void dense_small_launch(hipStream_t stream, const igan_dense_params& a) { dense_small_launch_groups(stream, &a, 1); }
@@ -287,7 +291,7 @@ void dense_small(hipStream_t stream, const float* x, const float* w, float* y, i
 }
 
 bool dense_small_wgrad_ok(int M, int N, const void* dy, const void* dw) {
-    return M >= 1 && M <= 32 && (N % 4) == 0 && ((((uintptr_t)dy) | ((uintptr_t)dw)) & 15) == 0;
+    return M >= 1 && M <= IGAN_DENSE_MAX_ROWS && (N % 4) == 0 && ((((uintptr_t)dy) | ((uintptr_t)dw)) & 15) == 0;
 }
 
 void dense_small_wgrad_groups(hipStream_t stream, const igan_dense_wgrad_params* groups, int count) {

@@ -107,6 +107,13 @@ class _DefaultRandom:
         """Scalar integer tensor in [low, high) (tf.random_uniform([], low, high, dtype=int32))."""
         return torch.randint(int(low), int(high), (), device=device)
 
+    def normal_many(self, shapes, device):
+        """Several independent normal tensors, as consecutive draws; the device generator fills them in ONE launch."""
+        shapes = [tuple(int(s) for s in sh) for sh in shapes]
+        sizes = [int(np.prod(sh)) for sh in shapes]
+        flat = torch.randn((sum(sizes),), device=device, dtype=torch.float32)
+        return [t.view(sh) for t, sh in zip(torch.split(flat, sizes), shapes)]
+
 
 class RandomTape:
     """Replays tensors in call order: entries are (kind, array-like). Raises when exhausted or on a
@@ -139,6 +146,9 @@ class RandomTape:
     def randint(self, low, high, device):
         return self._next('randint', (), device)
 
+    def normal_many(self, shapes, device):
+        return [self._next('normal', sh, device) for sh in shapes]
+
 
 class RecordingRandom(_DefaultRandom):
     """Default source that also records every draw (to build a tape for the oracle)."""
@@ -161,6 +171,12 @@ class RecordingRandom(_DefaultRandom):
         self.entries.append(('randint', t.detach().cpu().numpy()))
         return t
 
+    def normal_many(self, shapes, device):
+        ts = super().normal_many(shapes, device)
+        for t in ts:
+            self.entries.append(('normal', t.detach().cpu().numpy()))
+        return ts
+
 
 _random = _DefaultRandom()
 
@@ -179,6 +195,10 @@ def use_random(source):
 
 def random_normal(shape, device):
     return _random.normal(shape, device)
+
+def random_normal_many(shapes, device):
+    """Consecutive normal draws of the given shapes (same tape order as calling random_normal for each)."""
+    return _random.normal_many(shapes, device)
 
 def random_uniform(shape, device, minval=0.0, maxval=1.0):
     return _random.uniform(shape, device, minval, maxval)

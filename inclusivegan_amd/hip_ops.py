@@ -665,7 +665,7 @@ def _row_major(t):
 def dense_small_raw(x, w, w_transposed=False, alpha=1.0, prologue=_abi.DENSE_PRO_NONE, x2=None, pro_scale=0.0,
                     epilogue=_abi.DENSE_EPI_SCALE, bias=None, bias_scale=1.0, add_const=0.0, eps=0.0, e1=None, e2=None,
                     want_colsum=False):
-    """include/igan_hip.h igan_dense_small: y = epi(alpha * pro(x) . W), M <= 32 rows.  Returns y or (y, colsum)."""
+    """include/igan_hip.h igan_dense_small: y = epi(alpha * pro(x) . W), M <= 64 rows.  Returns y or (y, colsum)."""
     lib = _abi.get_plugin()
     _require_cuda_f32(x, w, x2, bias, e1, e2)
     x = _row_major(x)
@@ -753,7 +753,7 @@ class second_order:
 
 def style_mod_fusable(y, a_w, w, demodulate):
     cin = a_w.shape[1]
-    ok = _STYLE_FUSION and y.is_cuda and y.dim() == 2 and y.shape[0] <= 32 and y.shape[1] % 4 == 0 and cin % 4 == 0
+    ok = _STYLE_FUSION and y.is_cuda and y.dim() == 2 and y.shape[0] <= 64 and y.shape[1] % 4 == 0 and cin % 4 == 0
     if demodulate:
         ok = ok and w.shape[3] % 4 == 0
     return ok

@@ -255,12 +255,20 @@ def G_main(
     dlatent_avg = get_variable('dlatent_avg', shape=[dlatent_size], initializer=('zeros',), trainable=False)
     dev = latents_in.device
 
-    # Evaluate mapping network.
-    dlatents = components.mapping.get_output_for(latents_in, labels_in, is_training=is_training, **kwargs)
-
+    # Evaluate mapping network (:198).  With style mixing a second set of latents goes through the same network (:212-213);
+    # the mapping is row-wise, so both sets are evaluated as one batch (half the launches of its 8 small layers) -- the
+    # random draw of the second set moves in front of the first evaluation, which draws nothing itself.
     batch = int(latents_in.shape[0])
     assert batch % num_calls == 0
     per_call = batch // num_calls
+    dlatents2 = None
+    if style_mixing_prob is not None and not is_template_graph:
+        latents2 = tfutil.random_normal(latents_in.shape, dev)
+        both = components.mapping.get_output_for(torch.cat([latents_in, latents2], dim=0), torch.cat([labels_in, labels_in], dim=0),
+                                                 is_training=is_training, **kwargs)
+        dlatents, dlatents2 = both[:batch], both[batch:]
+    else:
+        dlatents = components.mapping.get_output_for(latents_in, labels_in, is_training=is_training, **kwargs)
 
     # Update moving average of W (:202-207), once per (virtual) call, in call order.
     if dlatent_avg_beta is not None and not is_template_graph:
@@ -271,8 +279,9 @@ def G_main(
 
     # Perform style mixing regularization (:210-221); the coin and the cutoff are per call.
     if style_mixing_prob is not None:
-        latents2 = tfutil.random_normal(latents_in.shape, dev)
-        dlatents2 = components.mapping.get_output_for(latents2, labels_in, is_training=is_training, **kwargs)
+        if dlatents2 is None:       # template pass: same graph, evaluated separately
+            latents2 = tfutil.random_normal(latents_in.shape, dev)
+            dlatents2 = components.mapping.get_output_for(latents2, labels_in, is_training=is_training, **kwargs)
         layer_idx = torch.arange(num_layers, device=dev)[None, :, None]
         cur_layers = num_layers   # lod is always 0 on this path (no progressive growing, training_loop.py:93-94)
         cutoffs = []
@@ -383,11 +392,17 @@ def G_synthesis_stylegan2(
         shape = [1, 1, 2**res, 2**res]
         noise_inputs.append(get_variable('noise%d' % layer_idx, shape=shape, initializer=('normal', 1.0), trainable=False))
 
+    # Fresh per-call noise of every layer (:351-352): consecutive draws in layer order, filled by one generator launch.
+    fresh_noise = None
+    if randomize_noise:
+        fresh_noise = tfutil.random_normal_many([[batch, 1, 2 ** ((l + 5) // 2), 2 ** ((l + 5) // 2)] for l in range(num_layers - 1)], dev)
+
     # Single convolution layer with all the bells and whistles (:349-357).
     def layer(x, layer_idx, fmaps, kernel, up=False):
         x = modulated_conv2d_layer(x, dlatents_in[layer_idx], fmaps=fmaps, kernel=kernel, up=up, resample_kernel=resample_kernel, fused_modconv=fused_modconv, init_mul=init_mul)
         if randomize_noise:
-            noise = tfutil.random_normal([batch, 1, int(x.shape[2]), int(x.shape[3])], dev)
+            noise = fresh_noise[layer_idx]
+            assert tuple(noise.shape[2:]) == tuple(int(d) for d in x.shape[2:])
         else:
             noise = noise_inputs[layer_idx]
         noise_strength = get_variable('noise_strength', shape=[], initializer=('zeros',))

@@ -231,7 +231,10 @@ CONV_CASES = [
     (3, 512, 1, 1, 512, 1, 1, 1, 0, None),   # ... at the path-length batch
     (12, 520, 1, 1, 36, 1, 1, 1, 0, None),   # K spans three LDS tiles with a ragged last one
     (32, 20, 1, 1, 3, 1, 1, 1, 0, None),     # 32 rows, Cout = 3 (weight gradient falls back to the MFMA path)
-    (33, 64, 1, 1, 64, 1, 1, 1, 0, None),    # 33 rows: too many for the dense kernels
+    (33, 64, 1, 1, 64, 1, 1, 1, 0, None),    # 33 rows: the 48-row form of the dense kernels
+    (48, 512, 1, 1, 512, 1, 1, 1, 0, None),  # both latent sets of a generator pass through the mapping network at once
+    (64, 96, 1, 1, 40, 1, 1, 1, 0, None),    # 64 rows
+    (65, 64, 1, 1, 64, 1, 1, 1, 0, None),    # 65 rows: too many for the dense kernels -> MFMA tiles
     (5, 30, 1, 1, 16, 1, 1, 1, 0, None),     # Cin % 4 != 0: MFMA path
     (2, 3, 12, 12, 64, 3, 1, 1, 1, None),    # VGG conv1_1 (thin-input kernel; its data gradient: thin-output 3x3)
     (3, 128, 9, 7, 3, 1, 1, 1, 0, None),     # ToRGB at a thin-kernel size: 32 lanes per pixel, ragged pixel count
