@@ -250,6 +250,103 @@ def test_optimizer_step_and_ema_match_oracle(cuda_device):
     assert rel_err(Gs.flat_params, gs_o) < 2e-6
 
 
+def test_multi_step_training_trajectory_matches_oracle(cuda_device):
+    """Five consecutive training iterations in the reference's op order (G step, G reg every 4th, D step, D reg every 16th;
+    training_loop.py:466-479) with the lazy-regularisation Adam settings (:247-255): the HIP losses + flat-bucket optimizer
+    against the fp64 oracle losses + the NumPy SimpleAdam, same inputs and same random draws.  Loss scalars of every op
+    stay within 1 % (north_star tolerance for the trajectory), the weights after 5 iterations within 1e-3."""
+    from inclusivegan_amd.dnnlib import tflib
+    from inclusivegan_amd.dnnlib.tflib import tfutil
+    from inclusivegan_amd.training import loss as PL
+    from inclusivegan_amd.training.dataset import SyntheticDataset
+    from oracle import loss as OL
+    from oracle import optimizer as OO
+    from oracle.misc import Tape
+    dev = cuda_device
+    fmap = 512
+    kw = dict(num_channels=3, resolution=RES, label_size=0, fmap_base=fmap, device=dev)
+    G = tflib.Network('G', func_name='inclusivegan_amd.training.networks_stylegan2.G_main', architecture='skip', seed=21, **kw)
+    D = tflib.Network('D', func_name='inclusivegan_amd.training.networks_stylegan2.D_stylegan2_feature', architecture='resnet', seed=22, **kw)
+    lp = tflib.Network('lpips', func_name='inclusivegan_amd.metrics.lpips.vgg16_zhang_perceptual', resolution=RES, device=dev, seed=23)
+    ts = SyntheticDataset(resolution=RES, label_size=0, data_size=24, device=dev)
+    cfg = dict(resolution=RES, num_channels=3, fmap_base=fmap, G_arch='skip', D_arch='resnet')
+    lpo = {n: v.detach().double().cpu() for n, v in lp.vars.items()}
+    B = 6
+    cl = lambda t: t.to(dev).contiguous(memory_format=torch.channels_last)
+    lab = torch.zeros(B, 0, device=dev); lab2 = torch.zeros(2 * B, 0, device=dev)
+
+    def make_opts(net, interval):
+        c = interval / (interval + 1)
+        args = dict(learning_rate=lambda: 0.002 * c, beta1=0.0 ** c, beta2=0.99 ** c, epsilon=1e-8)
+        o = tflib.Optimizer(name='Train', **args)
+        r = tflib.Optimizer(name='Reg', share=o, **args)
+        n = int(net.flat_params.numel())
+        return o, r, OO.SimpleAdam(n, 0.002 * c, 0.0 ** c, 0.99 ** c, 1e-8)
+    G_opt, G_reg_opt, adamG = make_opts(G, 4)
+    D_opt, D_reg_opt, adamD = make_opts(D, 16)
+    wG = G.flat_params.detach().cpu().numpy().copy(); wD = D.flat_params.detach().cpu().numpy().copy()
+
+    def odict(net, w):          # oracle parameter dict (fp64) from the oracle's own flat fp32 weights
+        p = {n: v.detach().double().cpu() for n, v in net.vars.items()}
+        for n, (off, cnt) in net._offsets.items():
+            p[n] = torch.from_numpy(w[off:off + cnt].astype(np.float64)).reshape(net.vars[n].shape).requires_grad_(True)
+        return p
+
+    def oflat(net, p):          # gradient dict -> flat fp32 in bucket order
+        g = np.zeros(int(net.flat_params.numel()), np.float32)
+        for n, (off, cnt) in net._offsets.items():
+            if p[n].grad is not None:
+                g[off:off + cnt] = p[n].grad.reshape(-1).numpy().astype(np.float32)
+        return g
+
+    gen = torch.Generator().manual_seed(77)
+    stateG = {}
+    worst = 0.0
+    for it in range(5):
+        r1 = torch.rand(B, 3, RES, RES, generator=gen) * 2 - 1; r2 = torch.rand(B, 3, RES, RES, generator=gen) * 2 - 1
+        z1 = torch.nn.functional.normalize(torch.randn(B, 512, generator=gen), dim=1)
+        z2 = torch.nn.functional.normalize(torch.randn(B, 512, generator=gen), dim=1)
+        reals = torch.rand(2 * B, 3, RES, RES, generator=gen) * 2 - 1
+        steps = [('G', 'loss')] + ([('G', 'reg')] if it % 4 == 0 else []) + [('D', 'loss')] + ([('D', 'reg')] if it % 16 == 0 else [])
+        for net_name, phase in steps:
+            rec = tfutil.RecordingRandom()
+            gp, dp = odict(G, wG), odict(D, wD)
+            if net_name == 'G':
+                D.requires_grad_(False)
+                with tfutil.use_random(rec):
+                    loss, reg = PL.G_logistic_ns_rec_interp_arb_pathreg(G, D, lp, ts, B, cl(r1), lab, z1.to(dev), cl(r2), lab, z2.to(dev),
+                                                                        NN_rec_lpips_weight=2.5, phase=phase)
+                D.requires_grad_(True)
+                val = loss if phase == 'loss' else reg * 4
+                (G_opt if phase == 'loss' else G_reg_opt).register_gradients(val.mean(), G)
+                (G_opt if phase == 'loss' else G_reg_opt).apply_updates()
+                entries = _gloss_tape_in_reference_order(rec.entries, B) if phase == 'loss' else rec.entries
+                lo, ro, _ = OL.G_loss(gp, {k: v.detach() for k, v in dp.items()}, lpo, cfg, Tape(entries, torch.float64), B,
+                                      r1.double(), z1.double(), r2.double(), z2.double(), 2.5, phase=phase, state=stateG)
+                vo = lo if phase == 'loss' else ro * 4
+                vo.mean().backward()
+                adamG.apply(wG, oflat(G, gp))
+            else:
+                G.requires_grad_(False)
+                with tfutil.use_random(rec):
+                    loss, reg = PL.D_logistic_r1(G, D, ts, B, cl(reals), lab2, gamma=100, phase=phase)
+                G.requires_grad_(True)
+                val = loss if phase == 'loss' else reg * 16
+                (D_opt if phase == 'loss' else D_reg_opt).register_gradients(val.mean(), D)
+                (D_opt if phase == 'loss' else D_reg_opt).apply_updates()
+                lo, ro, _ = OL.D_loss({k: v.detach() for k, v in gp.items()}, dp, cfg, Tape(rec.entries, torch.float64), B, reals.double(),
+                                      gamma=100, phase=phase, state={})
+                vo = lo if phase == 'loss' else ro * 16
+                vo.mean().backward()
+                adamD.apply(wD, oflat(D, dp))
+            hv, ov = float(val.detach().mean()), float(vo.detach().mean())
+            rel = abs(hv - ov) / (abs(ov) + 1e-12)
+            worst = max(worst, rel)
+            assert rel < 1e-2, (it, net_name, phase, hv, ov)
+    assert rel_err(G.flat_params, wG) < 1e-3
+    assert rel_err(D.flat_params, wD) < 1e-3
+
+
 def test_training_loop_runs_and_learns_shapes(cuda_device):
     """A few iterations of the real loop on tiny synthetic data: the IMLE refresh, all four step kinds
     (G, G-reg, D, D-reg) execute, parameters move, nothing becomes non-finite."""
