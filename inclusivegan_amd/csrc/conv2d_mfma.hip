@@ -1148,7 +1148,9 @@ extern "C" int igan_conv2d_wgrad(igan_stream_t stream_, const igan_conv2d_wgrad_
     dim3 grid(ceil_div(p->Cin, t.BM), ceil_div(p->Cout, t.BN), p->KH * p->KW * splits);
     const bool vec = a.vecA && a.vecB && (a.in_scale == nullptr || a.vecSA) && (a.out_scale == nullptr || a.vecSB);
     const int scm = (a.in_scale && a.out_scale) ? 1 : ((a.in_scale || a.out_scale) ? 2 : 0);
-    if (t.BM == 128 && t.BN == 128 && eight_waves("IGAN_WGRAD_8WAVE")) launch_wgrad<128, 128, 2, 4>(stream, a, grid, vec, scm);
+    // 8 waves pay on the short pixel axes (32x32 and below: +1.5 %), 4 waves on the 128x128 layers (+3-4 %): measured, tools/conv_bench.py
+    const bool long_axis = (long long)p->OH * p->OW >= 128LL * 128LL;
+    if (t.BM == 128 && t.BN == 128 && eight_waves("IGAN_WGRAD_8WAVE") && !long_axis) launch_wgrad<128, 128, 2, 4>(stream, a, grid, vec, scm);
     else if (t.BM == 128 && t.BN == 128) launch_wgrad<128, 128, 2, 2>(stream, a, grid, vec, scm);
     else if (t.BM == 128 && t.BN == 32) launch_wgrad<128, 32, 4, 1>(stream, a, grid, vec, scm);
     else launch_wgrad<32, 128, 1, 4>(stream, a, grid, vec, scm);
