@@ -164,6 +164,10 @@ typedef struct igan_conv2d_params {
     int sliced_tiles;       /* how many trailing tiles of the tile list are sliced (from igan_conv2d_plan) */
     float alpha;            /* y is multiplied by alpha (the layers' runtime weight scale, networks_stylegan2.py:30-36,
                              * rides here instead of in a separate w * coef pass); 1.0f for a plain convolution */
+    const float* bias;      /* fused epilogue (act != 0): y = act(y + bias[co]) * act_gain, the apply_bias_act that follows the
+                             * convolution (networks_stylegan2.py:66-68); bias may be NULL */
+    int act;                /* 0 = no epilogue; 1 linear, 2 relu, 3 lrelu (as igan_bias_act_noise_*) */
+    float act_alpha, act_gain;
 } igan_conv2d_params;
 
 int igan_conv2d_plan(const igan_conv2d_params* p, int* splits, int* sliced_tiles, size_t* workspace_floats);

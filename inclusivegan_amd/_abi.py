@@ -56,6 +56,7 @@ class Conv2DParams(ctypes.Structure):
         ('stride', ctypes.c_int), ('up', ctypes.c_int),
         ('pad_y', ctypes.c_int), ('pad_x', ctypes.c_int),
         ('w_transposed', ctypes.c_int), ('splits', ctypes.c_int), ('sliced_tiles', ctypes.c_int), ('alpha', ctypes.c_float),
+        ('bias', ctypes.c_void_p), ('act', ctypes.c_int), ('act_alpha', ctypes.c_float), ('act_gain', ctypes.c_float),
     ]
 
     def __init__(self, *args, **kwargs):

@@ -68,7 +68,16 @@ struct ConvArgs {
     int vecA, vecB, vecS;   // 16 B paths usable for x rows / w rows / in_scale rows
     int vecY;               // 8 B output stores usable (Cout even, y / out_scale 8 B aligned)
     float alpha;            // output multiplier (applied here when splits == 1, else by the reduce kernel)
+    const float* bias;      // fused epilogue (act != 0): y = act(y + bias[co]) * act_gain
+    int act;                // 0 none, 1 linear, 2 relu, 3 lrelu
+    float act_alpha, act_gain;
 };
+
+__device__ __forceinline__ float epi_act(int act, float v, float alpha) {
+    if (act == 2) return v > 0.f ? v : 0.f;
+    if (act == 3) return v > 0.f ? v : v * alpha;
+    return v;
+}
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ float4 f4mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
@@ -420,6 +429,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_fwd
                             const float2 sc = *reinterpret_cast<const float2*>(a.out_scale + nn * a.Cout + co);
                             v.x *= sc.x; v.y *= sc.y;
                         }
+                        if (a.act) {
+                            if (a.bias) { v.x += a.bias[co]; v.y += a.bias[co + 1]; }
+                            v.x = epi_act(a.act, v.x, a.act_alpha) * a.act_gain;
+                            v.y = epi_act(a.act, v.y, a.act_alpha) * a.act_gain;
+                        }
                         *reinterpret_cast<float2*>(out + (size_t)pix * a.Cout + co) = v;
                     }
                     continue;
@@ -431,6 +445,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_fwd
                 if (co < a.Cout) {
                     float v = acc[tm][tn][r] * alpha;
                     if (scale) v *= a.out_scale[nn * a.Cout + co];
+                    if (a.act) v = epi_act(a.act, v + (a.bias ? a.bias[co] : 0.f), a.act_alpha) * a.act_gain;
                     out[(size_t)pix * a.Cout + co] = v;
                 }
             }
@@ -496,6 +511,7 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(ConvArgs a, int BM, int
             if (co < a.Cout) {
                 float v = v4[e] * a.alpha;
                 if (a.out_scale) v *= a.out_scale[nn * a.Cout + co];
+                if (a.act) v = epi_act(a.act, v + (a.bias ? a.bias[co] : 0.f), a.act_alpha) * a.act_gain;
                 a.out[(size_t)pix * a.Cout + co] = v;
             }
         }
@@ -797,6 +813,8 @@ int fwd_geometry_check(const igan_conv2d_params* p) {
     IGAN_REQUIRE((long long)p->N * p->H * p->W * p->Cin * 4 <= 0x7FFFFFF0LL, "conv2d: input too large (2 GiB per operand)");
     IGAN_REQUIRE((long long)p->N * p->OH * p->OW * p->Cout <= INT32_MAX, "conv2d: output too large");
     IGAN_REQUIRE((long long)p->KH * p->KW * p->Cin * p->Cout * 4 <= 0x7FFFFFF0LL, "conv2d: filter too large (2 GiB per operand)");
+    IGAN_REQUIRE(p->act >= 0 && p->act <= 3, "conv2d: fused epilogue act must be 0 (none), 1 linear, 2 relu or 3 lrelu");
+    IGAN_REQUIRE(p->act == 0 || p->act_gain > 0.0f, "conv2d: fused epilogue gain must be positive");
     return IGAN_OK;
 }
 
@@ -812,7 +830,7 @@ bool eight_waves(const char* env) {
 // 1x1 convolution on a 1x1 map = a dense layer; with at most 32 rows and no scales it goes to dense_small.hip
 bool is_small_dense(const igan_conv2d_params* p) {
     return p->H == 1 && p->W == 1 && p->OH == 1 && p->OW == 1 && p->KH == 1 && p->KW == 1 && p->stride == 1 && p->up == 1 &&
-           p->pad_y == 0 && p->pad_x == 0 && !p->in_scale && !p->out_scale &&
+           p->pad_y == 0 && p->pad_x == 0 && !p->in_scale && !p->out_scale && p->act == 0 &&
            igan::dense_small_ok(p->N, p->Cin, p->x, p->w, p->w_transposed != 0);
 }
 bool is_small_dense_wgrad(const igan_conv2d_wgrad_params* p) {
@@ -1006,6 +1024,7 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
     else a.vecB = (p->Cout % 4 == 0) && (((uintptr_t)p->w & 15) == 0);
     a.vecY = (p->Cout % 2 == 0) && ((((uintptr_t)p->y | (uintptr_t)p->out_scale) & 7) == 0);
     a.alpha = p->alpha;
+    a.bias = p->bias; a.act = p->act; a.act_alpha = p->act_alpha; a.act_gain = p->act_gain;
 
     dim3 grid(a.full_tiles + (l.T - a.full_tiles) * splits);
     const bool wt = p->w_transposed != 0;

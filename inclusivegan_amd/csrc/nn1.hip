@@ -116,6 +116,7 @@ extern "C" int igan_nn1_update(igan_stream_t stream_, const float* query, const 
     p.splits = 1;
     p.sliced_tiles = 0;
     p.alpha = 1.0f;
+    p.bias = nullptr; p.act = 0; p.act_alpha = 0.0f; p.act_gain = 1.0f;
     if (int rc = igan_conv2d(stream_, &p)) return rc;
     const int grid = ceil_div(nq, 4);
     hipLaunchKernelGGL(nn1_fold_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream_, dots, qnorm, cnorm, best, nq, nc, idx_base);

@@ -322,7 +322,7 @@ static bool thin_enabled() {
 }
 
 int thin_conv_kind(const igan_conv2d_params* p) {
-    if (!thin_enabled() || p->stride != 1 || p->up != 1) return 0;
+    if (!thin_enabled() || p->stride != 1 || p->up != 1 || p->act != 0) return 0;
     const int taps = p->KH * p->KW;
     if (!(taps == 1 || (p->KH == 3 && p->KW == 3))) return 0;
     if (taps == 1 && (p->pad_y != 0 || p->pad_x != 0 || p->OH != p->H || p->OW != p->W)) return 0;

@@ -372,18 +372,21 @@ def conv_flops(n, h, w, cin, oh, ow, cout, geom):
     return 2.0 * n * pairs * cin * cout
 
 
-def conv2d_raw(x, w, geom, out_hw, cout, w_transposed=False, in_scale=None, out_scale=None):
+def conv2d_raw(x, w, geom, out_hw, cout, w_transposed=False, in_scale=None, out_scale=None, bias=None, act=None):
     """x: logical [N,Cin,H,W] (channels_last).  w: HWIO [KH,KW,Cin,Cout] (or the forward layer's
-    [KH,KW,Cout,Cin] when w_transposed).  Returns logical [N,Cout,OH,OW] channels_last."""
+    [KH,KW,Cout,Cin] when w_transposed).  Returns logical [N,Cout,OH,OW] channels_last.
+    act = (act_idx, alpha, gain) fuses y = act(y + bias) * gain into the kernel's epilogue (bias may be None)."""
     if _is_meta(x):
         return torch.empty((x.shape[0], cout, out_hw[0], out_hw[1]), device='meta')
     lib = _abi.get_plugin()
-    _require_cuda_f32(x, w, in_scale, out_scale)
+    _require_cuda_f32(x, w, in_scale, out_scale, bias)
     x = nhwc(x)
     w = w.contiguous()
     n, cin, h, wd = x.shape
     oh, ow = out_hw
     y = empty_nchw(n, cout, oh, ow, x)
+    if bias is not None:
+        bias = bias.contiguous()
     if in_scale is not None:
         in_scale = in_scale.contiguous()
     if out_scale is not None:
@@ -396,8 +399,10 @@ def conv2d_raw(x, w, geom, out_hw, cout, w_transposed=False, in_scale=None, out_
         N=n, H=h, W=wd, Cin=cin, OH=oh, OW=ow, Cout=cout,
         KH=geom.kh, KW=geom.kw, stride=geom.stride, up=geom.up,
         pad_y=geom.pad_y, pad_x=geom.pad_x,
-        w_transposed=1 if w_transposed else 0, splits=1, alpha=float(geom.alpha))
-    key = (n, h, wd, cin, oh, ow, cout, geom)
+        w_transposed=1 if w_transposed else 0, splits=1, alpha=float(geom.alpha),
+        bias=(bias.data_ptr() if bias is not None else None), act=(int(act[0]) if act is not None else 0),
+        act_alpha=(float(act[1]) if act is not None else 0.0), act_gain=(float(act[2]) if act is not None else 1.0))
+    key = (n, h, wd, cin, oh, ow, cout, geom, act is not None)
     plan = _plan_cache.get(key)
     if plan is None:
         splits = ctypes.c_int(1)
@@ -543,6 +548,54 @@ class ConvWgradFn(torch.autograd.Function):
         if _needed(ctx, 1):
             d_dy = Conv2dFn.apply(x, ddw, ctx.geom, (dy.shape[2], dy.shape[3]))
         return d_x, d_dy, None
+
+
+class ConvBiasActFn(torch.autograd.Function):
+    """y = act(conv(x, w; geom) + b) * gain with the bias / activation in the convolution's epilogue (the
+    apply_bias_act that follows conv2d_layer, networks_stylegan2.py:66-68): the pre-activation tensor is never written.
+    act_idx in {1 linear, 2 relu, 3 lrelu}.  Backward: the one-pass epilogue gradient (dx_pre, db), then the data /
+    weight gradient kernels; under create_graph the same through the closed Function pairs."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, geom, out_hw, act_idx, alpha, gain):
+        y = conv2d_raw(x, w, geom, out_hw, w.shape[3], bias=b, act=(act_idx, alpha, gain))
+        ctx.save_for_backward(x, w, y)
+        ctx.geom, ctx.cfg = geom, (act_idx, alpha, gain)
+        ctx.in_hw = (x.shape[2], x.shape[3])
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        act_idx, alpha, gain = ctx.cfg
+        need_x, need_w = _needed(ctx, 0), _needed(ctx, 1)
+        need_b = ctx.has_b and _needed(ctx, 2)
+        dx = dw = db = None
+        if torch.is_grad_enabled():
+            c = y.shape[1]
+            dxp = _FbaGradFn.apply(dy, None, y, 1, act_idx, alpha, gain, c, 1, True)
+            if need_b:
+                db = _BiasGradFn.apply(dxp, 1, c, 1)
+            if need_x:
+                dx = ConvDgradFn.apply(dxp, w, ctx.geom, ctx.in_hw)
+            if need_w:
+                dw = ConvWgradFn.apply(x, dxp, ctx.geom)
+            return dx, dw, db, None, None, None, None, None
+        dxp, db, _ = bias_act_noise_bwd_raw(dy, y, None, act_idx, alpha, gain, need_b)
+        if need_x:
+            dx = conv2d_raw(dxp, w, dgrad_geom(ctx.geom), ctx.in_hw, w.shape[2], w_transposed=True)
+        if need_w:
+            dw = conv2d_wgrad_raw(x, dxp, ctx.geom)
+        return dx, dw, (db if need_b else None), None, None, None, None, None
+
+
+def conv_bias_act_fusable(x, cout, act_idx):
+    """The fused epilogue runs on the MFMA tiles; thin-channel layers (Cin <= 4) and meta dry runs keep the two-step path."""
+    return (not _is_meta(x)) and x.is_cuda and x.dim() == 4 and x.shape[1] > 4 and cout % 4 == 0 and act_idx in (1, 2, 3) and _CONV_EPILOGUE
+
+
+_CONV_EPILOGUE = os.environ.get('IGAN_CONV_EPILOGUE', '1') != '0'      # A/B switch
 
 
 def conv2d(x, w, geom, out_hw):

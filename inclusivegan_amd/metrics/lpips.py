@@ -45,7 +45,10 @@ def _conv_relu(x, fmaps, name):
         std = float(np.sqrt(2.0 / (9 * cin)))
         w = get_variable('weight', shape=[3, 3, cin, fmaps], initializer=('normal', std), trainable=False)
         b = get_variable('bias', shape=[fmaps], initializer=('zeros',), trainable=False)
-        x = hip_ops.conv2d(x, w, hip_ops.ConvGeom(3, 3, 1, 1, 1, 1), (int(x.shape[2]), int(x.shape[3])))
+        geom, out_hw = hip_ops.ConvGeom(3, 3, 1, 1, 1, 1), (int(x.shape[2]), int(x.shape[3]))
+        if hip_ops.conv_bias_act_fusable(x, fmaps, 2):
+            return hip_ops.ConvBiasActFn.apply(x, w, b, geom, out_hw, 2, 0.0, 1.0)      # bias + relu in the conv epilogue
+        x = hip_ops.conv2d(x, w, geom, out_hw)
         return fused_bias_act(x, b=b, act='relu', gain=1.0)
 
 

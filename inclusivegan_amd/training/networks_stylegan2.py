@@ -88,6 +88,35 @@ def apply_bias_act(x, act='linear', alpha=None, gain=None, lrmul=1, bias_var='bi
     return fused_bias_act(x, b=b, act=act, alpha=alpha, gain=gain)
 
 #----------------------------------------------------------------------------
+# conv2d_layer followed by apply_bias_act (:66-68 after :51-61), the pair every discriminator convolution is
+# (`apply_bias_act(conv2d_layer(x, ...), act=act)`): same variables in the same order ('weight', then 'bias'), with
+# the bias / activation evaluated in the convolution's epilogue where the kernels allow it (no FIR after the
+# convolution, more than 4 input channels, piecewise-linear activation).
+
+def conv2d_bias_act_layer(x, fmaps, kernel, down=False, resample_kernel=None, act='linear', alpha=None, gain=None, init_mul=1.0):
+    from ..dnnlib.tflib.ops.fused_bias_act import activation_funcs
+    spec = activation_funcs[act]
+    if not hip_ops.conv_bias_act_fusable(x, fmaps, spec.hip_idx):
+        return apply_bias_act(conv2d_layer(x, fmaps=fmaps, kernel=kernel, down=down, resample_kernel=resample_kernel, init_mul=init_mul),
+                              act=act, alpha=alpha, gain=gain)
+    w, coef = get_weight([kernel, kernel, int(x.shape[1]), fmaps], init_mul=init_mul)
+    b = get_variable('bias', shape=[fmaps], initializer=('zeros',))
+    a = alpha if alpha is not None else (spec.def_alpha or 0.0)
+    g = spec.def_gain if gain is None else gain
+    if down:
+        # conv_downsample_2d (upfirdn_2d.py:296-332): FIR with gain = coef, then the VALID stride-2 convolution
+        from ..dnnlib.tflib.ops.upfirdn_2d import _setup_kernel, _simple_upfirdn_2d
+        k = _setup_kernel(resample_kernel if resample_kernel is not None else [1, 1]) * coef
+        p = (k.shape[0] - 2) + (kernel - 1)
+        x = _simple_upfirdn_2d(x, k, pad0=(p+1)//2, pad1=p//2, data_format='NCHW')
+        H, W = int(x.shape[2]), int(x.shape[3])
+        geom = hip_ops.ConvGeom(kernel, kernel, 2, 1, 0, 0)
+        return hip_ops.ConvBiasActFn.apply(x, w, b, geom, ((H - kernel) // 2 + 1, (W - kernel) // 2 + 1), spec.hip_idx, a, g)
+    pd = (kernel - 1) // 2
+    geom = hip_ops.ConvGeom(kernel, kernel, 1, 1, pd, pd, coef)
+    return hip_ops.ConvBiasActFn.apply(x, w, b, geom, (int(x.shape[2]), int(x.shape[3])), spec.hip_idx, a, g)
+
+#----------------------------------------------------------------------------
 # Naive upsampling (nearest neighbor) and downsampling (average pooling) (:73-84).  Not used by config-e/f
 # (the resample_kernel paths above are); kept for the operator surface.
 
@@ -508,9 +537,9 @@ def D_stylegan2_feature(
     def block(x, res): # res = 2..resolution_log2
         t = x
         with variable_scope('Conv0'):
-            x = apply_bias_act(conv2d_layer(x, fmaps=nf(res-1), kernel=3), act=act)
+            x = conv2d_bias_act_layer(x, fmaps=nf(res-1), kernel=3, act=act)
         with variable_scope('Conv1_down'):
-            x = apply_bias_act(conv2d_layer(x, fmaps=nf(res-2), kernel=3, down=True, resample_kernel=resample_kernel), act=act)
+            x = conv2d_bias_act_layer(x, fmaps=nf(res-2), kernel=3, down=True, resample_kernel=resample_kernel, act=act)
         if architecture == 'resnet':
             with variable_scope('Skip'):
                 t = conv2d_layer(t, fmaps=nf(res-2), kernel=1, down=True, resample_kernel=resample_kernel)
@@ -548,7 +577,7 @@ def D_stylegan2_feature(
             with variable_scope('MinibatchStddev'):
                 x = minibatch_stddev_layer(x, mbstd_group_size, mbstd_num_features)
         with variable_scope('Conv'):
-            x = apply_bias_act(conv2d_layer(x, fmaps=nf(1), kernel=3), act=act)
+            x = conv2d_bias_act_layer(x, fmaps=nf(1), kernel=3, act=act)
             feature_concat(x)
         with variable_scope('Dense0'):
             x = apply_bias_act(dense_layer(x, fmaps=nf(0)), act=act)

@@ -304,6 +304,36 @@ def test_conv_family_is_bit_reproducible(case, cuda_device):
             assert torch.equal(a_, b_)
 
 
+@pytest.mark.parametrize('case', [(2, 16, 9, 9, 24, 3, 1, 1, 3), (12, 128, 32, 32, 128, 3, 1, 1, 3), (3, 20, 11, 11, 28, 3, 2, 0, 3),
+                                  (6, 513, 4, 4, 512, 3, 1, 1, 3), (4, 64, 16, 16, 64, 3, 1, 1, 2), (2, 32, 8, 8, 32, 1, 1, 0, 1)])
+def test_conv_bias_act_epilogue(case, cuda_device):
+    """ConvBiasActFn (bias + activation in the convolution's epilogue, direct and sliced-tail tiles) == convolution followed by
+    the stand-alone epilogue kernel: values, first-order gradients, and an R1-style second-order gradient."""
+    from inclusivegan_amd import hip_ops
+    N, Cin, H, W, Cout, K, stride, pad, act = case
+    rng = np.random.RandomState(N * 7 + Cin)
+    oh = (H + 2 * pad - K) // stride + 1
+    x = to_nhwc_cuda(torch.from_numpy(rng.randn(N, Cin, H, W).astype(np.float32)), cuda_device)
+    w = torch.from_numpy((rng.randn(K, K, Cin, Cout) / np.sqrt(K * K * Cin)).astype(np.float32)).to(cuda_device)
+    b = torch.from_numpy((rng.randn(Cout) * 0.3).astype(np.float32)).to(cuda_device)
+    dy = to_nhwc_cuda(torch.from_numpy(rng.randn(N, Cout, oh, oh).astype(np.float32)), cuda_device)
+    geom = hip_ops.ConvGeom(K, K, stride, 1, pad, pad, 0.8)
+    alpha, gain = 0.2, float(np.sqrt(2))
+    def run(fused):
+        xs = x.clone().requires_grad_(True); ws = w.clone().requires_grad_(True); bs = b.clone().requires_grad_(True)
+        if fused:
+            y = hip_ops.ConvBiasActFn.apply(xs, ws, bs, geom, (oh, oh), act, alpha, gain)
+        else:
+            y = hip_ops.bias_act_noise(hip_ops.conv2d(xs, ws, geom, (oh, oh)), bs, None, None, act, alpha, gain)
+        g1 = torch.autograd.grad(y, [xs, ws, bs], dy, create_graph=True)
+        pen = (g1[0] * g1[0]).sum()
+        g2 = torch.autograd.grad(pen, [ws], allow_unused=True)
+        return [y] + list(g1) + [g2[0]]
+    assert hip_ops.conv_bias_act_fusable(x, Cout, act)
+    for a_, b_ in zip(run(True), run(False)):
+        assert rel_err(a_, b_) < 3e-5
+
+
 def test_conv2d_double_backward(cuda_device):
     """R1-style penalty through conv (needs d(dgrad)/dw and d(dgrad)/d(dy))."""
     from inclusivegan_amd import hip_ops
