@@ -528,6 +528,8 @@ def D_stylegan2_feature(
     act = nonlinearity
     assert tuple(images_in.shape[1:]) == (num_channels, resolution, resolution)
     images_in = images_in.to(torch.float32)
+    if images_in.is_cuda:
+        images_in = hip_ops.nhwc(images_in)      # one layout conversion for every consumer (FromRGB forward and weight gradient)
 
     # Building blocks for main layers (:438-455).
     def fromrgb(x, y, res): # res = 2..resolution_log2
