@@ -34,7 +34,8 @@
 extern "C" {
 #endif
 
-#define IGAN_ABI_VERSION 1
+/* Bumped whenever a struct layout or a signature changes (2: fused conv epilogue fields, fp64 nearest-neighbour state). */
+#define IGAN_ABI_VERSION 2
 
 typedef void* igan_stream_t; /* hipStream_t */
 
@@ -46,6 +47,10 @@ enum igan_status {
 };
 
 int igan_abi_version(void);
+/* sizeof() of the parameter structs as this library was compiled, by id: 0 upfirdn2d, 1 fused_bias_act, 2 conv2d,
+ * 3 conv2d_wgrad, 4 dense, 5 dense_wgrad, 6 taps; 0 for an unknown id.  A binding checks these against its own
+ * struct declarations at load time, so that a stale library can never be driven with a newer struct (or vice versa). */
+size_t igan_struct_size(int which);
 const char* igan_last_error(void);
 
 /* ------------------------------------------------------------------------
@@ -308,25 +313,23 @@ int igan_mbstd_bwd(igan_stream_t stream, const float* x, const float* dy, float*
 /* ------------------------------------------------------------------------
  * Exact streaming 1-nearest-neighbour (replaces dci_add + dci_query as used at
  * training/training_loop.py:367-368,398 with num_neighbours = 1).
- *   best[q] = min over candidates c of pack(|query_q - cand_c|^2, idx_base + c)
- * `best` holds one uint64 per query: high 32 bits = bit pattern of the (clamped
- * >= 0) fp32 squared distance, low 32 bits = candidate index; initialise to
- * 0xFFFFFFFFFFFFFFFF.  Candidates can be streamed batch after batch with
- * increasing idx_base; the running minimum is order-independent and ties go to
- * the lower index, so the result is deterministic.
- * qnorm / cnorm are the squared row norms (igan_row_sqnorm, fp64 accumulate);
- * the dot products run on the exact-fp32 MFMA and |q|^2 + |c|^2 - 2 q.c is combined
- * in fp64 before rounding to fp32 (absolute error in the squared distance ~1e-6 * (|q|^2+|c|^2)).
- * With refine != 0, every query whose running best came from THIS batch gets that distance
- * recomputed as a direct difference in fp64 (exactly compute_dist, dci_code/src/util.c:62-69),
- * so the distances finally reported for the winners carry no cancellation error.  The caller
- * takes sqrt (Euclidean distance) when unpacking.
+ *   (best_d2[q], best_idx[q]) = lexicographic min over candidates c of (|query_q - cand_c|^2, idx_base + c)
+ * with the squared distance of the winner -- and of every candidate that could be the winner -- computed
+ * as a direct difference in fp64 (compute_dist, dci_code/src/util.c:62-69, before its sqrt), i.e. the
+ * result equals an fp64 brute-force search (ties go to the lower index).  The fp32 MFMA product
+ * |q|^2 + |c|^2 - 2 q.c only screens: candidates whose error interval (relative half-width
+ * 2^-22 * sqrt(dim) of |q|^2 + |c|^2) cannot reach the best known upper bound are dropped, the rest are
+ * measured exactly.  Initialise best_d2 to +infinity and best_idx to INT32_MAX; candidates can be streamed
+ * batch after batch with increasing idx_base, the running minimum is order-independent, so the result is
+ * deterministic.  A candidate with a non-finite product or distance never wins.
+ * qnorm / cnorm are the squared row norms (igan_row_sqnorm, fp64 accumulate).  The caller takes sqrt
+ * (Euclidean distance) of best_d2.
  */
 int igan_row_sqnorm(igan_stream_t stream, const float* a, float* out, int rows, int dim);
 int igan_nn1_update(igan_stream_t stream, const float* query, const float* qnorm,
-                    const float* cand, const float* cnorm, unsigned long long* best,
+                    const float* cand, const float* cnorm, double* best_d2, int* best_idx,
                     float* dots /* caller workspace, nq*nc floats */,
-                    int nq, int nc, int dim, int idx_base, int refine);
+                    int nq, int nc, int dim, int idx_base);
 
 /* ------------------------------------------------------------------------
  * Flat-bucket optimizer step (dnnlib/tflib/optimizer.py:237-239,318-332):

@@ -110,6 +110,9 @@ class TapsParams(ctypes.Structure):
                 ('taps', ctypes.c_int), ('n', ctypes.c_int), ('scale', ctypes.c_float)]
 
 
+ABI_VERSION = 2      # include/igan_hip.h IGAN_ABI_VERSION
+STRUCTS = (UpFirDn2DParams, FusedBiasActParams, Conv2DParams, Conv2DWgradParams, DenseParams, DenseWgradParams, TapsParams)   # igan_struct_size ids
+
 DENSE_MAX_GROUPS = 24
 DENSE_PRO_NONE, DENSE_PRO_SQUARE, DENSE_PRO_DEMOD_GRAD = 0, 1, 2
 DENSE_EPI_SCALE, DENSE_EPI_BIAS, DENSE_EPI_RSQRT, DENSE_EPI_STYLE_GRAD = 0, 1, 2, 3
@@ -119,6 +122,7 @@ _I, _F, _P, _SZ = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 # name -> (restype, argtypes): every symbol include/igan_hip.h declares.
 SIGNATURES = {
     'igan_abi_version': (_I, []),
+    'igan_struct_size': (_SZ, [_I]),
     'igan_last_error': (ctypes.c_char_p, []),
     'igan_upfirdn2d': (_I, [_P, ctypes.POINTER(UpFirDn2DParams)]),
     'igan_fused_bias_act': (_I, [_P, ctypes.POINTER(FusedBiasActParams)]),
@@ -149,7 +153,7 @@ SIGNATURES = {
     'igan_mbstd_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I]),
     'igan_mbstd_bwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I]),
     'igan_row_sqnorm': (_I, [_P, _P, _P, _I, _I]),
-    'igan_nn1_update': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
+    'igan_nn1_update': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I]),
     'igan_finite_check': (_I, [_P, _P, _I, _P]),
     'igan_adam_step': (_I, [_P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _P, _P]),
     'igan_ema': (_I, [_P, _P, _P, _I, _F]),
@@ -180,8 +184,13 @@ def get_plugin():
             fn = getattr(lib, name)  # AttributeError if the symbol is absent
             fn.restype = restype
             fn.argtypes = argtypes
-        if lib.igan_abi_version() != 1:
-            raise ImportError('inclusivegan_amd: libigan_hip.so ABI version mismatch')
+        if lib.igan_abi_version() != ABI_VERSION:
+            raise ImportError('inclusivegan_amd: libigan_hip.so has ABI version %d, this binding needs %d -- rebuild it '
+                              '(make -C inclusivegan_amd/csrc)' % (lib.igan_abi_version(), ABI_VERSION))
+        for which, struct in enumerate(STRUCTS):      # a stale library must never be driven with a newer struct layout
+            if lib.igan_struct_size(which) != ctypes.sizeof(struct):
+                raise ImportError('inclusivegan_amd: libigan_hip.so was built with sizeof(%s) = %d, this binding declares %d -- '
+                                  'rebuild it' % (struct.__name__, lib.igan_struct_size(which), ctypes.sizeof(struct)))
         _lib = lib
     return _lib
 

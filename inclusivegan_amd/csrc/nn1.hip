@@ -34,56 +34,96 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const float* a, float* 
     if (lane == 0) out[wave] = (float)s;
 }
 
-__global__ __launch_bounds__(256) void nn1_fold_kernel(const float* dots, const float* qnorm, const float* cnorm,
-                                                       unsigned long long* best, int nq, int nc, int idx_base) {
+// Relative half-width of the interval the fp32 cancellation form |q|^2 + |c|^2 - 2 q.c is trusted to: the dot product is an
+// fp32 FMA chain of `dim` terms (error ~ 0.3 * 2^-24 * sqrt(dim) * |q.c| statistically; measured 3.5e-7 * sum|a b| at dim 4096),
+// the norms are fp64 sums rounded to fp32.  2^-22 * sqrt(dim) (5.3e-5 at dim 49 152) leaves an order of magnitude of margin;
+// a wider interval only costs more exact evaluations, never a wrong answer.
+__device__ __forceinline__ double nn1_tol(int dim) { return fmax(2.384185791015625e-07 * sqrt((double)dim), 1e-6); }
+
+// Squared distance of two rows as a direct difference with fp64 accumulation (compute_dist, dci_code/src/util.c:62-69,
+// before its sqrt), by one whole wavefront; the result is in every lane.  Fixed summation order: deterministic.
+__device__ __forceinline__ double wave_sqdist(const float* __restrict__ a, const float* __restrict__ b, int dim, int lane) {
+    double s0 = 0.0, s1 = 0.0;
+    int i = lane * 4;
+    if ((dim & 3) == 0 && ((((uintptr_t)a | (uintptr_t)b) & 15) == 0)) {
+        for (; i + 256 < dim; i += 512) {      // two 16 B loads per operand in flight
+            const float4 x0 = *reinterpret_cast<const float4*>(a + i), y0 = *reinterpret_cast<const float4*>(b + i);
+            const float4 x1 = *reinterpret_cast<const float4*>(a + i + 256), y1 = *reinterpret_cast<const float4*>(b + i + 256);
+            double d;
+            d = (double)x0.x - (double)y0.x; s0 += d * d; d = (double)x0.y - (double)y0.y; s0 += d * d;
+            d = (double)x0.z - (double)y0.z; s0 += d * d; d = (double)x0.w - (double)y0.w; s0 += d * d;
+            d = (double)x1.x - (double)y1.x; s1 += d * d; d = (double)x1.y - (double)y1.y; s1 += d * d;
+            d = (double)x1.z - (double)y1.z; s1 += d * d; d = (double)x1.w - (double)y1.w; s1 += d * d;
+        }
+        for (; i < dim; i += 256) {
+            const float4 x0 = *reinterpret_cast<const float4*>(a + i), y0 = *reinterpret_cast<const float4*>(b + i);
+            double d;
+            d = (double)x0.x - (double)y0.x; s0 += d * d; d = (double)x0.y - (double)y0.y; s0 += d * d;
+            d = (double)x0.z - (double)y0.z; s0 += d * d; d = (double)x0.w - (double)y0.w; s0 += d * d;
+        }
+    } else {
+        for (int j = lane; j < dim; j += 64) {
+            const double d = (double)a[j] - (double)b[j];
+            s0 += d * d;
+        }
+    }
+    double s = s0 + s1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    return s;
+}
+
+// One wavefront per query.  The cancellation form only SCREENS: a candidate stays a contender while the interval
+// [a - t, a + t] around its approximate squared distance a reaches below the best upper bound known (the running exact
+// minimum, or the smallest a + t of this batch); every contender is then measured exactly (fp64 direct difference) and the
+// choice is made on (exact distance, index) -- lexicographic, ties to the lower index, exactly what an fp64 brute-force
+// search returns (oracle/nn.py; the reference's dci_query(num_neighbours=1) approximates it).  A non-finite dot product or
+// distance compares false everywhere: such a candidate can never win.
+__global__ __launch_bounds__(256) void nn1_fold_kernel(const float* __restrict__ dots, const float* __restrict__ qnorm,
+                                                       const float* __restrict__ cnorm, const float* __restrict__ query,
+                                                       const float* __restrict__ cand, double* __restrict__ best_d2,
+                                                       int* __restrict__ best_idx, int nq, int nc, int dim, int idx_base) {
     const int q = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (q >= nq) return;
     const double qn = (double)qnorm[q];
-    unsigned long long m = ~0ull;
+    const double tol = nn1_tol(dim);
+    double bd = best_d2[q];
+    int bi = best_idx[q];
+    // pass 1: smallest upper bound of this batch
+    double u = bd;
     for (int c = lane; c < nc; c += 64) {
-        double d2 = qn + (double)cnorm[c] - 2.0 * (double)dots[(size_t)q * nc + c];
-        float f = (float)d2;
-        if (!(f > 0.0f)) f = 0.0f;  // clamp tiny negatives (and NaN) to 0
-        const unsigned long long packed = ((unsigned long long)__float_as_uint(f) << 32) | (unsigned int)(idx_base + c);
-        m = (packed < m) ? packed : m;
+        const double cn = (double)cnorm[c];
+        const double a = qn + cn - 2.0 * (double)dots[(size_t)q * nc + c];
+        const double hi = a + tol * (qn + cn);
+        u = (hi < u) ? hi : u;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-        const unsigned long long o = __shfl_down(m, off, 64);
-        m = (o < m) ? o : m;
+        const double o = __shfl_xor(u, off, 64);
+        u = (o < u) ? o : u;
     }
-    if (lane == 0) {
-        const unsigned long long cur = best[q];
-        best[q] = (m < cur) ? m : cur;
+    // pass 2: exact evaluation of the contenders, in index order
+    const float* qrow = query + (size_t)q * dim;
+    for (int c0 = 0; c0 < nc; c0 += 64) {
+        const int c = c0 + lane;
+        bool contender = false;
+        if (c < nc) {
+            const double cn = (double)cnorm[c];
+            const double a = qn + cn - 2.0 * (double)dots[(size_t)q * nc + c];
+            contender = (a - tol * (qn + cn)) <= u;
+        }
+        unsigned long long mask = __ballot(contender);
+        while (mask) {
+            const int j = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const double e = wave_sqdist(qrow, cand + (size_t)(c0 + j) * dim, dim, lane);
+            const int gi = idx_base + c0 + j;
+            if (e < bd || (e == bd && gi < bi)) { bd = e; bi = gi; }
+            u = (e < u) ? e : u;
+        }
     }
-}
-
-// Winners that come from THIS candidate batch get their distance recomputed as a direct
-// difference (fp64 accumulation, like compute_dist in dci_code/src/util.c:62-69), removing the
-// cancellation error of the |q|^2 + |c|^2 - 2 q.c form for close pairs.  One wavefront per query;
-// queries whose best did not change in this batch exit immediately (wave-uniform branch).
-__global__ __launch_bounds__(256) void nn1_refine_kernel(const float* query, const float* cand, unsigned long long* best,
-                                                         int nq, int nc, int dim, int idx_base) {
-    const int q = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    if (q >= nq) return;
-    const unsigned long long cur = best[q];
-    const long long idx = (long long)(cur & 0xFFFFFFFFull) - idx_base;
-    if (idx < 0 || idx >= nc) return;
-    const float* a = query + (size_t)q * dim;
-    const float* b = cand + (size_t)idx * dim;
-    double s = 0.0;
-    for (int i = lane; i < dim; i += 64) {
-        const double d = (double)a[i] - (double)b[i];
-        s += d * d;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if (lane == 0) {
-        const float f = (float)s;
-        best[q] = ((unsigned long long)__float_as_uint(f) << 32) | (cur & 0xFFFFFFFFull);
-    }
+    if (lane == 0) { best_d2[q] = bd; best_idx[q] = bi; }
 }
 
 }  // namespace
@@ -99,10 +139,10 @@ extern "C" int igan_row_sqnorm(igan_stream_t stream_, const float* a, float* out
 }
 
 extern "C" int igan_nn1_update(igan_stream_t stream_, const float* query, const float* qnorm,
-                               const float* cand, const float* cnorm, unsigned long long* best,
-                               float* dots, int nq, int nc, int dim, int idx_base, int refine) {
+                               const float* cand, const float* cnorm, double* best_d2, int* best_idx,
+                               float* dots, int nq, int nc, int dim, int idx_base) {
     using namespace igan;
-    IGAN_REQUIRE(query && qnorm && cand && cnorm && best && dots, "nn1_update: null buffer");
+    IGAN_REQUIRE(query && qnorm && cand && cnorm && best_d2 && best_idx && dots, "nn1_update: null buffer");
     IGAN_REQUIRE(nq >= 1 && nc >= 1 && dim >= 1, "nn1_update: sizes must be positive");
     IGAN_REQUIRE(idx_base >= 0 && (long long)idx_base + nc <= INT32_MAX, "nn1_update: candidate index overflows int32");
     igan_conv2d_params p;
@@ -119,11 +159,8 @@ extern "C" int igan_nn1_update(igan_stream_t stream_, const float* query, const 
     p.bias = nullptr; p.act = 0; p.act_alpha = 0.0f; p.act_gain = 1.0f;
     if (int rc = igan_conv2d(stream_, &p)) return rc;
     const int grid = ceil_div(nq, 4);
-    hipLaunchKernelGGL(nn1_fold_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream_, dots, qnorm, cnorm, best, nq, nc, idx_base);
+    hipLaunchKernelGGL(nn1_fold_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream_, dots, qnorm, cnorm, query, cand,
+                       best_d2, best_idx, nq, nc, dim, idx_base);
     IGAN_LAUNCH_CHECK("nn1_fold launch");
-    if (refine) {
-        hipLaunchKernelGGL(nn1_refine_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream_, query, cand, best, nq, nc, dim, idx_base);
-        IGAN_LAUNCH_CHECK("nn1_refine launch");
-    }
     return IGAN_OK;
 }

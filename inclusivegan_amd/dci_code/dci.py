@@ -109,17 +109,17 @@ class DCI(object):
         return [idx[i:i + 1] for i in range(idx.shape[0])], [dist[i:i + 1] for i in range(dist.shape[0])]
 
     def query_device(self, q):
-        """q: device fp32 [nq, dim] -> (int64 idx [nq], fp32 Euclidean dist [nq]) on the device."""
+        """q: device fp32 [nq, dim] -> (int64 idx [nq], fp64 Euclidean dist [nq]) on the device."""
         nq = int(q.shape[0])
-        best = torch.full((nq,), -1, device=self.device, dtype=torch.int64)   # 0xFFFF... as uint64
+        best_d2, best_idx = hip_ops.nn1_state(nq, self.device)
         n = self.num_points
         for q0 in range(0, nq, self.query_chunk):
             qs = q[q0:q0 + self.query_chunk]
             qn = hip_ops.row_sqnorm_raw(qs)
-            bs = best[q0:q0 + self.query_chunk]
             for c0 in range(0, n, self.cand_chunk):
-                hip_ops.nn1_update_raw(qs, qn, self._data[c0:c0 + self.cand_chunk], self._norms[c0:c0 + self.cand_chunk], bs, c0)
-        return unpack_best(best)
+                hip_ops.nn1_update_raw(qs, qn, self._data[c0:c0 + self.cand_chunk], self._norms[c0:c0 + self.cand_chunk],
+                                       best_d2[q0:q0 + self.query_chunk], best_idx[q0:q0 + self.query_chunk], c0)
+        return unpack_best(best_d2, best_idx)
 
     def clear(self):
         self._data = None
@@ -131,14 +131,6 @@ class DCI(object):
         self.clear()
 
 
-def unpack_best(best):
-    """packed uint64 (as int64) -> (idx int64, Euclidean distance fp32)."""
-    idx = best & 0xFFFFFFFF
-    bits = (best >> 32) & 0xFFFFFFFF
-    d2 = _bits_to_float(bits)
-    return idx, torch.sqrt(d2)
-
-
-def _bits_to_float(bits):
-    # bits < 2^31 for non-negative floats, so the int64 -> int32 narrowing is exact
-    return bits.to(torch.int32).view(torch.float32)
+def unpack_best(best_d2, best_idx):
+    """running minimum (fp64 squared distance, int32 index) -> (idx int64, Euclidean distance fp64)."""
+    return best_idx.to(torch.int64), torch.sqrt(best_d2)

@@ -402,7 +402,7 @@ def conv2d_raw(x, w, geom, out_hw, cout, w_transposed=False, in_scale=None, out_
         w_transposed=1 if w_transposed else 0, splits=1, alpha=float(geom.alpha),
         bias=(bias.data_ptr() if bias is not None else None), act=(int(act[0]) if act is not None else 0),
         act_alpha=(float(act[1]) if act is not None else 0.0), act_gain=(float(act[2]) if act is not None else 1.0))
-    key = (n, h, wd, cin, oh, ow, cout, geom, act is not None)
+    key = (n, h, wd, cin, oh, ow, cout, geom, act is not None, bool(w_transposed), in_scale is not None, out_scale is not None)
     plan = _plan_cache.get(key)
     if plan is None:
         splits = ctypes.c_int(1)
@@ -460,7 +460,7 @@ def conv2d_wgrad_raw(x, dy, geom, in_scale=None, out_scale=None):
         N=n, H=h, W=wd, Cin=cin, OH=oh, OW=ow, Cout=cout,
         KH=geom.kh, KW=geom.kw, stride=geom.stride, up=geom.up,
         pad_y=geom.pad_y, pad_x=geom.pad_x, splits=1, alpha=float(geom.alpha))
-    key = (n, h, wd, cin, oh, ow, cout, geom)
+    key = (n, h, wd, cin, oh, ow, cout, geom, in_scale is not None, out_scale is not None)
     plan = _wplan_cache.get(key)
     if plan is None:
         splits = ctypes.c_int(1)
@@ -1159,15 +1159,25 @@ def row_sqnorm_raw(a):
     return out
 
 
-def nn1_update_raw(query, qnorm, cand, cnorm, best, idx_base, refine=True):
-    """Fold one candidate batch into the running packed (dist2, idx) minimum `best` (int64 view of uint64)."""
+def nn1_state(nq, device):
+    """Running minimum of igan_nn1_update for nq queries: (squared distance fp64 = +inf, candidate index int32 = INT32_MAX)."""
+    return (torch.full((nq,), float('inf'), device=device, dtype=torch.float64),
+            torch.full((nq,), 2 ** 31 - 1, device=device, dtype=torch.int32))
+
+
+def nn1_update_raw(query, qnorm, cand, cnorm, best_d2, best_idx, idx_base):
+    """Fold one candidate batch into the running exact minimum (best_d2 fp64 [nq], best_idx int32 [nq]; contiguous views)."""
     lib = _abi.get_plugin()
     _require_cuda_f32(query, qnorm, cand, cnorm)
+    if best_d2.dtype != torch.float64 or best_idx.dtype != torch.int32 or not (best_d2.is_contiguous() and best_idx.is_contiguous()):
+        raise TypeError('nn1_update: best_d2 must be contiguous float64 and best_idx contiguous int32')
+    query = query.contiguous()
+    cand = cand.contiguous()
     nq, dim = query.shape
     nc = cand.shape[0]
     dots = torch.empty((nq, nc), device=query.device, dtype=torch.float32)
-    _abi.check(lib.igan_nn1_update(_stream(), _ptr(query), _ptr(qnorm), _ptr(cand), _ptr(cnorm), _ptr(best), _ptr(dots),
-                                   nq, nc, dim, idx_base, 1 if refine else 0))
+    _abi.check(lib.igan_nn1_update(_stream(), _ptr(query), _ptr(qnorm), _ptr(cand), _ptr(cnorm), _ptr(best_d2), _ptr(best_idx), _ptr(dots),
+                                   nq, nc, dim, idx_base))
 
 
 def finite_check_raw(g, flag):

@@ -77,8 +77,12 @@ def build_kwargs(dataset, data_dir, result_dir, config_id, num_gpus, gamma, mirr
     return out
 
 
-def run(**args):
+def run(attr_file=None, **args):
+    """`attr_file`: CelebA's Anno/list_attr_celeba.txt for --attr-interesting (the reference reads
+    'celeba/Anno/list_attr_celeba.txt' relative to the working directory, training_loop.py:174-180; that path is tried
+    too).  With the synthetic CelebA-shaped source the 40 label columns carry CelebA's attribute order."""
     from .training import training_loop as TL
+    from .training import imle
     kw = build_kwargs(**args)
     for k in ('run_func_name', 'num_gpus', 'run_desc'):
         kw.pop(k)
@@ -89,6 +93,14 @@ def run(**args):
         ds.update(resolution=32, num_channels=3, label_size=1000, label_kind='onehot')
     else:
         ds.update(resolution=128, num_channels=3, label_size=40, label_kind='attributes')
+    if kw.get('attr_interesting') is not None:
+        candidates = [f for f in (attr_file, 'celeba/Anno/list_attr_celeba.txt') if f and os.path.isfile(f)]
+        if attr_file is not None and not candidates:
+            raise FileNotFoundError('--attr-file %s does not exist' % attr_file)
+        kw['attr_names'] = imle.attribute_names(candidates[0]) if candidates else list(imle.CELEBA_ATTRIBUTES)
+        unknown = [a for a in kw['attr_interesting'].split(',') if a not in kw['attr_names']]
+        if unknown:
+            raise ValueError('--attr-interesting: unknown attribute(s) %s; known: %s' % (unknown, ', '.join(kw['attr_names'])))
     return TL.training_loop(**kw)
 
 
@@ -132,6 +144,7 @@ def main():
     p.add_argument('--dist-thres-percentile', default=100.0, type=float)
     p.add_argument('--attr-interesting', default=None, type=str)
     p.add_argument('--resume-pkl', default=None, type=str)
+    p.add_argument('--attr-file', default=None, type=str, help='CelebA Anno/list_attr_celeba.txt (attribute vocabulary for --attr-interesting)')
     args = p.parse_args()
     if args.config_id not in _valid_configs:
         print('Error: --config value must be one of: ', ', '.join(_valid_configs))

@@ -9,7 +9,9 @@ The TFRecord on-disk format is a "next" row.
 Images are uint8 [N, C, H, W] ~ U{0..255} (seeded), labels fp32 [N, label_size]: one-hot for
 Stacked-MNIST-like sets (dataset_tool.py:332-334) or Bernoulli(0.2) {0,1} attributes for
 CelebA-like sets (dataset_tool.py:467-486).  Like the reference with shuffle_mb=0
-(training_loop.py:169-170) minibatches walk the set in order and wrap around.
+(training_loop.py:169-170) minibatches walk the set in order and wrap around; get_minibatch_np and
+get_minibatch_tf share ONE iterator (dataset.py:148-157), which restarts whenever configure() changes
+the minibatch size (:139-145).
 """
 import numpy as np
 import torch
@@ -39,8 +41,8 @@ class SyntheticDataset:
             self._labels[np.arange(self.data_size), idx] = 1.0
         else:
             self._labels = (rng.rand(self.data_size, self.label_size) < 0.2).astype(np.float32)
-        self._label_rng = np.random.RandomState(seed + 1)
         self._cur_minibatch = -1
+        self._cur_lod = -1
         self._cursor = 0
         self._dev_images = None
         self._dev_labels = None
@@ -49,8 +51,14 @@ class SyntheticDataset:
         pass
 
     def configure(self, minibatch_size, lod=0):
-        assert minibatch_size >= 1 and int(np.floor(lod)) == 0
-        self._cur_minibatch = int(minibatch_size)
+        """dataset.py:139-145: a CHANGE of minibatch size (or lod) re-initialises the iterator, i.e. the walk restarts at
+        image 0; configuring the same values again does nothing."""
+        lod = int(np.floor(lod))
+        assert minibatch_size >= 1 and lod == 0
+        if self._cur_minibatch != int(minibatch_size) or self._cur_lod != lod:
+            self._cursor = 0
+            self._cur_minibatch = int(minibatch_size)
+            self._cur_lod = lod
 
     def _next_indices(self, n):
         idx = (self._cursor + np.arange(n)) % self.data_size
@@ -64,18 +72,22 @@ class SyntheticDataset:
 
     def get_minibatch_tf(self):  # => images (uint8, device), labels -- this rank's slice of the global minibatch
         assert self._cur_minibatch > 0
-        idx = self._next_indices(self._cur_minibatch)
+        start = self._cursor
+        self._next_indices(self._cur_minibatch)
         per = self._cur_minibatch // self.world_size
-        idx = idx[self.rank * per:(self.rank + 1) * per]
         if self._dev_images is None:
             self._dev_images = torch.from_numpy(self._images).to(self.device)
             self._dev_labels = torch.from_numpy(self._labels).to(self.device)
-        tidx = torch.from_numpy(idx).to(self.device)
+            self._dev_arange = torch.arange(self._cur_minibatch, device=self.device)
+        if self._dev_arange.shape[0] < per:
+            self._dev_arange = torch.arange(per, device=self.device)
+        # indices are formed ON the device from host scalars: no host->device copy, hence no stream synchronisation
+        tidx = (self._dev_arange[:per] + (start + self.rank * per)) % self.data_size
         return self._dev_images[tidx], self._dev_labels[tidx]
 
     def get_random_labels_np(self, minibatch_size):  # => labels
-        if self.label_size > 0:
-            return self._labels[self._label_rng.randint(self.data_size, size=[minibatch_size])]
+        if self.label_size > 0:      # the GLOBAL NumPy stream, like dataset.py:163-166 (the host loop's draws depend on it)
+            return self._labels[np.random.randint(self._labels.shape[0], size=[minibatch_size])]
         return np.zeros([minibatch_size, 0], np.float32)
 
     def get_random_labels_tf(self, minibatch_size):  # => labels

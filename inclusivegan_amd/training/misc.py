@@ -1,7 +1,9 @@
 """Host-side helpers the hot loop uses from the reference's `training/misc.py`:
 adjust_dynamic_range (:36-41) and the NumPy slerp / normalize pair (:190-203) that perturbs the
-matched IMLE latents (training_loop.py:447).  Pickle / image-grid / resume helpers are snapshot
-cosmetics and out of scope."""
+matched IMLE latents (training_loop.py:447), plus the snapshot helpers the loop's setup touches: pickle wrappers
+(:25-31), image grids (:43-74) and `setup_snapshot_image_grid` (:95-143), which advances the training set's iterator and
+fixes how many `grid_latents` are drawn from the host random stream before the IMLE candidates (training_loop.py:171,203).
+Resume bookkeeping from log files (:147-187) is run-directory maintenance and not built."""
 import numpy as np
 
 
@@ -29,3 +31,97 @@ def slerp(a, b, t):
     c = normalize(b - d * a)
     d = a * np.cos(p) + c * np.sin(p)
     return normalize(d)
+
+
+# ----------------------------------------------------------------------------
+# Pickle wrappers (misc.py:20-31; the URL cache is not offered: there is no network path here).
+
+def load_pkl(filename):
+    import pickle
+    with open(filename, 'rb') as file:
+        return pickle.load(file, encoding='latin1')
+
+
+def save_pkl(obj, filename):
+    import pickle
+    with open(filename, 'wb') as file:
+        pickle.dump(obj, file, protocol=pickle.HIGHEST_PROTOCOL)
+
+
+# ----------------------------------------------------------------------------
+# Snapshot image grids (misc.py:43-74,95-143): which reals fill the grid, and how a batch of images is tiled.
+
+def create_image_grid(images, grid_size=None):
+    """[num, (C,) H, W] -> [(C,) grid_h*H, grid_w*W], images laid out row by row; empty cells stay zero."""
+    assert images.ndim == 3 or images.ndim == 4
+    num, img_h, img_w = images.shape[0], images.shape[-2], images.shape[-1]
+    if grid_size is not None:
+        grid_w, grid_h = tuple(grid_size)
+    else:
+        grid_w = max(int(np.ceil(np.sqrt(num))), 1)
+        grid_h = max((num - 1) // grid_w + 1, 1)
+    grid = np.zeros(list(images.shape[1:-2]) + [grid_h * img_h, grid_w * img_w], dtype=images.dtype)
+    for i in range(num):
+        col, row = i % grid_w, i // grid_w
+        grid[..., row * img_h:(row + 1) * img_h, col * img_w:(col + 1) * img_w] = images[i]
+    return grid
+
+
+def convert_to_pil_image(image, drange=[0, 1]):
+    import PIL.Image
+    assert image.ndim == 2 or image.ndim == 3
+    if image.ndim == 3:
+        image = image[0] if image.shape[0] == 1 else image.transpose(1, 2, 0)    # grayscale CHW -> HW, else CHW -> HWC
+    image = adjust_dynamic_range(image, drange, [0, 255])
+    image = np.rint(image).clip(0, 255).astype(np.uint8)
+    return PIL.Image.fromarray(image, 'RGB' if image.ndim == 3 else 'L')
+
+
+def save_image_grid(images, filename, drange=[0, 1], grid_size=None):
+    convert_to_pil_image(create_image_grid(images, grid_size), drange).save(filename)
+
+
+def apply_mirror_augment(minibatch):
+    mask = np.random.rand(minibatch.shape[0]) < 0.5
+    minibatch = np.array(minibatch)
+    minibatch[mask] = minibatch[mask, :, :, ::-1]
+    return minibatch
+
+
+_GRID_SPANS = {'1080p': (1920, 1080, 3, 2), '4k': (3840, 2160, 7, 4), '8k': (7680, 4320, 7, 4)}     # width, height, min columns, min rows
+
+
+def setup_snapshot_image_grid(training_set, size='1080p', layout='random'):
+    """-> ((gw, gh), reals [gw*gh, C, H, W], labels [gw*gh, label_size]).  'random' = the next gw*gh images of the
+    training set's iterator; class layouts ('row_per_class', 'col_per_class', 'class4x4') fill blocks by label arg-max."""
+    gw = gh = 1
+    if size in _GRID_SPANS:
+        span_w, span_h, min_w, min_h = _GRID_SPANS[size]
+        gw = np.clip(span_w // training_set.shape[2], min_w, 32)
+        gh = np.clip(span_h // training_set.shape[1], min_h, 32)
+    reals = np.zeros([gw * gh] + training_set.shape, dtype=training_set.dtype)
+    labels = np.zeros([gw * gh, training_set.label_size], dtype=training_set.label_dtype)
+    if layout == 'random':
+        reals[:], labels[:] = training_set.get_minibatch_np(gw * gh)
+    class_layouts = dict(row_per_class=[gw, 1], col_per_class=[1, gh], class4x4=[4, 4])
+    if layout in class_layouts:
+        bw, bh = class_layouts[layout]
+        nw, nh = (gw - 1) // bw + 1, (gh - 1) // bh + 1
+        blocks = [[] for _ in range(nw * nh)]
+        for _ in range(1000000):
+            real, label = training_set.get_minibatch_np(1)
+            idx = np.argmax(label[0])
+            while idx < len(blocks) and len(blocks[idx]) >= bw * bh:
+                idx += training_set.label_size
+            if idx < len(blocks):
+                blocks[idx].append((real, label))
+                if all(len(block) >= bw * bh for block in blocks):
+                    break
+        for i, block in enumerate(blocks):
+            for j, (real, label) in enumerate(block):
+                x = (i % nw) * bw + j % bw
+                y = (i // nw) * bh + j // bw
+                if x < gw and y < gh:
+                    reals[x + y * gw] = real[0]
+                    labels[x + y * gw] = label[0]
+    return (gw, gh), reals, labels

@@ -14,7 +14,7 @@ one process per GPU (`num_gpus` = torch.distributed world size), every rank runs
 logic from the same NumPy seed (run_training.py:61 `rnd.np_random_seed`) and takes its slice of
 the global minibatch (tf.split, :231-239); gradients are averaged with one RCCL all-reduce per
 step over the flat bucket (tflib/optimizer.py); the IMLE candidates are sharded over ranks and the
-per-real minima are combined with one all-reduce(min) of packed (distance, index) words.
+per-real minima (fp64 distance, index) are combined with two all-reduce(min).
 
 Out of scope here: run-dir / snapshot / metric maintenance (:485-531).
 A `hooks` dict lets a driver (bench.py, tests) observe iterations and stop early.
@@ -34,6 +34,7 @@ from . import dataset
 from . import misc
 from ..dci_code.dci import DCI, unpack_best
 from .. import hip_ops
+from . import imle
 
 #----------------------------------------------------------------------------
 # Function to determine the dimension of random projection (:28-35).
@@ -108,59 +109,71 @@ def _dist_info():
     return 0, 1
 
 
-def combine_best_(best, world):
-    """Merge the per-rank running minima: packed (fp32 distance bits << 32 | candidate index) words are
-    non-negative int64, so an element-wise all-reduce(min) keeps, for every real, the closest candidate
-    over all ranks' shards (ties -> lowest index)."""
+def combine_best_(best_d2, best_idx, world):
+    """Merge the per-rank running minima (fp64 squared distance, int32 candidate index) into the lexicographic minimum
+    over all ranks' candidate shards: all-reduce(min) of the distances, then all-reduce(min) of the indices of the ranks
+    that hold that distance (the others propose INT32_MAX) -- ties go to the lowest index, as in a single search."""
     if world > 1:
-        # the kernels compare the words as unsigned; the collective compares int64: the "nothing yet" word (all ones =
-        # -1) of a rank that had no candidate batch must lose, not win
-        best.copy_(torch.where(best < 0, torch.full_like(best, torch.iinfo(torch.int64).max), best))
-        torch.distributed.all_reduce(best, op=torch.distributed.ReduceOp.MIN)
-    return best
+        mine = best_d2.clone()
+        torch.distributed.all_reduce(best_d2, op=torch.distributed.ReduceOp.MIN)
+        proposal = torch.where(mine == best_d2, best_idx, torch.full_like(best_idx, 2 ** 31 - 1))
+        torch.distributed.all_reduce(proposal, op=torch.distributed.ReduceOp.MIN)
+        best_idx.copy_(proposal)
+    return best_d2, best_idx
 
 
-def imle_refresh(G, training_set_rec, latent_candidates, data_size, minibatch_size, candidate_batch_size,
-                 drange_net, device, rank=0, world=1, query_chunk=4096):
-    """IMLE assignment (:357-406, non-exclusive, no projection): every real image (dataset order,
-    [-1,1] range, flattened CHW) gets the index of its nearest generated candidate and the Euclidean
-    distance.  Candidates are generated batch by batch with G (training weights, validation mode,
-    random noise -- `G.run(..., is_validation=True)`, :361) and folded into a running per-real
-    minimum; rank r handles candidate batches r, r+world, ... and the minima are combined with one
-    all-reduce(min).  Returns (nearest_indices int64 [data_size], dists float64 [data_size]) as NumPy."""
+def imle_refresh(G, training_set_rec, latent_candidates, label_candidates, data_size, minibatch_size, candidate_batch_size,
+                 drange_net, device, rank=0, world=1, query_chunk=4096, infer_minibatch=None, projector=None):
+    """IMLE assignment (:357-406, non-exclusive): every real image (dataset order, [-1,1] range, flattened CHW;
+    times `projector` [C*H*W, proj_dim] when random projection is on, :377-380) gets the index of its nearest generated
+    candidate and the Euclidean distance.  Candidates are generated batch by batch with G (training weights, validation
+    mode, random noise -- `G.run(..., is_validation=True)`, :361) and folded into a running per-real minimum; rank r
+    handles candidate batches r, r+world, ... and the minima are combined across ranks.  The reals are pulled from
+    `training_set_rec` exactly as the reference's query loop does (2 * minibatch_size per call, data_size in all, :374-403).
+    Returns (nearest_indices int64 [data_size], dists float64 [data_size]) as NumPy."""
     num_cand = latent_candidates.shape[0]
     dim = int(np.prod(training_set_rec.shape))
+    pdim = dim if projector is None else int(projector.shape[1])
     # Reals resident on the device in fp32 (30 000 x 49 152 x 4 B = 5.9 GB for CelebA-128).
-    reals = torch.empty((data_size, dim), device=device, dtype=torch.float32)
-    step = max(1, (256 << 20) // (4 * dim))
-    for i in range(0, data_size, step):
-        r, _ = training_set_rec.get_minibatch_np(min(step, data_size - i))
-        r = torch.from_numpy(r).to(device).to(torch.float32)
-        reals[i:i + r.shape[0]] = misc.adjust_dynamic_range(r, training_set_rec.dynamic_range, drange_net).reshape(r.shape[0], -1)
+    reals = torch.empty((data_size, pdim), device=device, dtype=torch.float32)
+    mb2 = minibatch_size * 2
+    assert data_size % mb2 == 0
+    per_upload = max(1, (256 << 20) // (4 * dim * mb2))        # query batches per host->device copy
+    i = 0
+    while i < data_size:
+        nb = min(per_upload, (data_size - i) // mb2)
+        host = np.concatenate([training_set_rec.get_minibatch_np(mb2)[0] for _ in range(nb)], axis=0)
+        r = torch.from_numpy(host).to(device).to(torch.float32)
+        r = misc.adjust_dynamic_range(r, training_set_rec.dynamic_range, drange_net).reshape(r.shape[0], -1)
+        reals[i:i + r.shape[0]] = r if projector is None else hip_ops.matmul(r, projector)
+        i += r.shape[0]
     rnorm = hip_ops.row_sqnorm_raw(reals)
-    best = torch.full((data_size,), -1, device=device, dtype=torch.int64)
+    best_d2, best_idx = hip_ops.nn1_state(data_size, device)
     nbatches = (num_cand + candidate_batch_size - 1) // candidate_batch_size
-    label_size = training_set_rec.label_size
     with torch.no_grad():
         for b in range(rank, nbatches, world):
             c0 = b * candidate_batch_size
             z = torch.from_numpy(latent_candidates[c0:c0 + candidate_batch_size]).to(device)
-            lab = torch.zeros((z.shape[0], label_size), device=device)
+            lab = torch.from_numpy(np.ascontiguousarray(label_candidates[c0:c0 + candidate_batch_size], dtype=np.float32)).to(device)
             imgs = []
             # Inference batch: the reference feeds sched.minibatch_size at a time (G.run(..., minibatch_size=), :361);
             # the images do not depend on how the candidates are batched, so use a batch that fills the MFMA
             # tiles (bounded so that the largest intermediate, [n, C, 2R+1, 2R+1], stays under 2 GiB).
             per_img = 4 * max(training_set_rec.shape[0], 128) * (training_set_rec.shape[1] * 2 + 1) ** 2 // 4
-            infer_batch = int(max(minibatch_size, min(candidate_batch_size, 64, (1 << 30) // max(per_img, 1))))
+            infer_batch = infer_minibatch or int(max(minibatch_size, min(candidate_batch_size, 64, (1 << 30) // max(per_img, 1))))
             for j in range(0, z.shape[0], infer_batch):
                 imgs.append(G.get_output_for(z[j:j + infer_batch], lab[j:j + infer_batch], is_validation=True))
             cand = torch.cat(imgs, dim=0).contiguous().reshape(z.shape[0], -1)   # logical NCHW flatten (:363)
+            if not bool(torch.isfinite(cand).all()):
+                raise FloatingPointError('IMLE refresh: the generator produced non-finite candidate images (batch %d)' % b)
+            if projector is not None:
+                cand = hip_ops.matmul(cand, projector)                           # :365
             cnorm = hip_ops.row_sqnorm_raw(cand)
             for q0 in range(0, data_size, query_chunk):
                 hip_ops.nn1_update_raw(reals[q0:q0 + query_chunk], rnorm[q0:q0 + query_chunk], cand, cnorm,
-                                       best[q0:q0 + query_chunk], c0)
-    combine_best_(best, world)
-    idx, dist = unpack_best(best)
+                                       best_d2[q0:q0 + query_chunk], best_idx[q0:q0 + query_chunk], c0)
+    combine_best_(best_d2, best_idx, world)
+    idx, dist = unpack_best(best_d2, best_idx)
     return idx.cpu().numpy(), dist.cpu().numpy().astype(np.float64)
 
 #----------------------------------------------------------------------------
@@ -207,7 +220,7 @@ def training_loop(
     # --- extensions (not in the reference) ---
     attr_names              = None,     # list of attribute names (reference reads celeba/Anno/list_attr_celeba.txt, :174-180)
     lpips_func_name         = 'inclusivegan_amd.metrics.lpips.vgg16_zhang_perceptual',
-    hooks                   = None,     # {'on_iteration': f(state) -> bool stop, 'on_refresh': f(seconds)}
+    hooks                   = None,     # {'on_iteration': f(state) -> bool stop, 'on_refresh': f(seconds), 'on_batch': f(host batch dict)}
     hip_graphs              = True,     # capture the four training ops into hipGraphs (env IGAN_HIP_GRAPHS=0 disables)
     submit_config           = None,
     ):
@@ -215,8 +228,6 @@ def training_loop(
     hooks = hooks or {}
     if resume_pkl is not None:
         raise NotImplementedError('resume_pkl: checkpoint interchange is a later row (SURVEY.md section 8f)')
-    if init_proj_dim is not None:
-        raise NotImplementedError('random projection before NN search is not built (default is no projection)')
     if exclusive_retrieved_code:
         raise NotImplementedError('exclusive_retrieved_code needs k-NN with k>1; only the default 1-NN path is built')
 
@@ -234,8 +245,17 @@ def training_loop(
     training_set = dataset.load_dataset(data_dir=data_dir, verbose=(rank == 0), device=device, rank=rank, world_size=world, **ds_args)
     training_set_rec = dataset.load_dataset(data_dir=data_dir, verbose=False, device=device, rank=0, world_size=1, **ds_args)
 
-    if attr_interesting is not None:
-        assert attr_names is not None, 'attr_interesting needs attr_names (celeba/Anno/list_attr_celeba.txt is not shipped)'
+    grid_size, grid_reals, grid_labels = misc.setup_snapshot_image_grid(training_set, **grid_args)   # :171 (walks training_set's iterator)
+
+    if attr_interesting is not None and attr_names is None:
+        # :174-180 reads the vocabulary from celeba/Anno/list_attr_celeba.txt (relative to the working directory)
+        import os
+        attr_file = 'celeba/Anno/list_attr_celeba.txt'
+        if not os.path.isfile(attr_file):
+            raise FileNotFoundError('attr_interesting=%r needs the attribute names: pass attr_names=[...] or provide %s' % (attr_interesting, attr_file))
+        if rank == 0:
+            print('Loading attributes from "%s"...' % attr_file)
+        attr_names = imle.attribute_names(attr_file)
 
     # Construct networks (:188-197).  Same seed on every rank => bit-identical replicas.
     G_args = dict(G_args); D_args = dict(D_args)
@@ -246,6 +266,16 @@ def training_loop(
     Gs = G.clone('Gs')
     lpips = tflib.Network('lpips', func_name=lpips_func_name, resolution=training_set.shape[1], device=device, seed=np_seed + 3)
     proj_dim = func_proj_dim(init_proj_dim, data_size, num_samples_factor, G)
+    grid_latents = np.random.randn(int(np.prod(grid_size)), *G.input_shapes[0][1:])      # :203 (consumes the host stream)
+
+    # Build random projector (:205-213; the reference caches it in an .npy next to the run -- not done here)
+    projector = None
+    if init_proj_dim is not None:
+        out_dim = int(np.prod(G.output_shape[1:]))
+        if rank == 0:
+            print('Building random projector %d to %d...' % (out_dim, proj_dim))
+        projector_np = np.random.normal(loc=0.0, scale=1.0 / float(proj_dim), size=(out_dim, proj_dim)).astype(np.float64)
+        projector = torch.from_numpy(projector_np.astype(np.float32)).to(device)
 
     if rank == 0:
         G.print_layers(); D.print_layers()
@@ -291,6 +321,8 @@ def training_loop(
         reals_rec_2=torch.zeros((B, C, R, R), device=device), labels_rec_2=torch.zeros((B, LS), device=device),
         latents_rec_2=torch.zeros([B] + G.input_shapes[0][1:], device=device),
         reals=torch.zeros((2 * B, C, R, R), device=device, dtype=torch.uint8), labels=torch.zeros((2 * B, LS), device=device))
+    staging = [dict({k: torch.empty(v.shape, dtype=torch.float32).pin_memory() for k, v in feed.items() if '_rec_' in k},
+                    event=torch.cuda.Event()) for _ in range(3)]
     use_graphs = graphs.graphs_enabled(hip_graphs)
 
     def G_grad():
@@ -298,9 +330,12 @@ def training_loop(
         D.requires_grad_(False)
         reals_1, labels_1 = process_reals(feed['reals_rec_1'], feed['labels_rec_1'], 0, mirror_augment, training_set.dynamic_range, drange_net)
         reals_2, labels_2 = process_reals(feed['reals_rec_2'], feed['labels_rec_2'], 0, mirror_augment, training_set.dynamic_range, drange_net)
-        loss, _ = G_loss_fn(G=G, D=D, lpips=lpips, training_set=training_set, minibatch_size=B,
-                            reals_rec_1=reals_1, labels_rec_1=labels_1, latents_rec_1=feed['latents_rec_1'],
-                            reals_rec_2=reals_2, labels_rec_2=labels_2, latents_rec_2=feed['latents_rec_2'], phase='loss', **G_loss_args)
+        loss, reg = G_loss_fn(G=G, D=D, lpips=lpips, training_set=training_set, minibatch_size=B,
+                              reals_rec_1=reals_1, labels_rec_1=labels_1, latents_rec_1=feed['latents_rec_1'],
+                              reals_rec_2=reals_2, labels_rec_2=labels_2, latents_rec_2=feed['latents_rec_2'],
+                              phase='loss' if lazy_regularization else 'both', **G_loss_args)
+        if not lazy_regularization and reg is not None:
+            loss = loss + reg       # :284-285 (broadcasts [B] + [B // pl_minibatch_shrink] exactly as the reference's `+=` does, or fails like it)
         G_opt.differentiate(torch.mean(loss), G)                    # register_gradients(tf.reduce_mean(G_loss)) :290
         D.requires_grad_(True)
         return loss
@@ -319,7 +354,10 @@ def training_loop(
         G.invalidate_derived(); D.invalidate_derived()
         reals, labels = process_reals(feed['reals'], feed['labels'], 0, mirror_augment, training_set.dynamic_range, drange_net)
         G.requires_grad_(False)
-        loss, _ = D_loss_fn(G=G, D=D, training_set=training_set, minibatch_size=B, reals=reals, labels=labels, phase='loss', **D_loss_args)
+        loss, reg = D_loss_fn(G=G, D=D, training_set=training_set, minibatch_size=B, reals=reals, labels=labels,
+                              phase='loss' if lazy_regularization else 'both', **D_loss_args)
+        if not lazy_regularization and reg is not None:
+            loss = loss + reg       # :286
         G.requires_grad_(True)
         D_opt.differentiate(torch.mean(loss), D)                    # :291
         return loss
@@ -345,7 +383,7 @@ def training_loop(
         saved = {n: v.clone() for n, v in G.vars.items() if n in ('dlatent_avg',)}
         for k in ('latents_rec_1', 'latents_rec_2'):
             feed[k].normal_()
-        for step in (G_grad_step, G_reg_step, D_grad_step, D_reg_step):
+        for step in ((G_grad_step, G_reg_step, D_grad_step, D_reg_step) if lazy_regularization else (G_grad_step, D_grad_step)):
             step()      # eager
             step()      # capture + first replay
         with torch.no_grad():
@@ -394,11 +432,21 @@ def training_loop(
     tick_start_time = time.time()
     start_time = tick_start_time
     running_mb_counter = 0
-    cursor = 0
     latent_candidates = np.random.randn(data_size * num_samples_factor, *G.input_shapes[0][1:]).astype(np.float32)  # :325
 
-    selected_latents = None
-    remained = None          # (reals, labels, latents) carried over between iterations (:328-330)
+    def search(latents, label_candidates, minibatch_size):
+        t0 = time.time()
+        out = imle_refresh(G, training_set_rec, latents, label_candidates, data_size, minibatch_size, candidate_batch_size,
+                           drange_net, device, rank=rank, world=world, projector=projector)
+        torch.cuda.synchronize()
+        if 'on_refresh' in hooks:
+            hooks['on_refresh'](time.time() - t0)
+        return out
+
+    # Host side of the IMLE term (:325-464): refresh cadence, selection, carry-over, perturbation, shuffles -- training/imle.py
+    sampler = imle.ImleSampler(training_set_rec, latent_candidates, data_size, num_samples_factor, init_staleness, knn_perturb_factor,
+                               dist_thres_percentile=dist_thres_percentile, attr_interesting=attr_interesting, attr_names=attr_names,
+                               search=search)
     stop = False
     while cur_nimg < total_kimg * 1000 and not stop:
         # Choose training parameters (:336-340).
@@ -416,66 +464,27 @@ def training_loop(
             run_G_reg = (lazy_regularization and running_mb_counter % G_reg_interval == 0)
             run_D_reg = (lazy_regularization and running_mb_counter % D_reg_interval == 0)
 
-            # IMLE refresh (:354-406).
-            if selected_latents is None or cur_nimg // (data_size * init_staleness) != (cur_nimg - mb * 2) // (data_size * init_staleness):
-                if selected_latents is not None:
-                    init_staleness *= 2
-                t0 = time.time()
-                nearest_indices, selected_dists = imle_refresh(
-                    G, training_set_rec, latent_candidates, data_size, sched.minibatch_gpu, candidate_batch_size,
-                    drange_net, device, rank=rank, world=world)
-                cursor += data_size     # the reference's query loop walks the whole set once (:403)
-                selected_latents = latent_candidates[nearest_indices]
-                dist_thres = np.percentile(selected_dists, dist_thres_percentile)
-                torch.cuda.synchronize()
-                if 'on_refresh' in hooks:
-                    hooks['on_refresh'](time.time() - t0)
+            # IMLE refresh (:354-406) and this iteration's (real, label, latent) triples (:409-464).
+            if sampler.refresh_due(cur_nimg, mb):
+                sampler.refresh(mb)
+            batch = sampler.next_batch(mb)
+            if 'on_batch' in hooks:
+                hooks['on_batch'](batch)
+            halves = [(batch['reals_rec_%d' % h], batch['labels_rec_%d' % h], batch['latents_rec_%d' % h]) for h in (1, 2)]
 
-            # Sync IMLE loss with G training loss (:409-441).
-            if remained is None or cursor % data_size == 0:
-                cur = None
-            else:
-                cur = [np.array(a) for a in remained]
-            while cur is None or cur[0].shape[0] < mb * 2:
-                reals_t, labels_t = training_set_rec.get_minibatch_np(mb * 2)
-                reals_t = reals_t.astype(np.float32)
-                pos = cursor % data_size
-                latents_t = selected_latents[pos:pos + mb * 2]
-                if attr_interesting is None:
-                    selected_idx = selected_dists[pos:pos + mb * 2] <= dist_thres
-                else:
-                    active = np.ones(labels_t.shape[0])
-                    for attr in attr_interesting.split(','):
-                        active *= labels_t[:, attr_names.index(attr)]
-                    selected_idx = active == 1
-                sel = [reals_t[selected_idx], labels_t[selected_idx], latents_t[selected_idx]]
-                if cur is None or cursor % data_size == 0:
-                    cur = [np.array(a) for a in sel]
-                else:
-                    cur = [np.concatenate((a, b), axis=0) for a, b in zip(cur, sel)]
-                if cur[0].shape[0] > mb * 2:
-                    remained = [np.array(a[mb * 2:]) for a in cur]
-                    cur = [np.array(a[:mb * 2]) for a in cur]
-                else:
-                    remained = None
-                cursor += mb * 2
-
-            cur_reals, cur_labels, cur_latents = cur
-            cur_latents = misc.slerp(cur_latents, np.random.randn(*cur_latents.shape).astype(np.float32), knn_perturb_factor)  # :447
-            halves = []
-            for h in range(2):
-                order = np.arange(mb)
-                np.random.shuffle(order)                                         # :456-464
-                sl = slice(h * mb, (h + 1) * mb)
-                halves.append((cur_reals[sl][order], cur_labels[sl][order], cur_latents[sl][order]))
-
-            # This rank's slice of the global minibatch (tf.split, :231-239) -> static device buffers.
+            # This rank's slice of the global minibatch (tf.split, :231-239) -> pinned staging -> static device buffers.
+            # The copies are asynchronous (a pageable source would make every copy a stream synchronisation, i.e. an idle
+            # device while the host prepares the next iteration -- and an idle-prone device also runs at a lower clock).
             assert sched.minibatch_gpu == B, 'minibatch_gpu must stay constant (static buffers / captured graphs)'
             rs = slice(rank * B, (rank + 1) * B)
+            stage = staging[running_mb_counter % len(staging)]
+            stage['event'].synchronize()            # the copy that last read this staging set has run
             for h, (r_, l_, z_) in enumerate(halves):
-                feed['reals_rec_%d' % (h + 1)].copy_(torch.from_numpy(np.ascontiguousarray(r_[rs])), non_blocking=True)
-                feed['labels_rec_%d' % (h + 1)].copy_(torch.from_numpy(np.ascontiguousarray(l_[rs])), non_blocking=True)
-                feed['latents_rec_%d' % (h + 1)].copy_(torch.from_numpy(np.ascontiguousarray(z_[rs]).astype(np.float32)), non_blocking=True)
+                for key, arr in (('reals_rec_%d', r_), ('labels_rec_%d', l_), ('latents_rec_%d', z_)):
+                    key = key % (h + 1)
+                    stage[key].copy_(torch.from_numpy(np.ascontiguousarray(arr[rs], dtype=np.float32)))
+                    feed[key].copy_(stage[key], non_blocking=True)
+            stage['event'].record()
 
             # Run training ops (:474-479).
             timed = hooks.get('op_times')          # optional: dict name -> list of (start, end) HIP events

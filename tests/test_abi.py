@@ -24,7 +24,12 @@ def test_header_symbols_are_exported_and_bound():
     for name in declared:
         assert hasattr(lib, name), name
     assert sorted(_abi.SIGNATURES) == declared
-    assert lib.igan_abi_version() == 1
+    header = open(os.path.join(ROOT, 'include', 'igan_hip.h')).read()
+    assert lib.igan_abi_version() == _abi.ABI_VERSION == int(re.search(r'#define IGAN_ABI_VERSION (\d+)', header).group(1))
+    # the library and the binding agree on every struct size (a stale .so must not load)
+    for which, struct in enumerate(_abi.STRUCTS):
+        assert lib.igan_struct_size(which) == ctypes.sizeof(struct), struct.__name__
+    assert lib.igan_struct_size(len(_abi.STRUCTS)) == 0
 
 
 def test_struct_layouts_match_header_field_order():

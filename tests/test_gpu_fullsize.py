@@ -121,13 +121,54 @@ def test_nn1_against_cdist_and_idempotence(cuda_device):
     q = torch.rand(nq, dim, generator=g).to(dev) * 2 - 1
     c = torch.rand(nc, dim, generator=g).to(dev) * 2 - 1
     qn = hip_ops.row_sqnorm_raw(q); cn = hip_ops.row_sqnorm_raw(c)
-    best = torch.full((nq,), -1, device=dev, dtype=torch.int64)
-    hip_ops.nn1_update_raw(q, qn, c, cn, best, 0)
-    once = best.clone()
-    hip_ops.nn1_update_raw(q, qn, c, cn, best, 0)
-    assert torch.equal(best, once)
-    idx, dist = unpack_best(best)
+    bd, bi = hip_ops.nn1_state(nq, dev)
+    hip_ops.nn1_update_raw(q, qn, c, cn, bd, bi, 0)
+    once = (bd.clone(), bi.clone())
+    hip_ops.nn1_update_raw(q, qn, c, cn, bd, bi, 0)
+    assert torch.equal(bd, once[0]) and torch.equal(bi, once[1])
+    idx, dist = unpack_best(bd, bi)
     ref = torch.cdist(q[:128].double(), c.double())
     rd, ri = ref.min(dim=1)
     assert torch.equal(idx[:128].cpu(), ri.cpu())
-    assert float((dist[:128].double().cpu() - rd.cpu()).abs().max() / rd.max()) < 1e-5
+    assert float((dist[:128].cpu() - rd.cpu()).abs().max() / rd.max()) < 1e-9      # winners are measured in fp64
+
+
+def test_nn1_near_ties_decided_in_fp64(cuda_device):
+    """Planted near-ties at dim 49 152 (the reference decides on fp64 distances, dci_code/src/util.c:62-69): per query
+    eight candidates lie at distances 0.1 * (1 + k * 2^-12) -- gaps of 2.4e-5 relative in d^2 = 5e-7 absolute, four orders
+    of magnitude below the cancellation error of |q|^2 + |c|^2 - 2 q.c in fp32 (~1e-6 * 3e4) -- scattered over the
+    candidate batches among far random rows.  The arg-min and its distance must equal the fp64 brute-force search of
+    oracle/nn.py exactly, whatever the batch order."""
+    from inclusivegan_amd import hip_ops
+    from inclusivegan_amd.dci_code.dci import unpack_best
+    from oracle import nn as ONN
+    dev = cuda_device
+    rng = np.random.RandomState(5)
+    dim, nq, nc, nb = 49152, 24, 96, 4
+    q = rng.uniform(-1, 1, size=(nq, dim)).astype(np.float32)
+    c = rng.uniform(-1, 1, size=(nb * nc, dim)).astype(np.float32)
+    want = np.empty(nq, dtype=np.int64)
+    for i in range(nq):
+        slots = rng.choice(nb * nc, size=8, replace=False)
+        order = rng.permutation(8)                      # which planted rank sits in which slot
+        for k, slot in zip(order, slots):
+            row = q[i].copy()
+            j = rng.randint(dim)
+            row[j] = np.float32(row[j] + 0.1 * (1.0 + k * 2.0 ** -12) * (1 if row[j] < 0 else -1))
+            c[slot] = row
+    oidx, odist = ONN.nearest_neighbour(c, q)
+    qd = torch.from_numpy(q).to(dev); cd = torch.from_numpy(c).to(dev)
+    qn = hip_ops.row_sqnorm_raw(qd)
+    for batches in (range(nb), reversed(range(nb))):
+        bd, bi = hip_ops.nn1_state(nq, dev)
+        for b in batches:
+            cb = cd[b * nc:(b + 1) * nc]
+            hip_ops.nn1_update_raw(qd, qn, cb, hip_ops.row_sqnorm_raw(cb), bd, bi, b * nc)
+        idx, dist = unpack_best(bd, bi)
+        assert np.array_equal(idx.cpu().numpy(), oidx.astype(np.int64))
+        assert np.abs(dist.cpu().numpy() - odist).max() <= 1e-12 * odist.max()
+    # a non-finite candidate can never win, and does not poison the state
+    cd2 = cd[:nc].clone(); cd2[3, 7] = float('nan'); cd2[5, 9] = float('inf')
+    bd, bi = hip_ops.nn1_state(nq, dev)
+    hip_ops.nn1_update_raw(qd, qn, cd2, hip_ops.row_sqnorm_raw(cd2), bd, bi, 0)
+    assert bool(torch.isfinite(bd).all()) and not bool(((bi == 3) | (bi == 5)).any())

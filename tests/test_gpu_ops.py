@@ -581,7 +581,7 @@ def test_nn1_large_dim_and_ties(cuda_device):
     idx, dist = db.query(torch.from_numpy(q).to(cuda_device), num_neighbours=1)
     oidx, odist = ONN.nearest_neighbour(data, q)
     assert [int(i[0]) for i in idx] == [5, 100, 299] == list(oidx)
-    assert np.abs(np.array([d[0] for d in dist]) - odist).max() < 1e-5 * odist.max()   # refined: direct differences
+    assert np.abs(np.array([d[0] for d in dist]) - odist).max() < 1e-12 * odist.max()   # fp32 data: the fp64 direct-difference distance is exact
 
 
 # ----------------------------------------------------------------------------- optimizer kernels

@@ -169,16 +169,16 @@ def _dp_worker(rank, world, port, out):
     # gradient exchange: every rank holds its own bucket; after the exchange all hold the mean
     g = torch.arange(10, dtype=torch.float32) * (rank + 1)
     allreduce_mean_(g, num_registered=1)
-    # IMLE shards: rank r saw candidates r, r+world, ...; packed (dist bits << 32 | idx)
-    d = torch.tensor([[4.0, 1.0, 9.0], [2.0, 3.0, 9.0]])[rank]
-    idx = torch.tensor([[10, 11, 12], [20, 21, 5]])[rank]
-    best = (d.view(torch.int32).to(torch.int64) << 32) | idx
-    combine_best_(best, world)
-    bi, bd = unpack_best(best)
-    # a rank without any candidate batch still holds the "nothing yet" word (all ones): it must lose the exchange
-    lone = torch.full((3,), -1, dtype=torch.int64) if rank == 1 else best.clone()
-    combine_best_(lone, world)
-    assert torch.equal(lone, best)
+    # IMLE shards: rank r saw candidates r, r+world, ...; running minimum = (squared distance fp64, index int32)
+    d = torch.tensor([[4.0, 1.0, 9.0], [2.0, 3.0, 9.0]], dtype=torch.float64)[rank]
+    idx = torch.tensor([[10, 11, 12], [20, 21, 5]], dtype=torch.int32)[rank]
+    combine_best_(d, idx, world)
+    bi, bd = unpack_best(d, idx)
+    # a rank without any candidate batch still holds the initial state (+inf, INT32_MAX): it must lose the exchange
+    ld = torch.full((3,), float('inf'), dtype=torch.float64) if rank == 1 else d.clone()
+    li = torch.full((3,), 2 ** 31 - 1, dtype=torch.int32) if rank == 1 else idx.clone()
+    combine_best_(ld, li, world)
+    assert torch.equal(ld, d) and torch.equal(li, idx)
     # identical host-side streams on every rank (np seed) -> identical shuffles / candidate latents
     np.random.seed(1000)
     order = np.arange(12); np.random.shuffle(order)
