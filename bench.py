@@ -3,7 +3,8 @@
 on synthetic CelebA-shaped 128x128 batches, one process per GPU.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: either under a launcher -- python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ... --
+     or bare: the script then starts its N ranks itself as a child torch.distributed.run)
 
 A "step" is one iteration of the reference's host loop (training/training_loop.py:466-482): G step,
 G path-length reg every 4th, D step + Gs EMA, D R1 reg every 16th; it advances the image counter by
@@ -12,9 +13,10 @@ G path-length reg every 4th, D step + Gs EMA, D R1 reg every 16th; it advances t
 separately (`imle_refresh_s`), as BASELINE.md prescribes.
 
 Prints ONE JSON line on rank 0.  Besides the contract fields it carries
-  roofline      the dominant kernel (f32-MFMA conv2d forward, 128x128 Conv1 shape) timed with HIP
-                events in this process: algorithmic FLOPs / launch time vs the 157.3 TFLOP/s f32
-                matrix peak of MI355X;
+  roofline      the dominant kernel (f32-MFMA conv2d forward) timed per launch INSIDE the replayed training
+                graphs with device-side time stamps: algorithmic FLOPs / launch time vs the 157.3 TFLOP/s f32
+                matrix peak of MI355X; the north-star shape (128x128 Conv1) alone and the HBM-bound upfirdn2d
+                (GB/s vs 8 TB/s) with HIP events, sustained;
   cpu_baseline  the CPU oracle (oracle/, PyTorch-CPU fp32) timed on this box's host cores on a
                 bounded sample of the same workload (rank 0, N = 1 only).
 """
@@ -29,6 +31,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 F32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (about 6.3 TB/s achievable)
 
 
 def parse_args():
@@ -44,12 +47,15 @@ def parse_args():
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true')
     p.add_argument('--op-times', action='store_true', help='also report the mean device time of each training op (HIP events)')
+    p.add_argument('--conv-shapes', default=None, metavar='FILE', help='write the per-shape table of the conv family inside the replayed graphs (device stamps) to FILE')
     return p.parse_args()
 
 
-def headline_shape_roofline(device, batch, reps=20):
+def headline_shape_roofline(device, batch, reps=40, warm_s=0.4):
     """The north-star shape: modulated conv 128x128 Conv1 (GEMM M = batch*128*128, N = 128, K = 1152;
-    SURVEY.md section 8a/8d), timed alone with HIP events on the launch stream."""
+    SURVEY.md section 8a/8d), timed alone with HIP events on the launch stream.  The shape first runs back to back for
+    `warm_s` seconds: the device leaves its idle clock only after a few hundred milliseconds of load, and a measurement
+    taken during that ramp (as in round 1) reads ~20 % low."""
     import torch
     from inclusivegan_amd import hip_ops
     cin = cout = 128
@@ -59,9 +65,11 @@ def headline_shape_roofline(device, batch, reps=20):
     s = torch.rand(batch, cin, device=device) + 0.5
     d = torch.rand(batch, cout, device=device) + 0.5
     geom = hip_ops.ConvGeom(3, 3, 1, 1, 1, 1)
-    for _ in range(3):
-        hip_ops.conv2d_raw(x, w, geom, (res, res), cout, in_scale=s, out_scale=d)
-    torch.cuda.synchronize()
+    t0 = time.time()
+    while time.time() - t0 < warm_s:
+        for _ in range(20):
+            hip_ops.conv2d_raw(x, w, geom, (res, res), cout, in_scale=s, out_scale=d)
+        torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     e0.record()     # same stream the kernels are launched on (torch's current stream)
@@ -77,31 +85,101 @@ def headline_shape_roofline(device, batch, reps=20):
                flops_per_launch=flops, us_per_launch=round(ms * 1e3, 1), traffic=None)
     # HBM-side bytes per launch of this shape from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled per
     # the gfx950 correction + WRITE_SIZE); only valid for the batch they were taken at.
-    pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_conv_headline.json')
-    if batch == 6 and os.path.isfile(pmc):
+    pmc = _latest_profile('pmc_conv_headline.json')
+    if batch == 6 and pmc:
         with open(pmc) as f:
             out['traffic'] = json.load(f)['traffic_bytes_per_launch']
     return out
 
 
-def step_roofline(log):
-    """Roofline of the dominant kernel over the launches of real training iterations: per-launch HIP
-    events (recorded by hip_ops.conv2d_raw on the launch stream) grouped by kernel instantiation; the
-    instantiation with the largest total time is the dominant kernel.  achieved = sum of algorithmic
-    FLOPs / sum of launch durations; avg_launch_us is what a rocprofv3 --stats run reports as that
-    kernel's average duration (launches with split-K include their small reduce kernel)."""
+def _latest_profile(suffix):
+    """profiles/rNN_<suffix> of the highest round present (evidence files are named per round)."""
+    import glob
+    hits = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_' + suffix)))
+    return hits[-1] if hits else None
+
+
+def hbm_kernel_roofline(device, batch, warm_s=0.2, reps=40):
+    """The HBM-bound kernel north_star names: upfirdn2d at its three 128x128 call sites (FIR after the up-convolution in G,
+    FIR before the two strided convolutions in D), sustained, HIP events on the launch stream.  Algorithmic bytes =
+    (numel_in + numel_out) * 4."""
+    import numpy as np
+    import torch
+    from inclusivegan_amd import hip_ops
+    k = np.outer([1, 3, 3, 1], [1, 3, 3, 1]).astype(np.float32) / 64
+    sites = [('G Conv0_up post-filter', (batch, 129, 129, 128), k * 4, 1, 1),
+             ('D Conv1_down pre-filter', (2 * batch, 128, 128, 128), k, 2, 2),
+             ('D Skip pre-filter', (2 * batch, 128, 128, 128), k, 1, 1)]
+    tot_b = tot_s = 0.0
+    per_site = {}
+    for name, shape, kk, p0, p1 in sites:
+        x = torch.randn(*shape, device=device)
+        fn = lambda: hip_ops.upfirdn2d_raw(x, kk, 1, 1, 1, 1, p0, p1, p0, p1)
+        y = fn()
+        t0 = time.time()
+        while time.time() - t0 < warm_s:
+            for _ in range(20):
+                fn()
+            torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        sec = e0.elapsed_time(e1) * 1e-3 / reps
+        by = (x.numel() + y.numel()) * 4.0
+        per_site[name] = round(by / sec / 1e9, 1)
+        tot_b += by; tot_s += sec
+    gbs = tot_b / tot_s / 1e9
+    out = dict(bound='hbm', kernel='upfirdn2d_fir4_kernel', achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s',
+               frac=round(gbs / HBM_PEAK_GBS, 4), bytes_per_launch=round(tot_b / len(sites)), us_per_launch=round(tot_s / len(sites) * 1e6, 1),
+               sites_GBps=per_site, traffic=None)
+    pmc = _latest_profile('pmc_upfirdn.json')
+    if batch == 6 and pmc:
+        with open(pmc) as f:
+            out['traffic'] = json.load(f)['traffic_bytes_per_launch']
+    return out
+
+
+def step_roofline(stamp, steps, shapes_file=None):
+    """Roofline of the dominant kernel over the launches of real training iterations, measured with the device running
+    exactly as in the timed region: the training ops' hipGraphs are re-captured with a pair of device-side time stamps around
+    every conv-family launch (hip_ops.StampLog: one-wave kernels reading the 100 MHz counter in stream order, plus a fold
+    kernel per graph that accumulates the durations), then replayed for further iterations.  Launches are grouped by kernel
+    instantiation; the one with the largest total time is the dominant kernel.  achieved = sum of algorithmic FLOPs / sum of
+    launch durations; avg_launch_us is what `rocprofv3 --kernel-trace --stats` of the same command reports as that kernel's
+    average duration (+ the ~1 us from stamp to kernel start).  (Round 1 timed eager launches with host events: the host-bound
+    eager loop leaves the device idle between kernels, which lowers its clock and read 6-9 % low.)"""
+    totals = stamp.totals_us()
+    replays = {}
+    for step, (first, count) in steps.items():
+        for i in range(first, first + count):
+            replays[i] = step.replays
     agg = {}
-    for name, flops, splits, e0, e1 in log:
+    for i, (name, flops, us) in enumerate(totals):
+        n = replays.get(i, 0)
+        if n == 0 or us <= 0 or not name.startswith('conv_fwd_kernel'):
+            continue        # the roofline entry is about the forward-type MFMA kernel (conv, data gradients); others stay in conv_family_tflops
         a = agg.setdefault(name, [0, 0.0, 0.0])
-        a[0] += 1
-        a[1] += flops
-        a[2] += e0.elapsed_time(e1) * 1e-3
+        a[0] += n
+        a[1] += flops * n
+        a[2] += us * 1e-6
     name, (calls, flops, secs) = max(agg.items(), key=lambda kv: kv[1][2])
     achieved = flops / secs / 1e12
     total_conv = sum(v[2] for v in agg.values())
+    fam_us = sum(us for i, (_, _, us) in enumerate(totals) if replays.get(i, 0) > 0)
+    fam_flops = sum(flops * replays.get(i, 0) for i, (_, flops, _) in enumerate(totals))
+    if shapes_file:
+        with open(shapes_file, 'w') as f:
+            f.write('# conv family inside the replayed training graphs (device stamps), %d stamped iterations; sorted by time\n' % max(replays.values()))
+            f.write('# %-78s %-58s %8s %10s %8s\n' % ('shape', 'kernel', 'launches', 'total us', 'TFLOP/s'))
+            for shape, kname, n, us, tf in stamp.shape_table(replays):
+                f.write('%-80s %-58s %8d %10.1f %8.1f\n' % (shape, kname[:58], n, us, tf))
+            f.write('# total %.1f ms, %.1f TFLOP/s\n' % (fam_us / 1e3, fam_flops / max(fam_us, 1e-9) / 1e6))
     return dict(bound='mfma', kernel=name, achieved=round(achieved, 2), peak=F32_MATRIX_PEAK_TFLOPS, unit='TFLOP/s',
                 frac=round(achieved / F32_MATRIX_PEAK_TFLOPS, 4), launches=calls, avg_launch_us=round(secs / calls * 1e6, 1),
-                flops_per_launch=round(flops / calls), share_of_conv_time=round(secs / total_conv, 3), traffic=None)
+                flops_per_launch=round(flops / calls), share_of_conv_time=round(secs / total_conv, 3),
+                conv_family_tflops=round(fam_flops / max(fam_us, 1e-9) / 1e6, 2), timing='device stamps inside the replayed hipGraphs', traffic=None)
 
 
 def cpu_baseline(resolution, batch, lpips_weight):
@@ -171,8 +249,24 @@ def log(msg):
 _T0 = time.time()
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU under
+    torch.distributed.run, rendezvous on 127.0.0.1) as a CHILD process -- nothing in this parent has touched the GPU --
+    pass its output through and exit with its code."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC: required for RCCL between processes on these hosts
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and 'RANK' not in os.environ and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args))
     import torch
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -182,7 +276,7 @@ def main():
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.distributed.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    assert world == args.gpus, '--gpus %d but WORLD_SIZE is %d' % (args.gpus, world)
 
     from inclusivegan_amd import _abi
     _abi.get_plugin()   # fail loudly if the HIP extension is missing
@@ -191,7 +285,7 @@ def main():
 
     B = args.minibatch_gpu
     state = dict(t_start=None, t_end=None, refresh=[], iters=0)
-    profile_iters = 0 if args.no_roofline else 16     # eager, per-launch-timed iterations after the timed region
+    profile_iters = 0 if args.no_roofline else 16     # stamped iterations (graphs re-captured with device time stamps) after the timed region
 
     def barrier_sync():
         if world > 1:
@@ -209,12 +303,15 @@ def main():
             state['t_end'] = time.perf_counter()
             if profile_iters == 0:
                 return True
-            # roofline leg: same iterations, run eagerly with every conv launch bracketed by HIP events
+            # roofline leg: the same iterations with the graphs re-captured around device-side time stamps
             from inclusivegan_amd import hip_ops
             from inclusivegan_amd.dnnlib.tflib.graphs import GraphedStep
-            GraphedStep.force_eager = True
             if rank == 0:
-                hip_ops.launch_log = []
+                state['stamp'] = hip_ops.StampLog(device)
+                state['stamp_steps'] = {}
+                hip_ops.stamp_log = state['stamp']
+                GraphedStep.after_capture = lambda step: state['stamp_steps'].__setitem__(step, state['stamp'].fold())
+                GraphedStep.generation += 1
         if state['iters'] == args.warmup + args.steps + profile_iters:
             torch.cuda.synchronize()
             return True
@@ -268,10 +365,19 @@ def main():
     if rank == 0:
         if not args.no_roofline:
             from inclusivegan_amd import hip_ops
-            log('aggregating %d timed conv launches' % len(hip_ops.launch_log))
-            out['roofline'] = step_roofline(hip_ops.launch_log)
-            hip_ops.launch_log = None
+            from inclusivegan_amd.dnnlib.tflib.graphs import GraphedStep
+            hip_ops.stamp_log = None
+            GraphedStep.after_capture = None
+            log('aggregating %d stamped conv launches' % len(state['stamp'].entries))
+            out['roofline'] = step_roofline(state['stamp'], state['stamp_steps'], args.conv_shapes)
+            pmc = _latest_profile('pmc_dominant.json')
+            if pmc and B == 6:
+                with open(pmc) as f:
+                    pj = json.load(f)
+                if pj.get('kernel') == out['roofline']['kernel']:
+                    out['roofline']['traffic'] = pj['traffic_bytes_per_launch']
             out['roofline']['headline_shape'] = headline_shape_roofline(device, B)
+            out['roofline']['hbm_kernel'] = hbm_kernel_roofline(device, B)
         if world == 1 and not args.no_cpu_baseline:
             log('timing the CPU oracle baseline')
             out['cpu_baseline'] = cpu_baseline_subprocess(args.resolution, 2 if args.resolution >= 128 else B, args.lpips_weight)

@@ -332,6 +332,15 @@ int igan_nn1_update(igan_stream_t stream, const float* query, const float* qnorm
                     int nq, int nc, int dim, int idx_base);
 
 /* ------------------------------------------------------------------------
+ * Device-side time stamps (measurement support, not part of the reference's surface): igan_stamp writes the constant
+ * 100 MHz counter (10 ns ticks) into *slot in stream order, so two stamps bracket whatever was launched between them --
+ * also inside a captured hipGraph, where host events cannot be placed.  igan_stamp_accumulate adds, for pairs
+ * first .. first+count-1, stamps[2i+1] - stamps[2i] into acc[i]; captured at the end of a graph it turns every replay
+ * into one more sample per launch without host involvement. */
+int igan_stamp(igan_stream_t stream, unsigned long long* slot);
+int igan_stamp_accumulate(igan_stream_t stream, const unsigned long long* stamps, unsigned long long* acc, int first, int count);
+
+/* ------------------------------------------------------------------------
  * Flat-bucket optimizer step (dnnlib/tflib/optimizer.py:237-239,318-332):
  *   flag[0] = all(isfinite(grad));  if flag: Adam update; else: skip.
  *   m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g; w -= lr_t * m / (sqrt(v) + eps)

@@ -908,7 +908,11 @@ extern "C" int igan_conv2d_plan(const igan_conv2d_params* p, int* splits, int* s
     fwd_counts(p, Mmax, chunks_max, nclass);
     const FwdTile t = pick_fwd_tile(Mmax, p->Cout);
     const TileList l = tile_list(p, t, Mmax, nclass);
-    if (l.rem == 0) return IGAN_OK;           // whole rounds: nothing to gain
+    {   // whole rounds: nothing to slice -- unless the CUs end on an unpaired tile (odd tiles per CU) and the A/B switch
+        // IGAN_SLICE_ODD=1 asks for that round to be cut in two (both workgroup slots of a CU stay busy to the end)
+        static const bool odd = getenv("IGAN_SLICE_ODD") && atoi(getenv("IGAN_SLICE_ODD")) == 1;
+        if (l.rem == 0 && !(odd && (l.T / device_cus()) % 2 == 1)) return IGAN_OK;
+    }
     {   // A/B switch: IGAN_SLICE_BIG=0 leaves layers with at least one whole round unsliced
         static const bool big = !(getenv("IGAN_SLICE_BIG") && atoi(getenv("IGAN_SLICE_BIG")) == 0);
         if (!big && l.T >= device_cus()) return IGAN_OK;
@@ -927,9 +931,10 @@ extern "C" int igan_conv2d_plan(const igan_conv2d_params* p, int* splits, int* s
     const double bw = 4.0e12;
     const int cand[] = {2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 32, 48, 64};
     int best_s = 1, best_sl = 0;
-    double best = pairs(l.T / cus + 1);       // unsliced: the busiest CU has one tile of the partial round
+    double best = pairs(igan::ceil_div(l.T, cus));   // unsliced: the busiest CU has one tile of the partial round
     for (int k = 0; k <= std::min(l.T / cus, 3); k++) {
         const int sl = l.rem + k * cus;       // sliced tiles
+        if (sl == 0) continue;
         const int whole = (l.T - sl) / cus;   // whole tiles per CU
         for (int c : cand) {
             if (c > std::max(1, chunks_max / 2)) break;

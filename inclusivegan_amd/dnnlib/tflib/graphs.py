@@ -27,6 +27,8 @@ def graphs_enabled(default=True):
 class GraphedStep:
     _pool = None
     force_eager = False     # profiling switch: run every step eagerly (per-launch event timing)
+    generation = 0          # bump to make every step re-capture its graph at its next call (e.g. after switching on hip_ops.stamp_log)
+    after_capture = None    # optional callable run INSIDE the capture, after fn() (e.g. StampLog.fold); receives the step
 
     def __init__(self, fn, enabled=True, eager_calls=2, name='step'):
         self.fn = fn
@@ -36,11 +38,17 @@ class GraphedStep:
         self.calls = 0
         self.graph = None
         self.out = None
+        self.captured_generation = 0
+        self.replays = 0        # replays of the CURRENT graph (first capture counts: a capture does not execute, the replay after it does)
 
     def __call__(self):
         if not self.enabled or GraphedStep.force_eager or self.calls < self.eager_calls:
             self.calls += 1
             return self.fn()
+        if self.graph is not None and self.captured_generation != GraphedStep.generation:
+            torch.cuda.synchronize()
+            self.graph = None
+            self.out = None
         if self.graph is None:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
@@ -49,9 +57,14 @@ class GraphedStep:
             dist_up = torch.distributed.is_available() and torch.distributed.is_initialized()
             with torch.cuda.graph(g, pool=GraphedStep._pool, capture_error_mode='thread_local' if dist_up else 'global'):
                 self.out = self.fn()
+                if GraphedStep.after_capture is not None:
+                    GraphedStep.after_capture(self)
+            self.captured_generation = GraphedStep.generation
+            self.replays = 0
             if GraphedStep._pool is None:
                 GraphedStep._pool = g.pool()
             self.graph = g
         self.calls += 1
+        self.replays += 1
         self.graph.replay()
         return self.out

@@ -343,7 +343,61 @@ _wplan_cache = {}
 # Profiling hook (bench.py): when set to a list, every conv2d_raw launch is bracketed by HIP events on the
 # launch stream and logged as (kernel name, algorithmic FLOPs, start event, end event).
 launch_log = None
+stamp_log = None      # a StampLog: every conv2d_raw launch is bracketed by device-side stamps (works inside captured graphs)
 shape_log = None      # tools/conv_shapes.py: (kind, shape key, flops, splits, start event, end event) per conv-family launch
+
+
+class StampLog:
+    """Per-launch device time of the conv family, measured ON the device (include/igan_hip.h igan_stamp): every logged launch
+    gets a slot; a pair of one-wave stamp kernels around it reads the 100 MHz counter in stream order, and `fold()` -- called
+    at the end of each captured graph / eager op -- adds the slot's duration into an accumulator.  Because stamps and folds
+    are ordinary kernels they are captured into the training ops' hipGraphs: replaying a graph K times yields K samples per
+    launch, with the device running exactly as in the timed region (no host-side gaps, full clocks)."""
+
+    def __init__(self, device, capacity=16384):
+        self.stamps = torch.zeros((2 * capacity,), device=device, dtype=torch.int64)
+        self.acc = torch.zeros((capacity,), device=device, dtype=torch.int64)
+        self.entries = []           # (kernel name, algorithmic flops) per slot
+        self.shapes = []            # free-form shape description per slot (for per-shape tables)
+        self.capacity = capacity
+        self._folded = 0            # slots below this index already have their fold kernel
+        self.folds = {}             # graph tag -> number of times its fold ran is tracked by the caller (replays)
+
+    def bracket(self, name, flops, launch, shape=None):
+        i = len(self.entries)
+        if i >= self.capacity:
+            raise RuntimeError('StampLog: capacity exceeded')
+        lib = _abi.get_plugin()
+        self.entries.append((name, flops))
+        self.shapes.append(shape)
+        _abi.check(lib.igan_stamp(_stream(), ctypes.c_void_p(self.stamps.data_ptr() + 16 * i)))
+        launch()
+        _abi.check(lib.igan_stamp(_stream(), ctypes.c_void_p(self.stamps.data_ptr() + 16 * i + 8)))
+
+    def fold(self):
+        """Accumulate the slots created since the last fold (one captured op's launches). Returns (first, count)."""
+        first, count = self._folded, len(self.entries) - self._folded
+        if count > 0:
+            _abi.check(_abi.get_plugin().igan_stamp_accumulate(_stream(), _ptr(self.stamps), _ptr(self.acc), first, count))
+            self._folded = len(self.entries)
+        return first, count
+
+    def totals_us(self):
+        """-> list of (name, flops, accumulated microseconds) per slot (10 ns ticks)."""
+        acc = self.acc[:len(self.entries)].cpu().tolist()
+        return [(n, f, a * 0.01) for (n, f), a in zip(self.entries, acc)]
+
+    def shape_table(self, replays):
+        """Rows (shape, launches per replayed iteration set, total us, TFLOP/s), grouped by shape, sorted by time; `replays`
+        maps slot index -> number of replays its graph saw."""
+        rows = {}
+        for i, ((name, flops, us), shape) in enumerate(zip(self.totals_us(), self.shapes)):
+            n = replays.get(i, 0)
+            if n == 0:
+                continue
+            r = rows.setdefault((shape, name), [0, 0.0, 0.0])
+            r[0] += n; r[1] += flops * n; r[2] += us
+        return sorted(((k[0], k[1], v[0], v[2], v[1] / max(v[2], 1e-9) / 1e6) for k, v in rows.items()), key=lambda r: -r[3])
 
 
 def _shape_logged(kind, key, flops, splits, launch):
@@ -418,6 +472,14 @@ def conv2d_raw(x, w, geom, out_hw, cout, w_transposed=False, in_scale=None, out_
         p.workspace_floats = plan[1]
         p.splits = plan[0]
         p.sliced_tiles = plan[2]
+    if stamp_log is not None:
+        buf = ctypes.create_string_buffer(128)
+        _abi.check(lib.igan_conv2d_kernel_name(ctypes.byref(p), buf, 128))
+        kind = ('dgrad' if w_transposed else 'fwd') + ('+scale' if (in_scale is not None or out_scale is not None) else '') + ('+act' if act is not None else '')
+        stamp_log.bracket(buf.value.decode(), conv_flops(n, h, wd, cin, oh, ow, cout, geom),
+                          lambda: _abi.check(lib.igan_conv2d(_stream(), ctypes.byref(p))),
+                          shape='%-12s N%-3d %3dx%-3d C%-4d -> %3dx%-3d C%-4d k%d s%d u%d splits %d' % (kind, n, h, wd, cin, oh, ow, cout, geom.kh, geom.stride, geom.up, plan[0]))
+        return y
     if launch_log is not None:
         buf = ctypes.create_string_buffer(128)
         _abi.check(lib.igan_conv2d_kernel_name(ctypes.byref(p), buf, 128))
@@ -474,6 +536,12 @@ def conv2d_wgrad_raw(x, dy, geom, in_scale=None, out_scale=None):
         p.workspace = ws.data_ptr()
         p.workspace_floats = plan[1]
         p.splits = plan[0]
+    if stamp_log is not None:
+        stamp_log.bracket('conv_wgrad_kernel (+ reduce)', conv_flops(n, h, wd, cin, oh, ow, cout, geom),
+                          lambda: _abi.check(lib.igan_conv2d_wgrad(_stream(), ctypes.byref(p))),
+                          shape='%-12s N%-3d %3dx%-3d C%-4d -> %3dx%-3d C%-4d k%d s%d u%d splits %d' % (
+                              'wgrad' + ('+scale' if (in_scale is not None or out_scale is not None) else ''), n, h, wd, cin, oh, ow, cout, geom.kh, geom.stride, geom.up, plan[0]))
+        return dw
     if shape_log is not None:
         _shape_logged('wgrad' + ('+s' if in_scale is not None or out_scale is not None else ''), key,
                       conv_flops(n, h, wd, cin, oh, ow, cout, geom), plan[0],

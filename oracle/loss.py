@@ -14,8 +14,12 @@ from .misc import lerp, slerp_t
 
 
 def G_loss(G_params, D_params, lpips_params, cfg, rand, minibatch_size, reals_rec_1, latents_rec_1, reals_rec_2, latents_rec_2,
-           NN_rec_lpips_weight, pl_minibatch_shrink=2, pl_decay=0.01, pl_weight=2.0, phase='both', state=None):
-    """cfg: dict(resolution, num_channels, fmap_base, G_arch, D_arch).  state: dict with 'pl_mean', 'dlatent_avg'."""
+           NN_rec_lpips_weight, pl_minibatch_shrink=2, pl_decay=0.01, pl_weight=2.0, phase='both', state=None, literal_zero_weight=False):
+    """cfg: dict(resolution, num_channels, fmap_base, G_arch, D_arch).  state: dict with 'pl_mean', 'dlatent_avg'.
+    The reference evaluates the reconstruction / interpolation terms unconditionally and multiplies them by
+    NN_rec_lpips_weight (:31-32,41-42); with a weight of 0 they contribute exactly 0 to the value and to every gradient, so by
+    default they are skipped here (as on the HIP path).  literal_zero_weight=True evaluates them anyway, like the reference
+    graph does -- tests/test_oracle_networks.py uses it to show that skipping is exact."""
     state = state if state is not None else {}
     dt = latents_rec_1.dtype
     def G(z, **kw):
@@ -30,7 +34,7 @@ def G_loss(G_params, D_params, lpips_params, cfg, rand, minibatch_size, reals_re
     loss = reg = None
     terms = {}
     if phase in ('both', 'loss'):
-        if NN_rec_lpips_weight != 0:
+        if NN_rec_lpips_weight != 0 or literal_zero_weight:
             rec1 = (G(latents_rec_1) + 1) * (255 / 2)                                    # :25-28
             rec2 = (G(latents_rec_2) + 1) * (255 / 2)
             real1 = (reals_rec_1 + 1) * (255 / 2)                                        # :29-30

@@ -79,6 +79,54 @@ def test_conv_adjointness_and_linearity_full_size(layer, cuda_device):
         assert float((y - yc).abs().max() / (yc.abs().max() + 1e-30)) < 5e-5
 
 
+@pytest.mark.parametrize('layer', LAYERS, ids=[l[0] for l in LAYERS])
+def test_conv_family_against_fp64_oracle_samples_full_size(layer, cuda_device):
+    """An INDEPENDENT check at the bench sizes: 256 randomly chosen elements of the forward output, of the data gradient and
+    of the weight gradient of every layer shape of config-e @128, each computed in fp64 by direct gather on the CPU
+    (oracle/conv_sample.py: the TensorFlow definitions, no tiling) and compared with the HIP kernels' values.
+    Tolerance 3e-5 of the largest sampled magnitude (exact-fp32 MFMA accumulation over K up to 8192)."""
+    from inclusivegan_amd import hip_ops
+    from oracle import conv_sample as CS
+    name, N, Cin, H, Cout, K, stride, up, pad, out, scales = layer
+    g = torch.Generator(device='cpu').manual_seed(len(name) * 131 + N)
+    dev = cuda_device
+    cl = lambda t: t.to(dev).contiguous(memory_format=torch.channels_last)
+    x_c = torch.randn(N, Cin, H, H, generator=g)
+    w_c = torch.randn(K, K, Cin, Cout, generator=g) / (K * K * Cin) ** 0.5
+    dy_c = torch.randn(N, Cout, out, out, generator=g)
+    s_c = (torch.rand(N, Cin, generator=g) + 0.5) if scales else None
+    d_c = (torch.rand(N, Cout, generator=g) + 0.5) if scales is True else None
+    alpha = 0.83
+    x, w, dy = cl(x_c), w_c.to(dev), cl(dy_c)
+    s = s_c.to(dev) if s_c is not None else None
+    d = d_c.to(dev) if d_c is not None else None
+    geom = hip_ops.ConvGeom(K, K, stride, up, pad, pad, alpha)
+    y = hip_ops.conv2d_raw(x, w, geom, (out, out), Cout, in_scale=s, out_scale=d)
+    dyd = dy * d[:, :, None, None] if d is not None else dy
+    dxs = hip_ops.conv2d_raw(dyd, w, hip_ops.dgrad_geom(geom), (H, H), Cin, w_transposed=True)
+    dx = dxs * s[:, :, None, None] if s is not None else dxs
+    dw = hip_ops.conv2d_wgrad_raw(x, dy, geom, in_scale=s, out_scale=d)
+    rng = np.random.RandomState(len(name))
+    m = 256
+    pick = lambda *dims: np.stack([rng.randint(n, size=m) for n in dims], 1)
+    xn, wn, dyn = x_c.numpy(), w_c.numpy(), dy_c.numpy()
+    sn = s_c.numpy() if s_c is not None else None
+    dn = d_c.numpy() if d_c is not None else None
+
+    def check(got, want, what):
+        got = got.astype(np.float64)
+        err = np.abs(got - want).max() / (np.abs(want).max() + 1e-30)
+        assert err < 3e-5, (name, what, err)
+
+    i = pick(N, Cout, out, out)
+    check(y.cpu().numpy()[tuple(i.T)], CS.forward_samples(xn, wn, i, stride, up, pad, sn, dn, alpha), 'forward')
+    i = pick(N, Cin, H, H)
+    check(dx.cpu().numpy()[tuple(i.T)], CS.dgrad_samples(dyn, wn, i, (H, H), stride, up, pad, sn, dn, alpha), 'data gradient')
+    i = pick(K, K, Cin, Cout)
+    iw = i[:64]     # a weight-gradient element sums N*OH*OW products: 64 of them keep the CPU side in seconds
+    check(dw.cpu().numpy()[tuple(iw.T)], CS.wgrad_samples(xn, dyn, iw, stride, up, pad, sn, dn, alpha), 'weight gradient')
+
+
 def test_torgb_and_dense_against_torch_einsum_full_size(cuda_device):
     """The thin-channel and small-batch dense kernels against torch's own matmul on the device (fp32, same inputs)."""
     from inclusivegan_amd import hip_ops

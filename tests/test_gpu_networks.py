@@ -18,9 +18,9 @@ RES = 32
 FMAP = 1024      # nf: 512,256,128,64,32 at 4..32  (config-e uses 8192)
 
 
-def _nets(dev, label_size=0):
+def _nets(dev, label_size=0, fmap=FMAP):
     from inclusivegan_amd.dnnlib import tflib
-    kw = dict(num_channels=3, resolution=RES, label_size=label_size, fmap_base=FMAP, device=dev)
+    kw = dict(num_channels=3, resolution=RES, label_size=label_size, fmap_base=fmap, device=dev)
     G = tflib.Network('G', func_name='inclusivegan_amd.training.networks_stylegan2.G_main', architecture='skip', seed=11, **kw)
     D = tflib.Network('D', func_name='inclusivegan_amd.training.networks_stylegan2.D_stylegan2_feature', architecture='resnet', seed=12, **kw)
     rng = np.random.RandomState(0)
@@ -108,9 +108,11 @@ def _gloss_tape_in_reference_order(entries, B, calls=4):
     return per_call[0] + per_call[1] + [t] + per_call[2] + [zr] + per_call[3]
 
 
-def test_losses_and_gradients_match_oracle(cuda_device):
+@pytest.mark.parametrize('fmap', [FMAP, 8192], ids=['width1024', 'config_e_width8192'])
+def test_losses_and_gradients_match_oracle(cuda_device, fmap):
     """G loss (rec + interp LPIPS + adversarial), G path-length reg, D loss, D R1 reg: values and the
-    gradients w.r.t. every trainable, including the second-order paths."""
+    gradients w.r.t. every trainable, including the second-order paths -- at the reduced width and at config-e's own
+    (fmap_base 8192: BASELINE config 2, Stacked-MNIST 32x32 StyleGAN2+IMLE)."""
     from inclusivegan_amd.dnnlib import tflib
     from inclusivegan_amd.dnnlib.tflib import tfutil
     from inclusivegan_amd.training import loss as PL
@@ -118,7 +120,7 @@ def test_losses_and_gradients_match_oracle(cuda_device):
     from oracle import loss as OL
     from oracle.misc import Tape
     dev = cuda_device
-    G, D = _nets(dev)
+    G, D = _nets(dev, fmap=fmap)
     lp = tflib.Network('lpips', func_name='inclusivegan_amd.metrics.lpips.vgg16_zhang_perceptual', resolution=RES, device=dev, seed=13)
     ts = SyntheticDataset(resolution=RES, label_size=0, data_size=24, device=dev)
     B = 6
@@ -126,7 +128,7 @@ def test_losses_and_gradients_match_oracle(cuda_device):
     reals1 = (torch.rand(B, 3, RES, RES, generator=g) * 2 - 1); reals2 = (torch.rand(B, 3, RES, RES, generator=g) * 2 - 1)
     z1 = torch.nn.functional.normalize(torch.randn(B, 512, generator=g), dim=1); z2 = torch.nn.functional.normalize(torch.randn(B, 512, generator=g), dim=1)
     lab = torch.zeros(B, 0, device=dev)
-    cfg = dict(resolution=RES, num_channels=3, fmap_base=FMAP, G_arch='skip', D_arch='resnet')
+    cfg = dict(resolution=RES, num_channels=3, fmap_base=fmap, G_arch='skip', D_arch='resnet')
     lpo = {n: v.detach().double().cpu() for n, v in lp.vars.items()}
     cl = lambda t: t.to(dev).contiguous(memory_format=torch.channels_last)
 
@@ -370,3 +372,112 @@ def test_training_loop_runs_and_learns_shapes(cuda_device):
     assert seen == [12, 24, 36] and len(refresh) == 1
     for net in (out['G'], out['D'], out['Gs']):
         assert bool(torch.isfinite(net.flat_params).all())
+
+
+def test_g_loss_adversarial_only_config3(cuda_device):
+    """BASELINE config 3: NN_rec_lpips_weight = 0 (training/loss.py with the reconstruction / interpolation terms weighted to
+    zero; tests/test_oracle_networks.py shows they then contribute exactly nothing).  The HIP loss takes its adversarial-only
+    branch: value and the gradient of every G trainable against the oracle."""
+    from inclusivegan_amd.dnnlib import tflib
+    from inclusivegan_amd.dnnlib.tflib import tfutil
+    from inclusivegan_amd.training import loss as PL
+    from inclusivegan_amd.training.dataset import SyntheticDataset
+    from oracle import loss as OL
+    from oracle.misc import Tape
+    dev = cuda_device
+    G, D = _nets(dev)
+    lp = tflib.Network('lpips', func_name='inclusivegan_amd.metrics.lpips.vgg16_zhang_perceptual', resolution=RES, device=dev, seed=13)
+    ts = SyntheticDataset(resolution=RES, label_size=0, data_size=24, device=dev)
+    B = 6
+    g = torch.Generator().manual_seed(8)
+    reals1 = torch.rand(B, 3, RES, RES, generator=g) * 2 - 1; reals2 = torch.rand(B, 3, RES, RES, generator=g) * 2 - 1
+    z1 = torch.randn(B, 512, generator=g); z2 = torch.randn(B, 512, generator=g)
+    lab = torch.zeros(B, 0, device=dev)
+    cl = lambda t: t.to(dev).contiguous(memory_format=torch.channels_last)
+    cfg = dict(resolution=RES, num_channels=3, fmap_base=FMAP, G_arch='skip', D_arch='resnet')
+    G.zero_grad(); D.requires_grad_(False)
+    gp = _oracle_params(G); dp = _oracle_params(D)
+    rec = tfutil.RecordingRandom()
+    with tfutil.use_random(rec):
+        loss, reg = PL.G_logistic_ns_rec_interp_arb_pathreg(G, D, lp, ts, B, cl(reals1), lab, z1.to(dev), cl(reals2), lab, z2.to(dev),
+                                                            NN_rec_lpips_weight=0.0, phase='loss')
+    assert reg is None and tuple(loss.shape) == (B,)
+    torch.autograd.backward(loss.mean(), inputs=list(G.trainables.values()))
+    D.requires_grad_(True)
+    lo, _, terms = OL.G_loss(gp, dp, {}, cfg, Tape(rec.entries, torch.float64), B, reals1.double(), z1.double(), reals2.double(), z2.double(),
+                             0.0, phase='loss', state={})
+    assert set(terms) == {'loss_G_arb'}
+    lo.mean().backward()
+    assert rel_err(loss, lo) < 2e-4
+    errs = _grad_errs(G, gp)
+    worst = max(errs, key=errs.get)
+    assert errs[worst] < 5e-3, (worst, errs[worst])
+
+
+def test_networks_at_config_e_width(cuda_device):
+    """BASELINE config 2 / config-e proper: fmap_base 8192 (512 channels up to 32x32) at 32x32, batch 2 -- G (training and
+    validation mode) and D (scores and features) against the fp64 oracle at FULL width."""
+    from inclusivegan_amd.dnnlib import tflib
+    from inclusivegan_amd.dnnlib.tflib import tfutil
+    from oracle import networks_stylegan2 as ON
+    from oracle.misc import Tape
+    dev = cuda_device
+    kw = dict(num_channels=3, resolution=32, label_size=0, fmap_base=8192, device=dev)
+    G = tflib.Network('G', func_name='inclusivegan_amd.training.networks_stylegan2.G_main', architecture='skip', seed=21, **kw)
+    D = tflib.Network('D', func_name='inclusivegan_amd.training.networks_stylegan2.D_stylegan2_feature', architecture='resnet', seed=22, **kw)
+    assert G.vars['G_synthesis/32x32/Conv1/weight'].shape == (3, 3, 512, 512)
+    rng = np.random.RandomState(1)
+    with torch.no_grad():
+        for net in (G, D):
+            for n, v in net.vars.items():
+                if n.endswith('bias') or n.endswith('noise_strength'):
+                    v.copy_(torch.from_numpy(np.asarray(rng.randn(*v.shape) * 0.1, dtype=np.float32)).to(dev).reshape(v.shape))
+    z = torch.randn(2, 512, device=dev)
+    lab = torch.zeros(2, 0, device=dev)
+    gp = _oracle_params(G); dp = _oracle_params(D)
+    for training in (True, False):
+        rec = tfutil.RecordingRandom()
+        with tfutil.use_random(rec), torch.no_grad():
+            img = G.get_output_for(z, lab, is_training=training, is_validation=not training)
+        with torch.no_grad():
+            img_o = ON.G_main(gp, z.double().cpu(), Tape(rec.entries, torch.float64), 32, fmap_base=8192, architecture='skip',
+                              is_training=training, is_validation=not training, fused_modconv=False)
+        assert rel_err(img, img_o) < 1e-4, training
+    x = torch.randn(6, 3, 32, 32, device=dev)
+    with torch.no_grad():
+        s, f = D.get_output_for(x, torch.zeros(6, 0, device=dev), is_training=True, return_features=True)
+        so, fo = ON.D_stylegan2_feature(dp, x.double().cpu(), 32, fmap_base=8192, architecture='resnet')
+    assert rel_err(s, so) < 1e-4 and rel_err(f, fo) < 1e-4
+
+
+def test_generator_and_discriminator_at_128_full_config(cuda_device):
+    """The bench configuration itself: config-e-Gskip-Dresnet at 128x128, fmap_base 8192 -- one G forward (batch 1, validation
+    mode: deterministic up to the recorded noise) and one D forward (batch 2) against the fp64 oracle."""
+    from inclusivegan_amd.dnnlib import tflib
+    from inclusivegan_amd.dnnlib.tflib import tfutil
+    from oracle import networks_stylegan2 as ON
+    from oracle.misc import Tape
+    dev = cuda_device
+    kw = dict(num_channels=3, resolution=128, label_size=0, fmap_base=8192, device=dev)
+    G = tflib.Network('G', func_name='inclusivegan_amd.training.networks_stylegan2.G_main', architecture='skip', seed=31, **kw)
+    D = tflib.Network('D', func_name='inclusivegan_amd.training.networks_stylegan2.D_stylegan2_feature', architecture='resnet', seed=32, **kw)
+    rng = np.random.RandomState(2)
+    with torch.no_grad():
+        for net in (G, D):
+            for n, v in net.vars.items():
+                if n.endswith('bias') or n.endswith('noise_strength'):
+                    v.copy_(torch.from_numpy(np.asarray(rng.randn(*v.shape) * 0.1, dtype=np.float32)).to(dev).reshape(v.shape))
+    z = torch.randn(1, 512, device=dev)
+    rec = tfutil.RecordingRandom()
+    with tfutil.use_random(rec), torch.no_grad():
+        img = G.get_output_for(z, torch.zeros(1, 0, device=dev), is_validation=True)
+    assert tuple(img.shape) == (1, 3, 128, 128)
+    with torch.no_grad():
+        img_o = ON.G_main(_oracle_params(G), z.double().cpu(), Tape(rec.entries, torch.float64), 128, fmap_base=8192, architecture='skip',
+                          is_validation=True, fused_modconv=False)
+    assert rel_err(img, img_o) < 1e-4
+    x = torch.randn(2, 3, 128, 128, device=dev)
+    with torch.no_grad():
+        s, _ = D.get_output_for(x, torch.zeros(2, 0, device=dev), is_training=True)
+        so, _ = ON.D_stylegan2_feature(_oracle_params(D), x.double().cpu(), 128, fmap_base=8192, architecture='resnet')
+    assert rel_err(s, so) < 1e-4

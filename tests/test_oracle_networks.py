@@ -68,3 +68,33 @@ def test_discriminator_shapes_and_mbstd():
     g0 = x[0::2]
     want = torch.sqrt(((g0 - g0.mean(0, keepdim=True)) ** 2).mean(0) + 1e-8).mean()
     assert torch.allclose(y[0, 4], want.expand(4, 4))
+
+
+def test_zero_weight_reconstruction_terms_contribute_exactly_nothing():
+    """BASELINE config 3 (NN_rec_lpips_weight = 0, adversarial only): the reference still evaluates the reconstruction and
+    interpolation terms and multiplies them by the weight (training/loss.py:31-32,41-42).  Evaluated literally, they add
+    exactly 0 to the loss and to every gradient -- so the HIP path (and the oracle by default) may skip them."""
+    from oracle import loss as OL
+    from oracle import lpips as OLP
+    from inclusivegan_amd.dnnlib import tflib
+    gp, dp = _params(res=16, fmap=128)
+    for p in gp.values():
+        p.requires_grad_(True)
+    lp = tflib.Network('lpips', func_name='inclusivegan_amd.metrics.lpips.vgg16_zhang_perceptual', resolution=16, device='cpu', seed=3)
+    lpo = {n: v.detach().double() for n, v in lp.vars.items()}
+    cfg = dict(resolution=16, num_channels=3, fmap_base=128, G_arch='skip', D_arch='resnet')
+    B = 2
+    g = torch.Generator().manual_seed(0)
+    r1 = torch.rand(B, 3, 16, 16, generator=g, dtype=torch.float64) * 2 - 1; r2 = torch.rand(B, 3, 16, 16, generator=g, dtype=torch.float64) * 2 - 1
+    z1 = torch.randn(B, 512, generator=g, dtype=torch.float64); z2 = torch.randn(B, 512, generator=g, dtype=torch.float64)
+    loss, _, terms = OL.G_loss(gp, dp, lpo, cfg, SeededRandom(5, torch.float64), B, r1, z1, r2, z2, 0.0, phase='loss', state={}, literal_zero_weight=True)
+    assert set(terms) == {'loss_NN_rec_lpips', 'loss_NN_interp_lpips', 'loss_G_arb'}
+    assert float(terms['loss_NN_rec_lpips'].abs().max()) == 0.0 and float(terms['loss_NN_interp_lpips'].abs().max()) == 0.0
+    assert torch.equal(loss, terms['loss_G_arb'])
+    params = [p for p in gp.values() if p.requires_grad]
+    g_all = torch.autograd.grad(loss.mean(), params, retain_graph=True, allow_unused=True)
+    g_adv = torch.autograd.grad(terms['loss_G_arb'].mean(), params, allow_unused=True)
+    for a, b in zip(g_all, g_adv):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.equal(a, b)

@@ -114,3 +114,32 @@ def test_fused_bias_act_bias_axes():
     assert torch.allclose(y, want)
     k = FB.fused_bias_act_kernel_ref(x, b, None, 0, 3, 0.2, float(np.sqrt(2)), 20).reshape(x.shape)   # stepB = H*W
     assert torch.allclose(k, want)
+
+
+def test_sampled_conv_oracle_matches_torch_autograd():
+    """oracle/conv_sample.py (single elements by direct gather, used for the full-size GPU spot checks) equals torch's fp64
+    conv2d / zero-insert + correlation and their autograd gradients on small problems of every geometry on the path."""
+    from oracle import conv_sample as CS
+    rng = np.random.RandomState(0)
+    for (N, Cin, H, Cout, K, stride, up, pad, out) in [(2, 5, 8, 7, 3, 1, 1, 1, 8), (2, 4, 9, 6, 3, 2, 1, 0, 4), (2, 4, 5, 6, 3, 1, 2, 2, 11),
+                                                        (2, 4, 7, 3, 1, 2, 1, 0, 4), (3, 6, 1, 5, 1, 1, 1, 0, 1)]:
+        x = rng.randn(N, Cin, H, H); w = rng.randn(K, K, Cin, Cout); s = rng.rand(N, Cin) + .5; d = rng.rand(N, Cout) + .5
+        dy = rng.randn(N, Cout, out, out)
+        xt = torch.tensor(x, requires_grad=True); wt = torch.tensor(w, requires_grad=True)
+        xs = xt * torch.tensor(s)[:, :, None, None]
+        wk = wt.permute(3, 2, 0, 1)
+        if up == 1:
+            y = torch.nn.functional.conv2d(xs, wk, stride=stride, padding=pad)
+        else:
+            xu = torch.nn.functional.conv_transpose2d(xs, torch.eye(Cin, dtype=torch.float64)[:, :, None, None], stride=up)   # zero insertion
+            y = torch.nn.functional.conv2d(xu, wk, padding=pad)
+        y = y * torch.tensor(d)[:, :, None, None] * 0.7
+        assert y.shape[-1] == out
+        (y * torch.tensor(dy)).sum().backward()
+        pick = lambda *dims: np.stack([rng.randint(m, size=24) for m in dims], 1)
+        i = pick(N, Cout, out, out)
+        assert np.allclose(CS.forward_samples(x, w, i, stride, up, pad, s, d, 0.7), y.detach().numpy()[tuple(i.T)], rtol=1e-11, atol=1e-11)
+        i = pick(N, Cin, H, H)
+        assert np.allclose(CS.dgrad_samples(dy, w, i, (H, H), stride, up, pad, s, d, 0.7), xt.grad.numpy()[tuple(i.T)], rtol=1e-11, atol=1e-11)
+        i = pick(K, K, Cin, Cout)
+        assert np.allclose(CS.wgrad_samples(x, dy, i, stride, up, pad, s, d, 0.7), wt.grad.numpy()[tuple(i.T)], rtol=1e-11, atol=1e-11)
