@@ -68,6 +68,7 @@ struct ConvArgs {
     int vecA, vecB, vecS;   // 16 B paths usable for x rows / w rows / in_scale rows
     int vecY;               // 8 B output stores usable (Cout even, y / out_scale 8 B aligned)
     float alpha;            // output multiplier (applied here when splits == 1, else by the reduce kernel)
+    int xcd_remap;          // XCD-aware block order (remap_xcd)
     const float* bias;      // fused epilogue (act != 0): y = act(y + bias[co]) * act_gain
     int act;                // 0 none, 1 linear, 2 relu, 3 lrelu
     float act_alpha, act_gain;
@@ -130,6 +131,17 @@ __device__ __forceinline__ float4 load4(__amdgpu_buffer_rsrc_t r, LoadAddr a) {
         f.w = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (a.left > 3) ? a.off + 12u : OOB, 0, 0));
         return f;
     }
+}
+
+// XCD-aware block order.  Workgroups are dealt round-robin to the 8 XCDs (block b runs on XCD b % 8, each with its own
+// 4 MiB L2), so with the plain order neighbouring tiles -- which read overlapping input rows (the 3x3 halo) or the same
+// pixel slice under different taps -- land on eight different L2s and every one of them fetches the shared rows again.
+// remap_xcd() returns the logical index of block b such that XCD x works through ONE contiguous range of logical indices
+// (bijective for any grid size): blocks that are resident together on an XCD are neighbours in tile order and share their
+// halo through that XCD's L2.  Placement is a speed matter only; no result depends on it.
+__device__ __forceinline__ int remap_xcd(int b, int n) {
+    const int q = n >> 3, r = n & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 }
 
 // One chunk of MFMAs for this wave.  A image: [m][k] (A_KMAJOR = false, pitch LDK)
@@ -215,7 +227,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_fwd
 
     const int up = 1 << a.up_shift;
     // block -> (tile, reduction slice): whole tiles first, then the sliced tail
-    const int bid = blockIdx.x;
+    const int bid = a.xcd_remap ? remap_xcd(blockIdx.x, gridDim.x) : (int)blockIdx.x;
     const bool sliced = bid >= a.full_tiles;
     const int tail = bid - a.full_tiles;
     const int tile = sliced ? a.full_tiles + tail / a.splits : bid;
@@ -536,6 +548,7 @@ struct WgradArgs {
     int splits;
     int vecA, vecB, vecSA, vecSB;
     int vecY;   // 8 B stores usable (Cout even, destination 8 B aligned)
+    int xcd_remap;  // XCD-aware block order (remap_xcd)
     float alpha;  // dw multiplier (applied here when splits == 1, else by the reduce kernel)
 };
 
@@ -573,8 +586,19 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_wgr
     const int wm = wave / WN, wn = wave % WN;
 
     const int up = 1 << a.up_shift;
-    const int tap = blockIdx.z / a.splits;
-    const int split = blockIdx.z - tap * a.splits;
+    // logical block = (pixel slice, co tile, ci tile, tap) with the tap fastest: the blocks that read one pixel slice (the
+    // same dy rows and the same x rows shifted by the tap) are neighbours and, through remap_xcd, share one XCD's L2
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    int tap = bz / a.splits, split = bz - tap * a.splits;
+    if (a.xcd_remap) {
+        const int gx = gridDim.x, gy = gridDim.y, taps = a.KH * a.KW;
+        const int lin = remap_xcd(bx + gx * (by + gy * bz), gx * gy * (int)gridDim.z);
+        tap = lin % taps;
+        int rest = lin / taps;
+        bx = rest % gx; rest /= gx;
+        by = rest % gy;
+        split = rest / gy;
+    }
     const int ky = tap / a.KW, kx = tap - ky * a.KW;
     const int py = (a.pad_y - ky) & (up - 1);  // stride == 1 whenever up > 1
     const int px = (a.pad_x - kx) & (up - 1);
@@ -584,8 +608,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_wgr
     const int chunks = (Kpix + BK - 1) / BK;
     const int c_begin = (int)(((long long)split * chunks) / a.splits);
     const int c_end = (int)(((long long)(split + 1) * chunks) / a.splits);
-    const int m0 = blockIdx.x * BM;  // ci
-    const int n0 = blockIdx.y * BN;  // co
+    const int m0 = bx * BM;  // ci
+    const int n0 = by * BN;  // co
 
     const int amv = tid % MV, aprow0 = tid / MV;
     const int bnv = tid % NV, bprow0 = tid / NV;
@@ -1029,6 +1053,10 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
     else a.vecB = (p->Cout % 4 == 0) && (((uintptr_t)p->w & 15) == 0);
     a.vecY = (p->Cout % 2 == 0) && ((((uintptr_t)p->y | (uintptr_t)p->out_scale) & 7) == 0);
     a.alpha = p->alpha;
+    {   // A/B switch: IGAN_XCD_REMAP=0 keeps the plain block order
+        static const bool remap = !(getenv("IGAN_XCD_REMAP") && atoi(getenv("IGAN_XCD_REMAP")) == 0);
+        a.xcd_remap = remap ? 1 : 0;
+    }
     a.bias = p->bias; a.act = p->act; a.act_alpha = p->act_alpha; a.act_gain = p->act_gain;
 
     dim3 grid(a.full_tiles + (l.T - a.full_tiles) * splits);
@@ -1167,6 +1195,10 @@ extern "C" int igan_conv2d_wgrad(igan_stream_t stream_, const igan_conv2d_wgrad_
 
     a.vecY = (p->Cout % 2 == 0) && (((uintptr_t)a.out & 7) == 0);
     a.alpha = p->alpha;
+    {
+        static const bool remap = !(getenv("IGAN_XCD_REMAP") && atoi(getenv("IGAN_XCD_REMAP")) == 0);
+        a.xcd_remap = remap ? 1 : 0;
+    }
 
     const WgTile t = pick_wg_tile(p->Cin, p->Cout);
     dim3 grid(ceil_div(p->Cin, t.BM), ceil_div(p->Cout, t.BN), p->KH * p->KW * splits);

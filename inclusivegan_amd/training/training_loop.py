@@ -324,6 +324,9 @@ def training_loop(
     staging = [dict({k: torch.empty(v.shape, dtype=torch.float32).pin_memory() for k, v in feed.items() if '_rec_' in k},
                     event=torch.cuda.Event()) for _ in range(3)]
     use_graphs = graphs.graphs_enabled(hip_graphs)
+    # Gradient exchange: chunk by chunk DURING backward (tflib/optimizer.py GradientExchange), inside the captured graph
+    # when the process group's collectives can be captured (RCCL); otherwise (gloo) one all-reduce after each replay.
+    overlap_exchange = world > 1 and (not use_graphs or tflib.optimizer.collectives_capturable())
 
     def G_grad():
         G.invalidate_derived(); D.invalidate_derived()
@@ -336,7 +339,7 @@ def training_loop(
                               phase='loss' if lazy_regularization else 'both', **G_loss_args)
         if not lazy_regularization and reg is not None:
             loss = loss + reg       # :284-285 (broadcasts [B] + [B // pl_minibatch_shrink] exactly as the reference's `+=` does, or fails like it)
-        G_opt.differentiate(torch.mean(loss), G)                    # register_gradients(tf.reduce_mean(G_loss)) :290
+        G_opt.differentiate(torch.mean(loss), G, overlap_exchange=overlap_exchange)                    # register_gradients(tf.reduce_mean(G_loss)) :290
         D.requires_grad_(True)
         return loss
 
@@ -346,7 +349,7 @@ def training_loop(
         _, reg = G_loss_fn(G=G, D=D, lpips=lpips, training_set=training_set, minibatch_size=B,
                            reals_rec_1=None, labels_rec_1=None, latents_rec_1=feed['latents_rec_1'],
                            reals_rec_2=None, labels_rec_2=None, latents_rec_2=feed['latents_rec_2'], phase='reg', **G_loss_args)
-        G_reg_opt.differentiate(torch.mean(reg * G_reg_interval), G)   # :288
+        G_reg_opt.differentiate(torch.mean(reg * G_reg_interval), G, overlap_exchange=overlap_exchange)   # :288
         D.requires_grad_(True)
         return reg
 
@@ -359,7 +362,7 @@ def training_loop(
         if not lazy_regularization and reg is not None:
             loss = loss + reg       # :286
         G.requires_grad_(True)
-        D_opt.differentiate(torch.mean(loss), D)                    # :291
+        D_opt.differentiate(torch.mean(loss), D, overlap_exchange=overlap_exchange)                    # :291
         return loss
 
     def D_reg_grad():
@@ -368,7 +371,7 @@ def training_loop(
         G.requires_grad_(False)
         _, reg = D_loss_fn(G=G, D=D, training_set=training_set, minibatch_size=B, reals=reals, labels=labels, phase='reg', **D_loss_args)
         G.requires_grad_(True)
-        D_reg_opt.differentiate(torch.mean(reg * D_reg_interval), D)   # :289
+        D_reg_opt.differentiate(torch.mean(reg * D_reg_interval), D, overlap_exchange=overlap_exchange)   # :289
         return reg
 
     G_grad_step = graphs.GraphedStep(G_grad, use_graphs, eager_calls=1, name='G')

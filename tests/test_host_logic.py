@@ -182,7 +182,25 @@ def _dp_worker(rank, world, port, out):
     # identical host-side streams on every rank (np seed) -> identical shuffles / candidate latents
     np.random.seed(1000)
     order = np.arange(12); np.random.shuffle(order)
-    out[rank] = (g.tolist(), bi.tolist(), bd.tolist(), order.tolist())
+    # hook-driven chunked exchange during backward (tflib/optimizer.py GradientExchange) on a CPU-resident network:
+    # rank r differentiates (r + 1) * sum(p^2) / 2, so the averaged bucket must be 1.5 * p for every trainable
+    from inclusivegan_amd.dnnlib import tflib
+    net = tflib.Network('D', func_name='inclusivegan_amd.training.networks_stylegan2.D_stylegan2_feature', architecture='resnet',
+                        num_channels=3, resolution=16, label_size=0, fmap_base=128, device='cpu', seed=3)
+    opt = tflib.Optimizer(name='T', learning_rate=0.01, beta1=0.0, beta2=0.99)
+    loss = sum((p * p).sum() for p in net.trainables.values()) * (0.5 * (rank + 1))
+    opt.differentiate(loss, net)            # world 2 -> overlapped exchange by default
+    ex = opt._state['exchange']
+    want = 1.5 * net.flat_params
+    exch = (len(ex.chunks), sum(c.numel() for c in ex.chunks) == net.flat_grads.numel(), bool(torch.allclose(net.flat_grads, want, rtol=1e-6, atol=1e-7)),
+            opt._exchanged)
+    # the blocking form gives the same bucket bit for bit
+    loss = sum((p * p).sum() for p in net.trainables.values()) * (0.5 * (rank + 1))
+    bucket = net.flat_grads.clone()
+    opt.differentiate(loss, net, overlap_exchange=False)
+    allreduce_mean_(net.flat_grads, 1)
+    exch = exch + (bool(torch.equal(bucket, net.flat_grads)),)
+    out[rank] = (g.tolist(), bi.tolist(), bd.tolist(), order.tolist(), exch)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -204,6 +222,9 @@ def test_data_parallel_exchange_gloo_world2():
     assert r0[1] == [20, 11, 5] and r1[1] == [20, 11, 5]         # per-real winner over both shards; tie (9.0) -> lower index
     assert r0[2] == [pytest.approx(2.0 ** 0.5), 1.0, 3.0]        # Euclidean (sqrt) distances
     assert r0[3] == r1[3]
+    for r in (r0, r1):
+        nchunks, covers, averaged, flagged, same_as_blocking = r[4]
+        assert nchunks >= 2 and covers and averaged and flagged and same_as_blocking
 
 
 def test_mbstd_preserving_interleave_is_exact():
