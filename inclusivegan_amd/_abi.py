@@ -15,7 +15,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libigan_hip.so')
+# IGAN_LIB selects another build of the same library (A/B runs of compile-time kernel variants: make VARIANT=...)
+LIB_PATH = os.environ.get('IGAN_LIB') or os.path.join(_HERE, 'csrc', 'libigan_hip.so')
 
 IGAN_OK = 0
 IGAN_ERR_INVALID_ARGUMENT = 1

@@ -69,6 +69,7 @@ struct ConvArgs {
     int vecY;               // 8 B output stores usable (Cout even, y / out_scale 8 B aligned)
     float alpha;            // output multiplier (applied here when splits == 1, else by the reduce kernel)
     int xcd_remap;          // XCD-aware block order (remap_xcd)
+    int walk;               // walking address computation usable (16 B paths, Cin % 32 == 0)
     const float* bias;      // fused epilogue (act != 0): y = act(y + bias[co]) * act_gain
     int act;                // 0 none, 1 linear, 2 relu, 3 lrelu
     float act_alpha, act_gain;
@@ -186,8 +187,12 @@ __device__ __forceinline__ void load_frag(const float* __restrict__ S, int r0, i
 }
 
 // MFMAs of k steps [J0, J1) of the chunk whose fragments are in af / bf.
+// IGAN_MFMA_PRIO (compile-time experiment): raise the wave's issue priority while it is in a matrix cluster.
 template <int TM, int TN, int J0, int J1>
 __device__ __forceinline__ void mma_steps(const float (&af)[TM][16], const float (&bf)[TN][16], f32x16 (&acc)[TM][TN]) {
+#ifdef IGAN_MFMA_PRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int j = J0; j < J1; j++)
 #pragma unroll
@@ -195,6 +200,9 @@ __device__ __forceinline__ void mma_steps(const float (&af)[TM][16], const float
 #pragma unroll
             for (int tn = 0; tn < TN; tn++)
                 acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm][j], bf[tn][j], acc[tm][tn], 0, 0, 0);
+#ifdef IGAN_MFMA_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
 }
 
 // ------------------------------------------------------------------------------
@@ -303,7 +311,65 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_fwd
     // that the scheduler tucks into MFMA shadows); the prefetch itself is then 3*AR.. buffer loads
     // issued back to back at the top of the iteration.
     LoadAddr aa[AR], as_[AR], ab[BR];
+    // Walking form of the address computation (a.walk: 16 B paths and Cin % 32 == 0, i.e. every layer of the networks but the
+    // RGB ends): inside one tap consecutive chunks differ by 32 input channels = +128 B on every activation / scale row and
+    // a uniform step on the filter rows, and validity (padding, ragged rows) is a property of the tap.  So the full decode --
+    // integer multiplies, compares, selects: ~90 vector instructions per chunk, which compete with the MFMAs for the SIMD's
+    // issue slots -- runs once per TAP (uniform branch), and a chunk costs three adds per staged row.  Past the last chunk
+    // the walk runs on into addresses that are either out of range (the buffer descriptor returns 0) or valid memory; what
+    // is fetched there lands in the LDS buffer nobody reads.
+    unsigned offA[AR], offS[AR], offB[BR];
+    bool walk_fresh = true;
+    const unsigned stepB = WT ? 128u : (unsigned)(BK * a.Cout) * 4u;
+    auto decode_tap = [&]() {
+        const int ky = ky0 + (ld_ta << a.up_shift), kx = kx0 + (ld_tb << a.up_shift);
+        const int ci = ld_cc * BK + 4 * kvec;
+#pragma unroll
+        for (int i = 0; i < AR; i++) {
+            const int vy = rby[i] + ky, vx = rbx[i] + kx;
+            const int iy = vy >> a.up_shift, ix = vx >> a.up_shift;
+            const bool ok = rok[i] & (vy >= 0) & (vx >= 0) & (iy < a.H) & (ix < a.W);
+            offA[i] = ok ? (unsigned)(((rn[i] * a.H + iy) * a.W + ix) * a.Cin + ci) * 4u : OOB;
+            if constexpr (SC) offS[i] = ok ? (unsigned)(rn[i] * a.Cin + ci) * 4u : OOB;
+        }
+        if constexpr (!WT) {
+#pragma unroll
+            for (int i = 0; i < BR; i++) {
+                const int cik = ld_cc * BK + krow0 + KROWS * i;
+                const int co = n0 + 4 * nvec;
+                offB[i] = (co < a.Cout) ? (unsigned)(((ky * a.KW + kx) * a.Cin + cik) * a.Cout + co) * 4u : OOB;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < BR; i++) {
+                const int co = n0 + brow0 + AROWS * i;
+                offB[i] = (co < a.Cout) ? (unsigned)((((a.KH - 1 - ky) * a.KW + (a.KW - 1 - kx)) * a.Cout + co) * a.Cin + ci) * 4u : OOB;
+            }
+        }
+    };
     auto prep_chunk = [&](bool live) {
+        if constexpr (VEC) {
+            if (a.walk) {
+                if (walk_fresh | (ld_cc == 0)) decode_tap();     // uniform
+                walk_fresh = false;
+#pragma unroll
+                for (int i = 0; i < AR; i++) {
+                    aa[i].off = offA[i]; aa[i].left = 0;
+                    offA[i] += 128u;                             // OOB stays out of range: 0x7FFFFFF0 + cpt * 128 < 2^32
+                    if constexpr (SC) { as_[i].off = offS[i]; as_[i].left = 0; offS[i] += 128u; }
+                }
+#pragma unroll
+                for (int i = 0; i < BR; i++) { ab[i].off = offB[i]; ab[i].left = 0; offB[i] += stepB; }
+                ++ld_cc;
+                const int w1 = (ld_cc == a.cpt) ? 1 : 0;
+                ld_cc = w1 ? 0 : ld_cc;
+                ld_tb += w1;
+                const int w2 = (ld_tb == nkx) ? 1 : 0;
+                ld_tb = w2 ? 0 : ld_tb;
+                ld_ta += w2;
+                return;
+            }
+        }
         const int ci0 = ld_cc * BK;
         const int ky = ky0 + (ld_ta << a.up_shift), kx = kx0 + (ld_tb << a.up_shift);
         const int ci = ci0 + 4 * kvec;
@@ -1056,6 +1122,8 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
     {   // A/B switch: IGAN_XCD_REMAP=0 keeps the plain block order
         static const bool remap = !(getenv("IGAN_XCD_REMAP") && atoi(getenv("IGAN_XCD_REMAP")) == 0);
         a.xcd_remap = remap ? 1 : 0;
+        static const bool walk = !(getenv("IGAN_CONV_WALK") && atoi(getenv("IGAN_CONV_WALK")) == 0);     // A/B switch
+        a.walk = (walk && a.vecA && a.vecB && (a.in_scale == nullptr || a.vecS) && (p->Cin % BK == 0)) ? 1 : 0;
     }
     a.bias = p->bias; a.act = p->act; a.act_alpha = p->act_alpha; a.act_gain = p->act_gain;
 

@@ -386,6 +386,53 @@ class Network:
             outs = outs[0] if len(outs) == 1 else tuple(outs)
         return outs
 
+    # ------------------------------------------------------------------
+    # Pickle export / import in the layout of the reference's Network.__getstate__ / __setstate__ (network.py:255-299):
+    #   version 4, name, static_kwargs, components {key: Network}, build_module_src, build_func_name,
+    #   variables = [(local name, ndarray)] of the network's OWN variables (component variables travel with the component).
+    def own_var_names(self):
+        """Local names of the variables that belong to this network itself, not to one of its components (network.py:181-185)."""
+        comp_prefixes = [c._prefix[len(self._prefix):] for c in self.components.values() if isinstance(c, Network)]
+        return [n for n in self.vars if not any(n.startswith(cp) for cp in comp_prefixes)]
+
+    def state_v4(self, build_module_src='', build_func_name=None):
+        """The reference's pickle state for this network (recursively for components).  `build_module_src` is the source
+        text of the reference module that defines the build function (training/networks_stylegan2.py of a reference
+        checkout) when the pickle is meant to be opened BY the reference; '' when it only has to come back here."""
+        fn = build_func_name or self._build_func_name.rsplit('.', 1)[-1]
+        return dict(version=4, name=self.name, static_kwargs=dict(self.static_kwargs),
+                    components={k: c for k, c in self.components.items() if isinstance(c, Network)},
+                    build_module_src=build_module_src, build_func_name=fn,
+                    variables=[(n, self.vars[n].detach().cpu().numpy().copy()) for n in self.own_var_names()])
+
+    def __getstate__(self):
+        return self.state_v4(build_module_src=getattr(self._root, '_export_module_src', ''))
+
+    def __reduce__(self):
+        return (_rebuild_network, (self.__getstate__(), str(self.device)))
+
+    def load_state_v4(self, state, strict=True):
+        """Copy the variables of a reference-layout state (this network's own + its components', recursively) into this
+        network by local name.  strict: every variable of this network must be present with the same shape."""
+        found = set()
+
+        def walk(st, prefix):
+            for local, value in st['variables']:
+                found.add(prefix + local)
+                if prefix + local in self.vars:
+                    self.set_var(prefix + local, value)
+                elif strict:
+                    raise KeyError('pickled variable %r does not exist in network %r' % (prefix + local, self.name))
+            for comp in dict(st.get('components', {})).values():
+                cst = comp if isinstance(comp, dict) else comp.__dict__.get('_state') or comp.state_v4()
+                walk(cst, prefix + cst['name'] + '/')
+        walk(state, '')
+        if strict:
+            missing = [n for n in self.vars if n not in found]
+            if missing:
+                raise KeyError('network %r: variables missing from the pickle: %s' % (self.name, missing[:5]))
+        return self
+
     def print_layers(self, title=None):
         rows = [[title or self.name, 'Params', 'Shape']]
         total = 0
@@ -399,3 +446,37 @@ class Network:
         for r in rows:
             print('  '.join(c + ' ' * (w - len(c)) for c, w in zip(r, widths)))
         print()
+
+
+class PickledNetwork:
+    """What a reference pickle's `dnnlib.tflib.network.Network` object becomes when it is opened here (training/misc.py
+    load_pkl): just its state dict.  `to_network(device)` builds the live Network."""
+
+    def __setstate__(self, state):
+        self._state = state
+
+    def to_network(self, device=None, func_module='inclusivegan_amd.training.networks_stylegan2', **override_static_kwargs):
+        return network_from_state(self._state, device=device, func_module=func_module, **override_static_kwargs)
+
+
+def network_from_state(state, device=None, func_module='inclusivegan_amd.training.networks_stylegan2', **override_static_kwargs):
+    """Reference-layout state (version 2-4) -> live Network on `device`: the build function is looked up BY NAME in this
+    engine's counterpart module (the pickled source text is the reference's TensorFlow code and is not executed)."""
+    assert state['version'] in (2, 3, 4)
+    kw = dict(state['static_kwargs'])
+    kw.update(override_static_kwargs)
+    kw.pop('func_name', None)
+    fn = state['build_func_name']
+    func_name = fn if '.' in fn else func_module + '.' + fn
+    if func_name.startswith('training.') or func_name.startswith('metrics.'):
+        func_name = 'inclusivegan_amd.' + func_name
+    net = Network(state['name'], func_name=func_name, device=device, **kw)
+    net.load_state_v4(state)
+    return net
+
+
+def _rebuild_network(state, device):
+    dev = device
+    if dev.startswith('cuda') and not torch.cuda.is_available():
+        dev = 'cpu'
+    return network_from_state(state, device=dev)

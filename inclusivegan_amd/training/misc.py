@@ -36,16 +36,116 @@ def slerp(a, b, t):
 # ----------------------------------------------------------------------------
 # Pickle wrappers (misc.py:20-31; the URL cache is not offered: there is no network path here).
 
+# The reference pickles (G, D, Gs) as `dnnlib.tflib.network.Network` objects (training_loop.py:518-519, network.py:255-299).
+# Opening such a file here maps that class onto a state holder (tflib.network.PickledNetwork) and `dnnlib.util.EasyDict` onto
+# this package's EasyDict; `as_networks()` then builds live networks.  Writing with reference_layout=True emits the same
+# class path, so the reference's own `misc.load_pkl` can open the file (given the source text of its network module).
+
+_REF_CLASSES = {('dnnlib.tflib.network', 'Network'): ('inclusivegan_amd.dnnlib.tflib.network', 'PickledNetwork'),
+                ('dnnlib.util', 'EasyDict'): ('inclusivegan_amd.dnnlib.util', 'EasyDict'),
+                ('dnnlib', 'EasyDict'): ('inclusivegan_amd.dnnlib.util', 'EasyDict')}
+
+
 def load_pkl(filename):
+    import importlib
     import pickle
+
+    class _Unpickler(pickle.Unpickler):
+        def find_class(self, module, name):
+            module, name = _REF_CLASSES.get((module, name), (module, name))
+            return getattr(importlib.import_module(module), name)
+
     with open(filename, 'rb') as file:
-        return pickle.load(file, encoding='latin1')
+        return _Unpickler(file, encoding='latin1').load()
 
 
-def save_pkl(obj, filename):
+def as_networks(obj, device=None):
+    """Turn every PickledNetwork inside a loaded object (typically the (G, D, Gs) tuple) into a live Network."""
+    from ..dnnlib.tflib.network import PickledNetwork
+    if isinstance(obj, PickledNetwork):
+        return obj.to_network(device=device)
+    if isinstance(obj, (tuple, list)):
+        return type(obj)(as_networks(o, device) for o in obj)
+    return obj
+
+
+def save_pkl(obj, filename, reference_layout=False, build_module_src=''):
+    """pickle.dump(obj) (misc.py:29-31).  reference_layout=True writes Networks under the reference's class path
+    `dnnlib.tflib.network.Network` with its version-4 state, `build_module_src` being the text of the reference's
+    training/networks_stylegan2.py (read it from a reference checkout; without it the file still loads here, but the
+    reference cannot rebuild the graph)."""
     import pickle
-    with open(filename, 'wb') as file:
-        pickle.dump(obj, file, protocol=pickle.HIGHEST_PROTOCOL)
+    import sys
+    import types
+    from ..dnnlib.tflib.network import Network
+    if not reference_layout:
+        with open(filename, 'wb') as file:
+            pickle.dump(obj, file, protocol=pickle.HIGHEST_PROTOCOL)
+        return
+
+    class _RefNetwork:      # stands where the reference's class will be when the file is opened there
+        def __init__(self, state):
+            self._state = state
+
+        def __getstate__(self):
+            return self._state
+
+    _RefNetwork.__module__ = 'dnnlib.tflib.network'
+    _RefNetwork.__qualname__ = _RefNetwork.__name__ = 'Network'
+
+    def convert(o):
+        if isinstance(o, Network):
+            st = o.state_v4(build_module_src=build_module_src)
+            st['components'] = {k: convert(c) for k, c in st['components'].items()}
+            return _RefNetwork(st)
+        if isinstance(o, (tuple, list)):
+            return type(o)(convert(x) for x in o)
+        return o
+
+    saved = {k: sys.modules.get(k) for k in ('dnnlib', 'dnnlib.tflib', 'dnnlib.tflib.network')}
+    try:
+        for k in saved:
+            sys.modules[k] = types.ModuleType(k)
+        sys.modules['dnnlib.tflib.network'].Network = _RefNetwork
+        with open(filename, 'wb') as file:
+            pickle.dump(convert(obj), file, protocol=pickle.HIGHEST_PROTOCOL)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+def resume_kimg_time(network_pkl):
+    """(kimg, seconds) a snapshot was taken at, from its file name and the run's log.txt next to it (misc.py:147-162)."""
+    import os
+    path, file = os.path.split(network_pkl)
+    kimg = str(int(os.path.splitext(file)[0][-6:]))
+    s = 0.0
+    with open('%s/log.txt' % path, 'r') as f:
+        for line in f:
+            if all(w in line for w in ('tick', 'kimg', 'minibatch', 'time', 'sec/tick', 'sec/kimg', 'maintenance', 'gpumem')) and kimg in line:
+                idx = line.find(kimg)
+                kimg = float(line[idx:idx + len(kimg) + 2])
+                idx = line.find('time')
+                s = time_to_seconds(line[idx + 5:idx + 5 + 12])
+                break
+    return float(kimg), s
+
+
+def time_to_seconds(string):
+    """'1d 02h 03m' / '04m 05s' style durations of dnnlib.util.format_time -> seconds (misc.py:164-187)."""
+    def field(ch, width=2):
+        i = string.find(ch)
+        if i < 0:
+            return 0
+        if ch == 'd':
+            return int(string[:i])
+        if ch == 'h' and i == 1:
+            return int(string[:i])
+        return int(string[i - width:i])
+    return float(((field('d') * 24 + field('h')) * 60 + field('m')) * 60 + field('s'))
 
 
 # ----------------------------------------------------------------------------

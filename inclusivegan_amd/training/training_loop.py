@@ -16,9 +16,12 @@ the global minibatch (tf.split, :231-239); gradients are averaged with one RCCL 
 step over the flat bucket (tflib/optimizer.py); the IMLE candidates are sharded over ranks and the
 per-real minima (fp64 distance, index) are combined with two all-reduce(min).
 
-Out of scope here: run-dir / snapshot / metric maintenance (:485-531).
-A `hooks` dict lets a driver (bench.py, tests) observe iterations and stop early.
+With `run_dir` set, rank 0 writes the reference's snapshots at its cadence (:165-166,506-519): image grids of Gs on fixed
+latents, the reconstruction pairs of the IMLE term, and (G, D, Gs) pickles in the reference's own layout (training/misc.py);
+`resume_pkl` continues from such a pickle -- or from one the reference wrote.  Metric scheduling and tfevents stay out
+(SURVEY.md section 2.1).  A `hooks` dict lets a driver (bench.py, tests) observe iterations and stop early.
 """
+import os
 import time
 
 import numpy as np
@@ -222,12 +225,12 @@ def training_loop(
     lpips_func_name         = 'inclusivegan_amd.metrics.lpips.vgg16_zhang_perceptual',
     hooks                   = None,     # {'on_iteration': f(state) -> bool stop, 'on_refresh': f(seconds), 'on_batch': f(host batch dict)}
     hip_graphs              = True,     # capture the four training ops into hipGraphs (env IGAN_HIP_GRAPHS=0 disables)
+    run_dir                 = None,     # where snapshots go (arb-reals.png, arb-fakes-*.png, rec-*.png, network-snapshot-*.pkl, :171-172,506-519); None = none
+    reference_src           = None,     # path of a reference checkout's training/networks_stylegan2.py: snapshots then open in the reference too
     submit_config           = None,
     ):
 
     hooks = hooks or {}
-    if resume_pkl is not None:
-        raise NotImplementedError('resume_pkl: checkpoint interchange is a later row (SURVEY.md section 8f)')
     if exclusive_retrieved_code:
         raise NotImplementedError('exclusive_retrieved_code needs k-NN with k>1; only the default 1-NN path is built')
 
@@ -246,10 +249,19 @@ def training_loop(
     training_set_rec = dataset.load_dataset(data_dir=data_dir, verbose=False, device=device, rank=0, world_size=1, **ds_args)
 
     grid_size, grid_reals, grid_labels = misc.setup_snapshot_image_grid(training_set, **grid_args)   # :171 (walks training_set's iterator)
+    image_snapshot_ticks = data_size // 1000            # :165
+    network_snapshot_ticks = data_size // 1000 * 5      # :166
+    tick_reals_old = None
+    module_src = ''
+    if run_dir is not None and rank == 0:
+        os.makedirs(run_dir, exist_ok=True)
+        misc.save_image_grid(grid_reals, os.path.join(run_dir, 'arb-reals.png'), drange=training_set.dynamic_range, grid_size=grid_size)   # :172
+        if reference_src is not None:
+            with open(reference_src) as f:
+                module_src = f.read()
 
     if attr_interesting is not None and attr_names is None:
         # :174-180 reads the vocabulary from celeba/Anno/list_attr_celeba.txt (relative to the working directory)
-        import os
         attr_file = 'celeba/Anno/list_attr_celeba.txt'
         if not os.path.isfile(attr_file):
             raise FileNotFoundError('attr_interesting=%r needs the attribute names: pass attr_names=[...] or provide %s' % (attr_interesting, attr_file))
@@ -261,9 +273,16 @@ def training_loop(
     G_args = dict(G_args); D_args = dict(D_args)
     G_args['func_name'] = _retarget(G_args.get('func_name', 'training.networks_stylegan2.G_main'))
     D_args['func_name'] = _retarget(D_args.get('func_name', 'training.networks_stylegan2.D_stylegan2_feature'))
-    G = tflib.Network('G', num_channels=training_set.shape[0], resolution=training_set.shape[1], label_size=training_set.label_size, device=device, seed=np_seed + 1, **G_args)
-    D = tflib.Network('D', num_channels=training_set.shape[0], resolution=training_set.shape[1], label_size=training_set.label_size, device=device, seed=np_seed + 2, **D_args)
-    Gs = G.clone('Gs')
+    resume_kimg, resume_time = 0.0, 0.0
+    if resume_pkl is None:
+        G = tflib.Network('G', num_channels=training_set.shape[0], resolution=training_set.shape[1], label_size=training_set.label_size, device=device, seed=np_seed + 1, **G_args)
+        D = tflib.Network('D', num_channels=training_set.shape[0], resolution=training_set.shape[1], label_size=training_set.label_size, device=device, seed=np_seed + 2, **D_args)
+        Gs = G.clone('Gs')
+    else:       # :193-195 -- a snapshot of this engine or of the reference (same pickle layout, training/misc.py)
+        if rank == 0:
+            print('Loading networks from "%s"...' % resume_pkl)
+        resume_kimg, resume_time = misc.resume_kimg_time(resume_pkl)
+        G, D, Gs = misc.as_networks(misc.load_pkl(resume_pkl), device=device)
     lpips = tflib.Network('lpips', func_name=lpips_func_name, resolution=training_set.shape[1], device=device, seed=np_seed + 3)
     proj_dim = func_proj_dim(init_proj_dim, data_size, num_samples_factor, G)
     grid_latents = np.random.randn(int(np.prod(grid_size)), *G.input_shapes[0][1:])      # :203 (consumes the host stream)
@@ -429,7 +448,7 @@ def training_loop(
 
     if rank == 0:
         print('Training for %d kimg...\n' % total_kimg)
-    cur_nimg = 0
+    cur_nimg = int(resume_kimg * 1000)
     cur_tick = -1
     tick_start_nimg = cur_nimg
     tick_start_time = time.time()
@@ -529,6 +548,23 @@ def training_loop(
                     print('    %-32s %g' % (k, v))
             tick_start_nimg = cur_nimg
             tick_start_time = now
+
+            # Save snapshots (:506-519); rank 0 only, and only when a run directory was asked for.
+            if run_dir is not None and rank == 0:
+                snap = lambda name: os.path.join(run_dir, name)
+                if image_snapshot_ticks is not None and (cur_tick % max(image_snapshot_ticks, 1) == 0 or done):
+                    grid_fakes = Gs.run(grid_latents, grid_labels, is_validation=True, minibatch_size=sched.minibatch_gpu)
+                    misc.save_image_grid(grid_fakes, snap('arb-fakes-%06d.png' % (cur_nimg // 1000)), drange=drange_net, grid_size=grid_size)
+                    if sampler.tick is not None:
+                        t_reals, t_labels, t_latents = sampler.tick
+                        rec_grid = (8, (sched.minibatch_size * 2) // 8) if (sched.minibatch_size * 2) % 8 == 0 else None
+                        if tick_reals_old is None or np.sum(t_reals != tick_reals_old) > 0:
+                            misc.save_image_grid(t_reals, snap('rec-reals.png'), drange=training_set.dynamic_range, grid_size=rec_grid)
+                            tick_reals_old = np.array(t_reals)
+                        fakes_nn = Gs.run(t_latents, t_labels, is_validation=True, minibatch_size=sched.minibatch_gpu)
+                        misc.save_image_grid(fakes_nn, snap('rec-fakes-%06d.png' % (cur_nimg // 1000)), drange=drange_net, grid_size=rec_grid)
+                if network_snapshot_ticks is not None and (cur_tick % max(network_snapshot_ticks, 1) == 0 or done):
+                    misc.save_pkl((G, D, Gs), snap('network-snapshot-%06d.pkl' % (cur_nimg // 1000)), reference_layout=True, build_module_src=module_src)
 
     training_set.close()
     training_set_rec.close()
