@@ -338,6 +338,9 @@ int igan_nn1_update(igan_stream_t stream, const float* query, const float* qnorm
  * first .. first+count-1, stamps[2i+1] - stamps[2i] into acc[i]; captured at the end of a graph it turns every replay
  * into one more sample per launch without host involvement. */
 int igan_stamp(igan_stream_t stream, unsigned long long* slot);
+/* Diagnostic: while p != NULL every igan_conv2d launch of the MFMA forward kernel writes, per workgroup, 4 ticks of the same
+ * counter (kernel entry, main-loop start, main-loop end, exit) to p[4 * workgroup + k]; the buffer must hold 4 * grid words. */
+void igan_debug_set_conv_diag(unsigned long long* p);
 int igan_stamp_accumulate(igan_stream_t stream, const unsigned long long* stamps, unsigned long long* acc, int first, int count);
 
 /* ------------------------------------------------------------------------

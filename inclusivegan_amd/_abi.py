@@ -156,6 +156,7 @@ SIGNATURES = {
     'igan_row_sqnorm': (_I, [_P, _P, _P, _I, _I]),
     'igan_nn1_update': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I]),
     'igan_stamp': (_I, [_P, _P]),
+    'igan_debug_set_conv_diag': (None, [_P]),
     'igan_stamp_accumulate': (_I, [_P, _P, _P, _I, _I]),
     'igan_finite_check': (_I, [_P, _P, _I, _P]),
     'igan_adam_step': (_I, [_P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _P, _P]),

@@ -46,6 +46,9 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 32;        // reduction chunk (floats)
+#ifndef IGAN_SPLIT
+#define IGAN_SPLIT 8          // k steps (of 16) issued before the staged chunk is written to LDS: the lead time of the global loads
+#endif
 constexpr int LDK = BK + 4;   // row pitch of a [rows][k] LDS image (144 B: 16 B aligned, conflict-free b128 reads)
 
 struct ConvArgs {
@@ -70,6 +73,8 @@ struct ConvArgs {
     float alpha;            // output multiplier (applied here when splits == 1, else by the reduce kernel)
     int xcd_remap;          // XCD-aware block order (remap_xcd)
     int walk;               // walking address computation usable (16 B paths, Cin % 32 == 0)
+    int stagger;            // start delay (64-cycle quanta) of the workgroup in the upper LDS slot (0 = none)
+    unsigned long long* diag;   // diagnostic build-in: 4 time stamps (100 MHz ticks) per workgroup, or nullptr
     const float* bias;      // fused epilogue (act != 0): y = act(y + bias[co]) * act_gain
     int act;                // 0 none, 1 linear, 2 relu, 3 lrelu
     float act_alpha, act_gain;
@@ -187,12 +192,13 @@ __device__ __forceinline__ void load_frag(const float* __restrict__ S, int r0, i
 }
 
 // MFMAs of k steps [J0, J1) of the chunk whose fragments are in af / bf.
-// IGAN_MFMA_PRIO (compile-time experiment): raise the wave's issue priority while it is in a matrix cluster.
-template <int TM, int TN, int J0, int J1>
+// PRIO: raise the wave's issue priority while it is in a matrix cluster, so that another wave's address / staging VALU work
+// cannot delay its next MFMA.  Measured (sustained, B = 6, 128x128 C128): weight-gradient kernel 269 -> 255 us (+5.6 %);
+// forward kernel 244 -> 252 us (its staging stores then wait behind every other wave's matrix cluster); the 8-wave form of the
+// weight-gradient kernel loses 20 %, the plain 4-wave form 1 % -- so only the 4-wave modulated weight-gradient kernel sets it.
+template <int TM, int TN, int J0, int J1, bool PRIO = false>
 __device__ __forceinline__ void mma_steps(const float (&af)[TM][16], const float (&bf)[TN][16], f32x16 (&acc)[TM][TN]) {
-#ifdef IGAN_MFMA_PRIO
-    __builtin_amdgcn_s_setprio(1);
-#endif
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int j = J0; j < J1; j++)
 #pragma unroll
@@ -200,9 +206,7 @@ __device__ __forceinline__ void mma_steps(const float (&af)[TM][16], const float
 #pragma unroll
             for (int tn = 0; tn < TN; tn++)
                 acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm][j], bf[tn][j], acc[tm][tn], 0, 0, 0);
-#ifdef IGAN_MFMA_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
 }
 
 // ------------------------------------------------------------------------------
@@ -211,7 +215,7 @@ __device__ __forceinline__ void mma_steps(const float (&af)[TM][16], const float
 // SC: an in_scale operand exists (host dispatch on the pointer) -- without it the scale loads,
 // their addresses and the multiplies are not in the loop at all.
 template <int BM, int BN, int WM, int WN, bool WT, bool VEC, bool SC>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_fwd_kernel(ConvArgs a) {
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 8 : ((WM * WN == 8) ? 4 : 2)) void conv_fwd_kernel(ConvArgs a) {
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
     constexpr int LDB = WT ? LDK : BN + 4;
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_fwd
     constexpr int AROWS = NT / 8;        // tile rows covered by one pass of the loaders (8 float4 per 32-k row)
     constexpr int AR = BM / AROWS;       // A rows per thread
     constexpr int BR = BN / AROWS;       // B float4 per thread (both layouts: BK * BN / 4 / NT)
-    static_assert(TM >= 1 && TN >= 1 && (WM * WN == 4 || WM * WN == 8) && AR >= 1 && BR >= 1, "bad tile config");
+    static_assert(TM >= 1 && TN >= 1 && (WM * WN == 4 || WM * WN == 8 || WM * WN == 16) && AR >= 1 && BR >= 1, "bad tile config");
 
     __shared__ __attribute__((aligned(16))) float As[2 * A_ELEMS];
     __shared__ __attribute__((aligned(16))) float Bs[2 * B_ELEMS];
@@ -234,6 +238,21 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_fwd
     const int wm = wave / WN, wn = wave % WN;
 
     const int up = 1 << a.up_shift;
+    auto stamp = [&](int k) {       // diagnostic only (a.diag == nullptr in every normal launch)
+        if (a.diag != nullptr && (threadIdx.x >> 6) == 0) {
+            const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+            if ((threadIdx.x & 63) == 0) a.diag[(size_t)blockIdx.x * 4 + k] = t;
+        }
+    };
+    stamp(0);
+    if (a.stagger > 0) {
+        // Two workgroups share a CU and run the same program on equal tiles: left alone they stay in phase, and their
+        // barrier / staging bubbles coincide.  The one that did not get the bottom of the CU's LDS starts `stagger`
+        // sleep quanta (64 cycles each) late, i.e. about half a chunk out of phase.
+        const unsigned lds_base = __builtin_amdgcn_s_getreg((7 << 11) | (0 << 6) | 6) & 0xFF;   // HW_REG_LDS_ALLOC.LDS_BASE
+        if (lds_base != 0)
+            for (int i = 0; i < a.stagger; i++) __builtin_amdgcn_s_sleep(1);
+    }
     // block -> (tile, reduction slice): whole tiles first, then the sliced tail
     const int bid = a.xcd_remap ? remap_xcd(blockIdx.x, gridDim.x) : (int)blockIdx.x;
     const bool sliced = bid >= a.full_tiles;
@@ -445,6 +464,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_fwd
         prep_chunk(c_begin + 1 < c_end);
     }
     __syncthreads();
+    stamp(1);
     for (int c = c_begin; c < c_end; c++) {
         const int cur = (c - c_begin) & 1;
         // Prefetch of chunk c+1 (predicated off -- every lane out of range, no memory traffic -- on the
@@ -454,7 +474,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_fwd
         float af[TM][16], bf[TN][16];
         load_frag<TM, false, LDK>(As + cur * A_ELEMS, wm * (BM / WM), l31, h, af);
         load_frag<TN, !WT, LDB>(Bs + cur * B_ELEMS, wn * (BN / WN), l31, h, bf);
-        mma_steps<TM, TN, 0, 8>(af, bf, acc);
+        mma_steps<TM, TN, 0, IGAN_SPLIT>(af, bf, acc);
         prep_chunk(c + 2 < c_end);           // addresses of chunk c+2: VALU only, free to interleave with the MFMAs
         // ... and its consumers (with their s_waitcnt vmcnt) stay BEHIND the first half of the MFMAs:
         // without this fence hipcc hoists the first scale-multiply + ds_write up to the first MFMA and
@@ -463,10 +483,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_fwd
         // interleave with the second half of the MFMAs, whose issue slots they fill.
         __builtin_amdgcn_sched_barrier(0);
         store_chunk(cur ^ 1);
-        mma_steps<TM, TN, 8, 16>(af, bf, acc);
+        mma_steps<TM, TN, IGAN_SPLIT, 16>(af, bf, acc);
         __syncthreads();
     }
 
+    stamp(2);
     // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*h; tile -> column via tile_row ----
     if (sliced && nsplit > 1) {
         // partial tile, raw, into its [BM][BN] slot of the workspace (a.y): slot = tail tile * splits + slice
@@ -490,6 +511,21 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_fwd
     const bool scale = a.out_scale != nullptr;
     const float alpha = a.alpha;
     const int cbase = n0 + wn * (BN / WN);
+    // Per-lane constants of the epilogue: the lane's output channels are fixed, so bias (and alpha) are loaded once; the
+    // per-(sample, channel) output scale is loaded once too when the whole tile lies in one sample (every layer from 16x16
+    // up: 128 rows <= H*W), otherwise per row.  (One dependent L2 round trip per row made the epilogue 7-20 us per tile.)
+    int cos[TN];
+    float mul[TN], bia[TN];
+    const int n_first = row_n[0], n_last = row_n[min(BM, Mcls - m0) - 1];
+    const bool one_sample = n_first == n_last;
+#pragma unroll
+    for (int tn = 0; tn < TN; tn++) {
+        cos[tn] = cbase + tile_row<TN, !WT>(tn, l31);
+        const bool in = cos[tn] < a.Cout;
+        mul[tn] = (scale && one_sample && in) ? a.out_scale[n_first * a.Cout + cos[tn]] : 1.0f;
+        bia[tn] = (a.act && a.bias && in) ? a.bias[cos[tn]] : 0.0f;
+    }
+    const bool row_scale = scale && !one_sample;
 #pragma unroll
     for (int tm = 0; tm < TM; tm++) {
 #pragma unroll
@@ -497,38 +533,26 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_fwd
             const int row = wm * (BM / WM) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             const int pix = row_pix[row];
             if (pix < 0) continue;
-            const int nn = row_n[row];
+            float v[TN];
+#pragma unroll
+            for (int tn = 0; tn < TN; tn++) {
+                v[tn] = acc[tm][tn][r] * alpha;
+                if (scale && one_sample) v[tn] *= mul[tn];       // same product order as the per-row form and the fix-up kernel
+                if (row_scale && cos[tn] < a.Cout) v[tn] *= a.out_scale[row_n[row] * a.Cout + cos[tn]];
+                if (a.act) v[tn] = epi_act(a.act, v[tn] + bia[tn], a.act_alpha) * a.act_gain;
+            }
             if constexpr (!WT && TN == 2) {
                 if (a.vecY) {   // the lane's two tiles are adjacent channels: one 8 B store
-                    const int co = cbase + 2 * l31;
-                    if (co < a.Cout) {
-                        float2 v = make_float2(acc[tm][0][r] * alpha, acc[tm][1][r] * alpha);
-                        if (scale) {
-                            const float2 sc = *reinterpret_cast<const float2*>(a.out_scale + nn * a.Cout + co);
-                            v.x *= sc.x; v.y *= sc.y;
-                        }
-                        if (a.act) {
-                            if (a.bias) { v.x += a.bias[co]; v.y += a.bias[co + 1]; }
-                            v.x = epi_act(a.act, v.x, a.act_alpha) * a.act_gain;
-                            v.y = epi_act(a.act, v.y, a.act_alpha) * a.act_gain;
-                        }
-                        *reinterpret_cast<float2*>(out + (size_t)pix * a.Cout + co) = v;
-                    }
+                    if (cos[0] < a.Cout) *reinterpret_cast<float2*>(out + (size_t)pix * a.Cout + cos[0]) = make_float2(v[0], v[1]);
                     continue;
                 }
             }
 #pragma unroll
-            for (int tn = 0; tn < TN; tn++) {
-                const int co = cbase + tile_row<TN, !WT>(tn, l31);
-                if (co < a.Cout) {
-                    float v = acc[tm][tn][r] * alpha;
-                    if (scale) v *= a.out_scale[nn * a.Cout + co];
-                    if (a.act) v = epi_act(a.act, v + (a.bias ? a.bias[co] : 0.f), a.act_alpha) * a.act_gain;
-                    out[(size_t)pix * a.Cout + co] = v;
-                }
-            }
+            for (int tn = 0; tn < TN; tn++)
+                if (cos[tn] < a.Cout) out[(size_t)pix * a.Cout + cos[tn]] = v[tn];
         }
     }
+    stamp(3);
 }
 
 // Fix-up of the sliced tail tiles: y[tile] = alpha * out_scale * sum_slices ws[tile][slice]  (fixed order).
@@ -830,11 +854,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_wgr
         float af[TM][16], bf[TN][16];
         load_frag<TM, true, LDA>(As + cur * A_ELEMS, wm * (BM / WM), l31, h, af);
         load_frag<TN, true, LDB>(Bs + cur * B_ELEMS, wn * (BN / WN), l31, h, bf);
-        mma_steps<TM, TN, 0, 8>(af, bf, acc);
+        mma_steps<TM, TN, 0, 8, (WM * WN == 4 && SCM != 0)>(af, bf, acc);
         prep_chunk(c + 2 < c_end);            // walk to chunk c+2 in the MFMA shadows
         __builtin_amdgcn_sched_barrier(0);
         store_chunk(cur ^ 1);                 // interleaves with the second half (see conv_fwd_kernel)
-        mma_steps<TM, TN, 8, 16>(af, bf, acc);
+        mma_steps<TM, TN, 8, 16, (WM * WN == 4 && SCM != 0)>(af, bf, acc);
         __syncthreads();
     }
 
@@ -987,6 +1011,11 @@ TileList tile_list(const igan_conv2d_params* p, const FwdTile& t, int Mmax, int 
 
 }  // namespace
 
+// Diagnostic hook (tools/conv_phases.py): when set, every forward-type launch writes 4 time stamps per workgroup (entry, main
+// loop start, main loop end, exit; 100 MHz ticks) to this buffer.  Not part of the operator surface.
+static unsigned long long* g_conv_diag = nullptr;
+extern "C" void igan_debug_set_conv_diag(unsigned long long* p) { g_conv_diag = p; }
+
 extern "C" int igan_conv2d_plan(const igan_conv2d_params* p, int* splits, int* sliced_tiles, size_t* workspace_floats) {
     IGAN_REQUIRE(p && splits && sliced_tiles && workspace_floats, "conv2d_plan: null argument");
     if (int rc = fwd_geometry_check(p)) return rc;
@@ -1123,6 +1152,9 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
         static const bool remap = !(getenv("IGAN_XCD_REMAP") && atoi(getenv("IGAN_XCD_REMAP")) == 0);
         a.xcd_remap = remap ? 1 : 0;
         static const bool walk = !(getenv("IGAN_CONV_WALK") && atoi(getenv("IGAN_CONV_WALK")) == 0);     // A/B switch
+        a.diag = g_conv_diag;
+        static const int stagger = getenv("IGAN_CONV_STAGGER") ? atoi(getenv("IGAN_CONV_STAGGER")) : 0;     // experiment
+        a.stagger = stagger;
         a.walk = (walk && a.vecA && a.vecB && (a.in_scale == nullptr || a.vecS) && (p->Cin % BK == 0)) ? 1 : 0;
     }
     a.bias = p->bias; a.act = p->act; a.act_alpha = p->act_alpha; a.act_gain = p->act_gain;
@@ -1130,7 +1162,9 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
     dim3 grid(a.full_tiles + (l.T - a.full_tiles) * splits);
     const bool wt = p->w_transposed != 0;
     const bool vec = a.vecA && a.vecB && (a.in_scale == nullptr || a.vecS);
-    if (t.BM == 128 && t.BN == 128 && eight_waves("IGAN_CONV_8WAVE")) launch_fwd<128, 128, 2, 4>(stream, a, grid, wt, vec);
+    static const bool sixteen = getenv("IGAN_CONV_16WAVE") && atoi(getenv("IGAN_CONV_16WAVE")) == 1;     // experiment
+    if (t.BM == 128 && t.BN == 128 && sixteen) launch_fwd<128, 128, 4, 4>(stream, a, grid, wt, vec);
+    else if (t.BM == 128 && t.BN == 128 && eight_waves("IGAN_CONV_8WAVE")) launch_fwd<128, 128, 2, 4>(stream, a, grid, wt, vec);
     else if (t.BM == 128 && t.BN == 128) launch_fwd<128, 128, 2, 2>(stream, a, grid, wt, vec);
     else if (t.BM == 128 && t.BN == 64 && eight_waves("IGAN_CONV_8WAVE")) launch_fwd<128, 64, 4, 2>(stream, a, grid, wt, vec);
     else if (t.BM == 128 && t.BN == 64) launch_fwd<128, 64, 2, 2>(stream, a, grid, wt, vec);

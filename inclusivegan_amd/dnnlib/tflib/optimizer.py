@@ -289,6 +289,44 @@ class Optimizer:
 
 
 class SimpleAdam:
-    """Name kept for parity with optimizer.py:290; the arithmetic lives in csrc/optimizer.hip."""
-    def __init__(self, *args, **kwargs):
-        raise NotImplementedError('use Optimizer; SimpleAdam arithmetic is fused into the flat-bucket HIP kernel')
+    """The reference's stand-alone Adam (optimizer.py:290-336: "behaves identically" to tf.train.AdamOptimizer under
+    tflib.Optimizer) for loose lists of tensors: `compute_gradients(loss, var_list)` -> [(grad, var)],
+    `apply_gradients(grads_and_vars)` updates the variables in place.  One beta-power pair per apply_gradients call set
+    (:311-317), one (m, v) pair per variable (:321-324), lr_new = lr * sqrt(1 - b2^t) / (1 - b1^t) (:317), all through the
+    flat Adam kernel of csrc/optimizer.hip (no overflow gate here: the gate belongs to Optimizer.apply_updates, :237)."""
+
+    def __init__(self, name='Adam', learning_rate=0.001, beta1=0.9, beta2=0.999, epsilon=1e-8):
+        self.name = name
+        self.learning_rate = learning_rate
+        self.beta1 = beta1
+        self.beta2 = beta2
+        self.epsilon = epsilon
+        self.all_state_vars = []
+        self._slots = {}
+
+    def variables(self):
+        return self.all_state_vars
+
+    def compute_gradients(self, loss, var_list):
+        return list(zip(torch.autograd.grad(loss, var_list, allow_unused=True), var_list))
+
+    def apply_gradients(self, grads_and_vars):
+        lr = self.learning_rate() if callable(self.learning_rate) else self.learning_rate
+        key = tuple(id(v) for _, v in grads_and_vars)
+        if key not in self._slots:
+            dev = grads_and_vars[0][1].device
+            slot = dict(pow=torch.ones((2,), device=dev), flag=torch.zeros((1,), device=dev, dtype=torch.int32),
+                        mv=[(torch.zeros(v.numel(), device=dev), torch.zeros(v.numel(), device=dev)) for _, v in grads_and_vars])
+            self._slots[key] = slot
+            self.all_state_vars += [slot['pow']] + [t for mv in slot['mv'] for t in mv]
+        slot = self._slots[key]
+        with torch.no_grad():
+            pow_before = slot['pow'].clone()
+            for (g, v), (m, vv) in zip(grads_and_vars, slot['mv']):
+                if g is None:
+                    continue
+                if not v.is_contiguous():
+                    raise ValueError('SimpleAdam: variables must be contiguous')
+                slot['pow'].copy_(pow_before)           # every variable of the set sees the same power pair (:317)
+                hip_ops.adam_step_raw(v.detach().reshape(-1), g.contiguous().reshape(-1), m, vv, lr, self.beta1, self.beta2, self.epsilon,
+                                      slot['pow'], slot['flag'])

@@ -612,3 +612,24 @@ def test_adam_ema_finite_check(cuda_device):
     dst0 = wt.clone()
     hip_ops.ema_raw(wt, src, 0.9995)
     assert rel_err(wt, OO.ema(dst0.cpu().numpy(), src.cpu().numpy(), 0.9995)) < 1e-6
+
+
+def test_simple_adam_class_matches_reference_arithmetic(cuda_device):
+    """tflib.SimpleAdam (dnnlib/tflib/optimizer.py:290-336) on two loose variables: three steps against the NumPy restatement;
+    both variables of a step see the same beta-power pair."""
+    from oracle import optimizer as OO
+    from inclusivegan_amd.dnnlib.tflib.optimizer import SimpleAdam
+    rng = np.random.RandomState(9)
+    a0 = rng.randn(40, 8).astype(np.float32); b0 = rng.randn(64).astype(np.float32)
+    a = torch.from_numpy(a0.copy()).to(cuda_device).requires_grad_(True); b = torch.from_numpy(b0.copy()).to(cuda_device).requires_grad_(True)
+    opt = SimpleAdam(learning_rate=0.01, beta1=0.9, beta2=0.999)
+    oa, ob = OO.SimpleAdam(a0.size, 0.01, 0.9, 0.999, 1e-8), OO.SimpleAdam(b0.size, 0.01, 0.9, 0.999, 1e-8)
+    wa, wb = a0.reshape(-1).copy(), b0.copy()
+    for _ in range(3):
+        loss = (a * a).sum() * 0.5 + (b ** 3).sum()
+        gv = opt.compute_gradients(loss, [a, b])
+        ga, gb = gv[0][0].cpu().numpy().reshape(-1), gv[1][0].cpu().numpy()
+        opt.apply_gradients(gv)
+        oa.apply(wa, ga); ob.apply(wb, gb)
+    assert rel_err(a.detach().reshape(-1), wa) < 2e-6 and rel_err(b.detach(), wb) < 2e-6
+    assert len(opt.variables()) == 5

@@ -40,6 +40,14 @@ def main():
     print('largest gaps (us, after -> before):')
     for g in sorted(gaps, reverse=True)[:top]:
         print('  %9.1f  %-40s -> %s' % (g[0] / 1e3, g[1][:40], g[2][:60]))
+    # per-kernel time inside the window (steady state): what the non-conv remainder of a step is made of
+    per = Counter(); cnt = Counter()
+    for st, e, name in iv:
+        per[name] += e - st; cnt[name] += 1
+    tot = sum(per.values())
+    print('kernel time inside the window: %.1f ms; by kernel:' % (tot / 1e6))
+    for name, t in per.most_common(45):
+        print('  %6.2f %%  %9.2f ms  %7d launches  %8.1f us avg  %s' % (100.0 * t / tot, t / 1e6, cnt[name], t / cnt[name] / 1e3, name[:90]))
     c = Counter()
     for g in gaps:
         if g[0] > 20e3:

@@ -3,7 +3,7 @@
 # and HBM-side traffic with the XCD-aware block order off and on.  Run on a GPU box from the repo root:
 #   tools/pmc_conv.sh <outdir> [batch]
 # Counter passes are separate runs with --kernel-trace only (no other trace domains).
-OUT=${1:?outdir}; B=${2:-6}
+OUT=$(realpath -m ${1:?outdir}); B=${2:-6}
 mkdir -p $OUT
 export TMPDIR=/tmp
 R=$PWD
