@@ -254,7 +254,17 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 8 : ((WM * WN == 8)
             for (int i = 0; i < a.stagger; i++) __builtin_amdgcn_s_sleep(1);
     }
     // block -> (tile, reduction slice): whole tiles first, then the sliced tail
-    const int bid = a.xcd_remap ? remap_xcd(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    // XCD-aware order INSIDE groups of equal-cost tiles only: the whole tiles of one parity class (a transposed conv's classes
+    // have 1 / 2 / 2 / 4 taps; the sliced tail tiles are short).  Remapping across groups would hand one XCD all the heavy
+    // tiles and another all the light ones (measured: the up = 2 layers ran at half speed).
+    int bid = blockIdx.x;
+    if (a.xcd_remap && bid < a.full_tiles) {
+        const int per_class = a.nx * a.ny;
+        const int cls0 = bid / per_class;
+        const int lo = cls0 * per_class;
+        const int cnt = min(per_class, a.full_tiles - lo);
+        bid = lo + remap_xcd(bid - lo, cnt);
+    }
     const bool sliced = bid >= a.full_tiles;
     const int tail = bid - a.full_tiles;
     const int tile = sliced ? a.full_tiles + tail / a.splits : bid;
@@ -465,8 +475,24 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 8 : ((WM * WN == 8)
     }
     __syncthreads();
     stamp(1);
+#ifdef IGAN_YOUNG_PRIO
+    // The second-dispatched half of an 8-wave workgroup (waves 4-7: one per SIMD, beside waves 0-3) loses every issue
+    // arbitration to its older partner, arrives late at each chunk's barrier and makes the older half wait there (measured per
+    // chunk: older waves 1370 cycles at the barrier, younger ones 270).  A static priority for the younger half evens it out.
+    if (WM * WN == 8 && wave >= 4) __builtin_amdgcn_s_setprio(IGAN_YOUNG_PRIO);
+#endif
+#ifdef IGAN_LOOP_STAMPS
+    // Diagnostic variant (make variant DEFS=-DIGAN_LOOP_STAMPS): per wave, the shader cycles spent in the four phases of a
+    // chunk, summed over the tile's chunks: [top .. first MFMA half issued] [.. staged chunk written to LDS] [.. second MFMA
+    // half issued] [.. barrier passed].  Written to diag[4 * grid + (block * 8 + wave) * 4 + k] (tools/conv_phases.py --loop).
+    unsigned long long ph[4] = {0, 0, 0, 0};
+#define LOOP_STAMP(var) __builtin_amdgcn_sched_barrier(0); const unsigned long long var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
+#else
+#define LOOP_STAMP(var)
+#endif
     for (int c = c_begin; c < c_end; c++) {
         const int cur = (c - c_begin) & 1;
+        LOOP_STAMP(ts0)
         // Prefetch of chunk c+1 (predicated off -- every lane out of range, no memory traffic -- on the
         // last iteration, instead of branched around: the loop body stays ONE basic block).
         issue_loads();
@@ -475,6 +501,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 8 : ((WM * WN == 8)
         load_frag<TM, false, LDK>(As + cur * A_ELEMS, wm * (BM / WM), l31, h, af);
         load_frag<TN, !WT, LDB>(Bs + cur * B_ELEMS, wn * (BN / WN), l31, h, bf);
         mma_steps<TM, TN, 0, IGAN_SPLIT>(af, bf, acc);
+        LOOP_STAMP(ts1)
         prep_chunk(c + 2 < c_end);           // addresses of chunk c+2: VALU only, free to interleave with the MFMAs
         // ... and its consumers (with their s_waitcnt vmcnt) stay BEHIND the first half of the MFMAs:
         // without this fence hipcc hoists the first scale-multiply + ds_write up to the first MFMA and
@@ -483,9 +510,19 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 8 : ((WM * WN == 8)
         // interleave with the second half of the MFMAs, whose issue slots they fill.
         __builtin_amdgcn_sched_barrier(0);
         store_chunk(cur ^ 1);
+        LOOP_STAMP(ts2)
         mma_steps<TM, TN, IGAN_SPLIT, 16>(af, bf, acc);
+        LOOP_STAMP(ts3)
         __syncthreads();
+#ifdef IGAN_LOOP_STAMPS
+        const unsigned long long ts4 = __builtin_amdgcn_s_memtime();
+        ph[0] += ts1 - ts0; ph[1] += ts2 - ts1; ph[2] += ts3 - ts2; ph[3] += ts4 - ts3;
+#endif
     }
+#ifdef IGAN_LOOP_STAMPS
+    if (a.diag != nullptr && lane == 0 && wave < 8)
+        for (int k = 0; k < 4; k++) a.diag[(size_t)gridDim.x * 4 + ((size_t)blockIdx.x * 8 + wave) * 4 + k] = ph[k];
+#endif
 
     stamp(2);
     // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*h; tile -> column via tile_row ----
@@ -553,6 +590,259 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 8 : ((WM * WN == 8)
         }
     }
     stamp(3);
+}
+
+// ------------------------------------------------------------------------------
+// Forward-type kernel, LDS-DMA form (128x128x32 tile, 8 waves = 2 x 4 of 64x32).  Same tile list, same MFMA order per
+// accumulator and therefore the same results bit for bit as conv_fwd_kernel<128,128,2,4>; what changes is how a chunk gets
+// into LDS.  In the register-staged kernel every wave spends 600-1250 cycles per chunk between its two MFMA halves waiting
+// for its global loads and writing them to LDS (tools/conv_phases.py --loop), a window in which it issues no MFMA.  Here the
+// chunk is fetched by `buffer_load_dwordx4 ... lds`: the data goes from L2 straight into the LDS stage, needs no staging
+// registers, no scale multiply at store time, no ds_write and no mid-chunk wait -- a wave's chunk is
+//     [4 DMA instructions for chunk c+1] [fragment reads of chunk c] [32 MFMAs] [vmcnt(0) + barrier].
+//  * An LDS-DMA instruction writes 64 lanes x 16 B to ONE contiguous KiB (wave-uniform base + lane * 16), so the stage images
+//    are unpadded: A [128 rows][32 k] and (transposed weights) B [128 n][32 k] store the 16 B k-segment q of row r at slot
+//    q ^ ((r >> 1) & 7) -- each lane simply fetches the segment that belongs in its slot -- which makes the fragment reads
+//    (ds_read_b128, 16 lanes per LDS cycle) conflict-free; B [32 k][128 n] needs no swizzle (ds_read_b32 rows).
+//  * Out-of-range lanes (padding taps, ragged rows) use an out-of-range buffer offset: the DMA writes zeros for them.
+//  * The modulation scale is applied to the A fragments after the LDS read (the products x*s are the same single roundings as
+//    in the staged kernel); the scale row of the tile's sample sits in LDS.  Dispatch therefore needs every tile inside ONE
+//    sample (H*W of the class a multiple of 128) when a scale is present, and 16 B paths with Cin % 32 == 0 (`walk`).
+template <bool WT, bool SC>
+__global__ __launch_bounds__(512, 4) void conv_fwd_dma_kernel(ConvArgs a) {
+    constexpr int BM = 128, BN = 128, WN = 4, TM = 2, TN = 1;
+    constexpr int A_STAGE = BM * BK, B_STAGE = BK * BN;          // floats per stage (16 KiB each)
+    constexpr int SMAX = 512;                                    // scale row (Cin <= 512 with a scale; checked by the host)
+    // one LDS object: [A0 A1 B0 B1 | scale row | row_pix row_n]
+    __shared__ __attribute__((aligned(1024))) float smem[2 * A_STAGE + 2 * B_STAGE + SMAX + 2 * BM];
+    float* As = smem;
+    float* Bs = smem + 2 * A_STAGE;
+    float* s_tab = smem + 2 * A_STAGE + 2 * B_STAGE;
+    int* row_pix = reinterpret_cast<int*>(s_tab + SMAX);
+    int* row_n = row_pix + BM;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int up = 1 << a.up_shift;
+    int bid = blockIdx.x;
+    if (a.xcd_remap && bid < a.full_tiles) {
+        const int per_class = a.nx * a.ny;
+        const int lo = (bid / per_class) * per_class;
+        bid = lo + remap_xcd(bid - lo, min(per_class, a.full_tiles - lo));
+    }
+    const bool sliced = bid >= a.full_tiles;
+    const int tail = bid - a.full_tiles;
+    const int tile = sliced ? a.full_tiles + tail / a.splits : bid;
+    const int split = sliced ? tail % a.splits : 0;
+    const int nsplit = sliced ? a.splits : 1;
+    const int mt = tile % a.nx, nt = (tile / a.nx) % a.ny, cls = tile / (a.nx * a.ny);
+    const int py = cls >> a.up_shift, px = cls & (up - 1);
+    const int QH = (a.OH - py + up - 1) >> a.up_shift;
+    const int QW = (a.OW - px + up - 1) >> a.up_shift;
+    const int Mcls = a.N * QH * QW;
+    const int m0 = mt * BM;
+    if (m0 >= Mcls) return;
+    const int n0 = nt * BN;
+    const int ky0 = (a.pad_y - py * a.stride) & (up - 1);
+    const int kx0 = (a.pad_x - px * a.stride) & (up - 1);
+    const int nky = (ky0 < a.KH) ? ((a.KH - ky0 + up - 1) >> a.up_shift) : 0;
+    const int nkx = (kx0 < a.KW) ? ((a.KW - kx0 + up - 1) >> a.up_shift) : 0;
+    const int chunks = nky * nkx * a.cpt;
+    const int c_begin = (int)(((long long)split * chunks) / nsplit);
+    const int c_end = (int)(((long long)(split + 1) * chunks) / nsplit);
+
+    if (tid < BM) {
+        const int m = m0 + tid;
+        int pix = -1, nn = 0;
+        if (m < Mcls) {
+            nn = m / (QH * QW);
+            const int r = m - nn * (QH * QW);
+            const int qy = r / QW, qx = r - qy * QW;
+            pix = (nn * a.OH + (qy * up + py)) * a.OW + (qx * up + px);
+        }
+        row_pix[tid] = pix;
+        row_n[tid] = nn;
+    }
+    if constexpr (SC) {   // the tile's sample (one per tile by dispatch): its scale row
+        const int nn = m0 / (QH * QW);
+        for (int i = tid; i < a.Cin; i += 512) s_tab[i] = a.in_scale[nn * a.Cin + i];
+    }
+
+    // ---- DMA lane geometry.  A (and transposed B): wave w fills rows [8w, 8w+8) and [64 + 8w, ...): lane -> row = lane >> 3,
+    // LDS slot = lane & 7, fetched k-segment = slot ^ ((row >> 1) & 7).
+    int rn[2], rby[2], rbx[2];
+    bool rok[2];
+    int aseg[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int row = wave * 8 + (lane >> 3) + 64 * i;
+        const int m = m0 + row;
+        rok[i] = m < Mcls;
+        const int mm = rok[i] ? m : 0;
+        const int nn = mm / (QH * QW);
+        const int r = mm - nn * (QH * QW);
+        const int qy = r / QW, qx = r - qy * QW;
+        rn[i] = nn;
+        rby[i] = (qy * up + py) * a.stride - a.pad_y;
+        rbx[i] = (qx * up + px) * a.stride - a.pad_x;
+        aseg[i] = (lane & 7) ^ ((row >> 1) & 7);
+    }
+    int ld_t0 = (c_begin < c_end) ? c_begin / a.cpt : 0;
+    int ld_cc = (c_begin < c_end) ? c_begin - ld_t0 * a.cpt : 0;
+    int ld_ta = (c_begin < c_end) ? ld_t0 / nkx : 0;
+    int ld_tb = (c_begin < c_end) ? ld_t0 - ld_ta * nkx : 0;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, (unsigned)a.N * a.H * a.W * a.Cin * 4u);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.w, (unsigned)a.KH * a.KW * a.Cin * a.Cout * 4u);
+    unsigned offA[2], offB[2];
+    bool fresh = true;
+    const unsigned stepB = WT ? 128u : (unsigned)(BK * a.Cout) * 4u;
+    auto decode_tap = [&]() {
+        const int ky = ky0 + (ld_ta << a.up_shift), kx = kx0 + (ld_tb << a.up_shift);
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int vy = rby[i] + ky, vx = rbx[i] + kx;
+            const int iy = vy >> a.up_shift, ix = vx >> a.up_shift;
+            const bool ok = rok[i] & (vy >= 0) & (vx >= 0) & (iy < a.H) & (ix < a.W);
+            offA[i] = ok ? (unsigned)(((rn[i] * a.H + iy) * a.W + ix) * a.Cin + ld_cc * BK + 4 * aseg[i]) * 4u : OOB;
+        }
+        if constexpr (!WT) {
+#pragma unroll
+            for (int i = 0; i < 2; i++) {   // wave w fills k rows 2w, 2w+1 (+16 i): lane -> k row = lane >> 5, 4 columns at 4 * (lane & 31)
+                const int cik = ld_cc * BK + wave * 2 + (lane >> 5) + 16 * i;
+                const int co = n0 + 4 * (lane & 31);
+                offB[i] = (co < a.Cout) ? (unsigned)(((ky * a.KW + kx) * a.Cin + cik) * a.Cout + co) * 4u : OOB;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; i++) {   // like A: n rows, swizzled k segments
+                const int co = n0 + wave * 8 + (lane >> 3) + 64 * i;
+                offB[i] = (co < a.Cout) ? (unsigned)((((a.KH - 1 - ky) * a.KW + (a.KW - 1 - kx)) * a.Cout + co) * a.Cin + ld_cc * BK + 4 * aseg[i]) * 4u : OOB;
+            }
+        }
+    };
+    typedef __attribute__((address_space(3))) void lds_void;
+    auto dma_chunk = [&](int stage) {       // 4 wave instructions: 2 KiB of A, 2 KiB of B for this wave
+        if (fresh | (ld_cc == 0)) decode_tap();
+        fresh = false;
+        float* A = As + stage * A_STAGE + wave * 8 * BK;
+        float* B = Bs + stage * B_STAGE + (WT ? wave * 8 * BK : wave * 2 * BN);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)A, 16, offA[0], 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(A + 64 * BK), 16, offA[1], 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)B, 16, offB[0], 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(B + (WT ? 64 * BK : 16 * BN)), 16, offB[1], 0, 0, 0);
+        offA[0] += 128u; offA[1] += 128u; offB[0] += stepB; offB[1] += stepB;
+        ++ld_cc;
+        const int w1 = (ld_cc == a.cpt) ? 1 : 0;
+        ld_cc = w1 ? 0 : ld_cc;
+        ld_tb += w1;
+        const int w2 = (ld_tb == nkx) ? 1 : 0;
+        ld_tb = w2 ? 0 : ld_tb;
+        ld_ta += w2;
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[tm][0][r] = 0.0f;
+
+    // Fragments in quarters of the chunk (k steps 4q .. 4q+3 of this lane's half: one 16 B read per A tile, four B values, one
+    // 16 B read of the scale row), so that the reads of a chunk can straddle the barrier that precedes it:
+    //     [DMA chunk c+1] [read Q2, Q3 of c] [MFMA Q0 Q1 Q2 of c] [vmcnt(0) + barrier] [read Q0, Q1 of c+1] [MFMA Q3 of c]
+    // the 8 MFMAs of Q3 cover the LDS latency of the next chunk's first reads, and the DMA has 24 MFMA slots to land.
+    float afq[4][TM][4], bfq[4][4];
+    auto read_q = [&](int stage, int q, int ci_chunk) {
+        const float* A = As + stage * A_STAGE;
+        const float* B = Bs + stage * B_STAGE;
+        float4 sv = make_float4(1.f, 1.f, 1.f, 1.f);
+        if constexpr (SC) sv = *reinterpret_cast<const float4*>(s_tab + ci_chunk * BK + 16 * h + 4 * q);
+#pragma unroll
+        for (int tm = 0; tm < TM; tm++) {
+            const int row = wm * 64 + tm * 32 + l31;
+            const float4 v = *reinterpret_cast<const float4*>(A + row * BK + (((4 * h + q) ^ ((row >> 1) & 7)) << 2));
+            afq[q][tm][0] = SC ? v.x * sv.x : v.x; afq[q][tm][1] = SC ? v.y * sv.y : v.y;
+            afq[q][tm][2] = SC ? v.z * sv.z : v.z; afq[q][tm][3] = SC ? v.w * sv.w : v.w;
+        }
+        if constexpr (!WT) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) bfq[q][j] = B[(16 * h + 4 * q + j) * BN + wn * 32 + l31];
+        } else {
+            const int row = wn * 32 + l31;
+            const float4 v = *reinterpret_cast<const float4*>(B + row * BK + (((4 * h + q) ^ ((row >> 1) & 7)) << 2));
+            bfq[q][0] = v.x; bfq[q][1] = v.y; bfq[q][2] = v.z; bfq[q][3] = v.w;
+        }
+    };
+    auto mma_q = [&](int q) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int tm = 0; tm < TM; tm++)
+                acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(afq[q][tm][j], bfq[q][j], acc[tm][0], 0, 0, 0);
+    };
+    auto next_ci = [&](int ci) { return (ci + 1 == a.cpt) ? 0 : ci + 1; };
+
+    if (c_begin < c_end) dma_chunk(0);
+    __syncthreads();                         // vmcnt(0): chunk c_begin has landed; the scale row and row tables are visible
+    int sc_ci = c_begin - (c_begin / a.cpt) * a.cpt;   // channel chunk (within the tap) of the chunk being computed
+    read_q(0, 0, sc_ci);
+    read_q(0, 1, sc_ci);
+    for (int c = c_begin; c < c_end; c++) {
+        const int cur = (c - c_begin) & 1;
+        dma_chunk(cur ^ 1);                  // chunk c+1 (past the end: out-of-range or harmless, lands in the idle stage)
+        __builtin_amdgcn_sched_barrier(0);
+        read_q(cur, 2, sc_ci);
+        read_q(cur, 3, sc_ci);
+        mma_q(0);
+        mma_q(1);
+        mma_q(2);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                     // vmcnt(0) lgkmcnt(0) + barrier: chunk c+1 landed, everyone done reading stage `cur`
+        __builtin_amdgcn_sched_barrier(0);
+        sc_ci = next_ci(sc_ci);
+        read_q(cur ^ 1, 0, sc_ci);
+        read_q(cur ^ 1, 1, sc_ci);
+        mma_q(3);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- epilogue (as conv_fwd_kernel) ----
+    if (sliced && nsplit > 1) {
+        float* wst = a.y + ((size_t)(tile - a.full_tiles) * a.splits + split) * (BM * BN);
+#pragma unroll
+        for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                wst[row * BN + wn * 32 + l31] = acc[tm][0][r];
+            }
+        return;
+    }
+    float* out = a.out;
+    const bool scale = a.out_scale != nullptr;
+    const float alpha = a.alpha;
+    const int co = n0 + wn * 32 + l31;
+    const bool in = co < a.Cout;
+    const int n_first = row_n[0], n_last = row_n[min(BM, Mcls - m0) - 1];
+    const bool one_sample = n_first == n_last;
+    const float mul = (scale && one_sample && in) ? a.out_scale[n_first * a.Cout + co] : 1.0f;
+    const float bia = (a.act && a.bias && in) ? a.bias[co] : 0.0f;
+    const bool row_scale = scale && !one_sample;
+#pragma unroll
+    for (int tm = 0; tm < TM; tm++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int pix = row_pix[row];
+            if (pix < 0 || !in) continue;
+            float v = acc[tm][0][r] * alpha;
+            if (scale && one_sample) v *= mul;
+            if (row_scale) v *= a.out_scale[row_n[row] * a.Cout + co];
+            if (a.act) v = epi_act(a.act, v + bia, a.act_alpha) * a.act_gain;
+            out[(size_t)pix * a.Cout + co] = v;
+        }
+    }
 }
 
 // Fix-up of the sliced tail tiles: y[tile] = alpha * out_scale * sum_slices ws[tile][slice]  (fixed order).
@@ -1162,8 +1452,32 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
     dim3 grid(a.full_tiles + (l.T - a.full_tiles) * splits);
     const bool wt = p->w_transposed != 0;
     const bool vec = a.vecA && a.vecB && (a.in_scale == nullptr || a.vecS);
+    bool launched = false;
+    {   // LDS-DMA form of the 128x128 tile (IGAN_CONV_DMA=0 keeps the register-staged kernel: A/B runs)
+        static const bool dma = !(getenv("IGAN_CONV_DMA") && atoi(getenv("IGAN_CONV_DMA")) == 0);
+        bool one_sample_tiles = true;
+        if (a.in_scale) {
+            const int up_ = p->up;
+            for (int c = 0; c < up_ * up_; c++) {
+                const int qh = (p->OH - c / up_ + up_ - 1) / up_, qw = (p->OW - c % up_ + up_ - 1) / up_;
+                if (qh > 0 && qw > 0 && (qh * qw) % 128 != 0) one_sample_tiles = false;
+            }
+            if (p->Cin > 512) one_sample_tiles = false;
+        }
+        if (dma && t.BM == 128 && t.BN == 128 && a.walk && one_sample_tiles && eight_waves("IGAN_CONV_8WAVE")) {
+            if (wt) {
+                if (a.in_scale) hipLaunchKernelGGL((conv_fwd_dma_kernel<true, true>), grid, dim3(512), 0, stream, a);
+                else hipLaunchKernelGGL((conv_fwd_dma_kernel<true, false>), grid, dim3(512), 0, stream, a);
+            } else {
+                if (a.in_scale) hipLaunchKernelGGL((conv_fwd_dma_kernel<false, true>), grid, dim3(512), 0, stream, a);
+                else hipLaunchKernelGGL((conv_fwd_dma_kernel<false, false>), grid, dim3(512), 0, stream, a);
+            }
+            launched = true;
+        }
+    }
     static const bool sixteen = getenv("IGAN_CONV_16WAVE") && atoi(getenv("IGAN_CONV_16WAVE")) == 1;     // experiment
-    if (t.BM == 128 && t.BN == 128 && sixteen) launch_fwd<128, 128, 4, 4>(stream, a, grid, wt, vec);
+    if (launched) {}
+    else if (t.BM == 128 && t.BN == 128 && sixteen) launch_fwd<128, 128, 4, 4>(stream, a, grid, wt, vec);
     else if (t.BM == 128 && t.BN == 128 && eight_waves("IGAN_CONV_8WAVE")) launch_fwd<128, 128, 2, 4>(stream, a, grid, wt, vec);
     else if (t.BM == 128 && t.BN == 128) launch_fwd<128, 128, 2, 2>(stream, a, grid, wt, vec);
     else if (t.BM == 128 && t.BN == 64 && eight_waves("IGAN_CONV_8WAVE")) launch_fwd<128, 64, 4, 2>(stream, a, grid, wt, vec);

@@ -17,7 +17,8 @@ from inclusivegan_amd import _abi, hip_ops  # noqa: E402
 
 
 def main():
-    batches = [int(a) for a in sys.argv[1:]] or [2, 4, 6, 12]
+    loop_stamps = '--loop' in sys.argv          # library built with -DIGAN_LOOP_STAMPS: per-wave phase cycles inside the main loop
+    batches = [int(a) for a in sys.argv[1:] if a != '--loop'] or [2, 4, 6, 12]
     dev = torch.device('cuda', 0)
     lib = _abi.get_plugin()
     g = hip_ops.ConvGeom(3, 3, 1, 1, 1, 1)
@@ -34,12 +35,13 @@ def main():
                 fn()
             torch.cuda.synchronize()
         tiles = B * 128 * 128 // 128
-        diag = torch.zeros(tiles * 4, device=dev, dtype=torch.int64)
+        diag = torch.zeros(tiles * 4 + (tiles * 32 if loop_stamps else 0), device=dev, dtype=torch.int64)
         lib.igan_debug_set_conv_diag(ctypes.c_void_p(diag.data_ptr()))
         fn()
         torch.cuda.synchronize()
         lib.igan_debug_set_conv_diag(ctypes.c_void_p(0))
-        t = diag.cpu().numpy().reshape(tiles, 4).astype(np.float64) * 0.01      # us
+        raw = diag.cpu().numpy()
+        t = raw[:tiles * 4].reshape(tiles, 4).astype(np.float64) * 0.01      # us
         t0 = t[:, 0].min()
         span = t[:, 3].max() - t0
         pro, loop, epi = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2]
@@ -53,6 +55,13 @@ def main():
         edges = np.linspace(t0, t0 + span, 21)
         active = [int(((t[:, 1] <= e) & (t[:, 2] > e)).sum()) for e in edges]
         print('   workgroups inside the main loop at 5 %% steps of the span:', active)
+        if loop_stamps:
+            ph = raw[tiles * 4:].reshape(tiles, 8, 4).astype(np.float64) / 36.0      # cycles per chunk
+            med = np.median(ph.reshape(-1, 4), axis=0)
+            print('   per wave and chunk (shader cycles, median over all waves): first MFMA half %.0f | stage -> LDS (incl. wait for the global loads) %.0f | second MFMA half %.0f | barrier %.0f | total %.0f (ideal: 2 waves x 32 MFMAs x 64 = 4096)' % (med[0], med[1], med[2], med[3], med.sum()))
+            w = np.median(ph, axis=0)
+            for wv in range(8):
+                print('      wave %d: %6.0f %6.0f %6.0f %6.0f' % (wv, w[wv, 0], w[wv, 1], w[wv, 2], w[wv, 3]))
         first_round = np.sort(t[:, 0] - t0)[:512]
         print('   start of the first %d workgroups spans %.1f us' % (len(first_round), first_round.max()))
 
