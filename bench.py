@@ -158,7 +158,7 @@ def step_roofline(stamp, steps, shapes_file=None):
     agg = {}
     for i, (name, flops, us) in enumerate(totals):
         n = replays.get(i, 0)
-        if n == 0 or us <= 0 or not name.startswith('conv_fwd_kernel'):
+        if n == 0 or us <= 0 or not name.startswith('conv_fwd'):
             continue        # the roofline entry is about the forward-type MFMA kernel (conv, data gradients); others stay in conv_family_tflops
         a = agg.setdefault(name, [0, 0.0, 0.0])
         a[0] += n

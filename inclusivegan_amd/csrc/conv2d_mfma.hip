@@ -606,13 +606,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 8 : ((WM * WN == 8)
 //    (ds_read_b128, 16 lanes per LDS cycle) conflict-free; B [32 k][128 n] needs no swizzle (ds_read_b32 rows).
 //  * Out-of-range lanes (padding taps, ragged rows) use an out-of-range buffer offset: the DMA writes zeros for them.
 //  * The modulation scale is applied to the A fragments after the LDS read (the products x*s are the same single roundings as
-//    in the staged kernel); the scale row of the tile's sample sits in LDS.  Dispatch therefore needs every tile inside ONE
-//    sample (H*W of the class a multiple of 128) when a scale is present, and 16 B paths with Cin % 32 == 0 (`walk`).
+//    in the staged kernel); the scale rows of the samples the tile touches sit in LDS (at most 2048 floats: the host checks),
+//    and 16 B paths with Cin % 32 == 0 (`walk`) are required.
 template <bool WT, bool SC>
 __global__ __launch_bounds__(512, 4) void conv_fwd_dma_kernel(ConvArgs a) {
     constexpr int BM = 128, BN = 128, WN = 4, TM = 2, TN = 1;
     constexpr int A_STAGE = BM * BK, B_STAGE = BK * BN;          // floats per stage (16 KiB each)
-    constexpr int SMAX = 512;                                    // scale row (Cin <= 512 with a scale; checked by the host)
+    constexpr int SMAX = 2048;                                   // scale rows of the tile's samples: (samples per tile) * Cin <= SMAX, checked by the host
     // one LDS object: [A0 A1 B0 B1 | scale row | row_pix row_n]
     __shared__ __attribute__((aligned(1024))) float smem[2 * A_STAGE + 2 * B_STAGE + SMAX + 2 * BM];
     float* As = smem;
@@ -665,9 +665,11 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_dma_kernel(ConvArgs a) {
         row_pix[tid] = pix;
         row_n[tid] = nn;
     }
-    if constexpr (SC) {   // the tile's sample (one per tile by dispatch): its scale row
-        const int nn = m0 / (QH * QW);
-        for (int i = tid; i < a.Cin; i += 512) s_tab[i] = a.in_scale[nn * a.Cin + i];
+    const int n_lo = m0 / (QH * QW);                 // first sample of the tile
+    if constexpr (SC) {   // scale rows of the samples this tile touches (consecutive; their number is bounded by the host)
+        const int n_hi = (min(m0 + BM, Mcls) - 1) / (QH * QW);
+        const int cnt = (n_hi - n_lo + 1) * a.Cin;
+        for (int i = tid; i < cnt; i += 512) s_tab[i] = a.in_scale[n_lo * a.Cin + i];
     }
 
     // ---- DMA lane geometry.  A (and transposed B): wave w fills rows [8w, 8w+8) and [64 + 8w, ...): lane -> row = lane >> 3,
@@ -753,14 +755,20 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_dma_kernel(ConvArgs a) {
     //     [DMA chunk c+1] [read Q2, Q3 of c] [MFMA Q0 Q1 Q2 of c] [vmcnt(0) + barrier] [read Q0, Q1 of c+1] [MFMA Q3 of c]
     // the 8 MFMAs of Q3 cover the LDS latency of the next chunk's first reads, and the DMA has 24 MFMA slots to land.
     float afq[4][TM][4], bfq[4][4];
+    int srow[TM];        // offset of this lane's rows' scale rows in s_tab (rows of one tile can belong to different samples)
+#pragma unroll
+    for (int tm = 0; tm < TM; tm++) {
+        const int m = min(m0 + wm * 64 + tm * 32 + l31, Mcls - 1);
+        srow[tm] = SC ? (m / (QH * QW) - n_lo) * a.Cin + 16 * h : 0;
+    }
     auto read_q = [&](int stage, int q, int ci_chunk) {
         const float* A = As + stage * A_STAGE;
         const float* B = Bs + stage * B_STAGE;
-        float4 sv = make_float4(1.f, 1.f, 1.f, 1.f);
-        if constexpr (SC) sv = *reinterpret_cast<const float4*>(s_tab + ci_chunk * BK + 16 * h + 4 * q);
 #pragma unroll
         for (int tm = 0; tm < TM; tm++) {
             const int row = wm * 64 + tm * 32 + l31;
+            float4 sv = make_float4(1.f, 1.f, 1.f, 1.f);
+            if constexpr (SC) sv = *reinterpret_cast<const float4*>(s_tab + srow[tm] + ci_chunk * BK + 4 * q);
             const float4 v = *reinterpret_cast<const float4*>(A + row * BK + (((4 * h + q) ^ ((row >> 1) & 7)) << 2));
             afq[q][tm][0] = SC ? v.x * sv.x : v.x; afq[q][tm][1] = SC ? v.y * sv.y : v.y;
             afq[q][tm][2] = SC ? v.z * sv.z : v.z; afq[q][tm][3] = SC ? v.w * sv.w : v.w;
@@ -1299,6 +1307,33 @@ TileList tile_list(const igan_conv2d_params* p, const FwdTile& t, int Mmax, int 
     return l;
 }
 
+
+// Does this launch take the LDS-DMA form of the 128x128 tile (conv_fwd_dma_kernel)?  16 B paths with Cin % 32 == 0, 8-wave
+// tiles, and -- when an input scale is present -- the scale rows of the samples one tile can touch fitting its LDS table.
+bool use_dma_kernel(const igan_conv2d_params* p, const FwdTile& t, bool walk) {
+    static const bool dma = !(getenv("IGAN_CONV_DMA") && atoi(getenv("IGAN_CONV_DMA")) == 0);      // A/B switch
+    if (!dma || t.BM != 128 || t.BN != 128 || !walk || !eight_waves("IGAN_CONV_8WAVE")) return false;
+    if (p->in_scale) {      // the scale rows of all samples a tile can touch must fit the kernel's LDS table (2048 floats)
+        const int up = p->up;
+        for (int c = 0; c < up * up; c++) {
+            const int qh = (p->OH - c / up + up - 1) / up, qw = (p->OW - c % up + up - 1) / up;
+            if (qh <= 0 || qw <= 0) continue;
+            const int samples = 127 / (qh * qw) + 2;          // a 128-row tile starting anywhere inside a sample
+            if ((long long)std::min(samples, p->N) * p->Cin > 2048) return false;
+        }
+    }
+    return true;
+}
+
+bool walk_ok(const igan_conv2d_params* p) {
+    static const bool walk = !(getenv("IGAN_CONV_WALK") && atoi(getenv("IGAN_CONV_WALK")) == 0);     // A/B switch
+    const bool wt = p->w_transposed != 0;
+    const bool vecA = (p->Cin % 4 == 0) && (((uintptr_t)p->x & 15) == 0);
+    const bool vecS = (p->Cin % 4 == 0) && (((uintptr_t)p->in_scale & 15) == 0);
+    const bool vecB = ((wt ? p->Cin : p->Cout) % 4 == 0) && (((uintptr_t)p->w & 15) == 0);
+    return walk && vecA && vecB && (p->in_scale == nullptr || vecS) && (p->Cin % BK == 0);
+}
+
 }  // namespace
 
 // Diagnostic hook (tools/conv_phases.py): when set, every forward-type launch writes 4 time stamps per workgroup (entry, main
@@ -1379,6 +1414,10 @@ extern "C" int igan_conv2d_kernel_name(const igan_conv2d_params* p, char* buf, i
     const bool vecS = (p->Cin % 4 == 0) && (((uintptr_t)p->in_scale & 15) == 0);
     const bool vecB = ((wt ? p->Cin : p->Cout) % 4 == 0) && (((uintptr_t)p->w & 15) == 0);
     const bool vec = vecA && vecB && (p->in_scale == nullptr || vecS);
+    if (use_dma_kernel(p, t, walk_ok(p))) {
+        snprintf(buf, (size_t)buflen, "conv_fwd_dma_kernel<%s, %s>", wt ? "true" : "false", p->in_scale ? "true" : "false");
+        return IGAN_OK;
+    }
     int wm = 2, wn = 2;
     if (t.BM == 128 && t.BN == 128 && eight_waves("IGAN_CONV_8WAVE")) wn = 4;
     if (t.BM == 128 && t.BN == 64 && eight_waves("IGAN_CONV_8WAVE")) { wm = 4; wn = 2; }
@@ -1453,27 +1492,16 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
     const bool wt = p->w_transposed != 0;
     const bool vec = a.vecA && a.vecB && (a.in_scale == nullptr || a.vecS);
     bool launched = false;
-    {   // LDS-DMA form of the 128x128 tile (IGAN_CONV_DMA=0 keeps the register-staged kernel: A/B runs)
-        static const bool dma = !(getenv("IGAN_CONV_DMA") && atoi(getenv("IGAN_CONV_DMA")) == 0);
-        bool one_sample_tiles = true;
-        if (a.in_scale) {
-            const int up_ = p->up;
-            for (int c = 0; c < up_ * up_; c++) {
-                const int qh = (p->OH - c / up_ + up_ - 1) / up_, qw = (p->OW - c % up_ + up_ - 1) / up_;
-                if (qh > 0 && qw > 0 && (qh * qw) % 128 != 0) one_sample_tiles = false;
-            }
-            if (p->Cin > 512) one_sample_tiles = false;
+    if (use_dma_kernel(p, t, a.walk != 0)) {       // LDS-DMA form of the 128x128 tile
+        if (wt) {
+            if (a.in_scale) hipLaunchKernelGGL((conv_fwd_dma_kernel<true, true>), grid, dim3(512), 0, stream, a);
+            else hipLaunchKernelGGL((conv_fwd_dma_kernel<true, false>), grid, dim3(512), 0, stream, a);
+        } else {
+            if (a.in_scale) hipLaunchKernelGGL((conv_fwd_dma_kernel<false, true>), grid, dim3(512), 0, stream, a);
+            else hipLaunchKernelGGL((conv_fwd_dma_kernel<false, false>), grid, dim3(512), 0, stream, a);
         }
-        if (dma && t.BM == 128 && t.BN == 128 && a.walk && one_sample_tiles && eight_waves("IGAN_CONV_8WAVE")) {
-            if (wt) {
-                if (a.in_scale) hipLaunchKernelGGL((conv_fwd_dma_kernel<true, true>), grid, dim3(512), 0, stream, a);
-                else hipLaunchKernelGGL((conv_fwd_dma_kernel<true, false>), grid, dim3(512), 0, stream, a);
-            } else {
-                if (a.in_scale) hipLaunchKernelGGL((conv_fwd_dma_kernel<false, true>), grid, dim3(512), 0, stream, a);
-                else hipLaunchKernelGGL((conv_fwd_dma_kernel<false, false>), grid, dim3(512), 0, stream, a);
-            }
-            launched = true;
-        }
+        IGAN_LAUNCH_CHECK("conv2d (LDS-DMA) launch");
+        launched = true;
     }
     static const bool sixteen = getenv("IGAN_CONV_16WAVE") && atoi(getenv("IGAN_CONV_16WAVE")) == 1;     // experiment
     if (launched) {}
