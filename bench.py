@@ -224,12 +224,57 @@ def cpu_baseline(resolution, batch, lpips_weight):
                        % (iters, batch, resolution, resolution, dt))
 
 
+def knn_cpu_baseline(num_points=30000, dim=3072, num_queries=256):
+    """The nearest-neighbour stage on the host: the REFERENCE's own Prioritized-DCI library (oracle/_ref, built from
+    /root/reference/dci_code/src by oracle/Makefile) with the training-time parameters (training_loop.py:197,368,398:
+    DCI(dim, 3, 15), add(num_levels 3, field_of_view 10, prop_to_retrieve 0.002), query(k 1, field_of_view 200,
+    prop_to_retrieve 1.0)) on a bounded sample -- Stacked-MNIST-sized rows (dim 3072), 30 000 candidates -- with all host
+    cores (OpenMP).  Returns queries/s for index construction + queries; the GPU leg runs the same problem."""
+    import numpy as np
+    from oracle import dci_ref
+    if not dci_ref.available():
+        return dict(value=None, unit='queries/s', cores=0, kind='reference', sample='oracle/_ref/libdci_ref.so not built')
+    cores = os.cpu_count() or 1
+    rng = np.random.RandomState(0)
+    data = rng.uniform(-1, 1, size=(num_points, dim))
+    queries = rng.uniform(-1, 1, size=(num_queries, dim))
+    t0 = time.time()
+    d = dci_ref.DCIRef(dim, 3, 15)
+    d.add(data, num_levels=3, field_of_view=10, prop_to_retrieve=0.002)
+    t_add = time.time() - t0
+    t0 = time.time()
+    d.query(queries, num_neighbours=1, field_of_view=200, prop_to_retrieve=1.0)
+    t_q = time.time() - t0
+    d.close()
+    return dict(value=round(num_queries / t_q, 2), unit='queries/s', cores=cores, kind='reference',
+                sample='reference DCI library (dci_code/src/dci.c, OpenMP, %d threads): %d candidates x %d dims, add %.1f s, %d queries in %.1f s'
+                       % (cores, num_points, dim, t_add, num_queries, t_q), add_s=round(t_add, 2), num_points=num_points, dim=dim)
+
+
+def knn_gpu(device, num_points=30000, dim=3072, num_queries=3000):
+    """The same problem on the HIP path (exact 1-NN): queries/s, candidates resident."""
+    import torch
+    from inclusivegan_amd.dci_code.dci import DCI
+    g = torch.Generator(device='cpu').manual_seed(0)
+    data = (torch.rand(num_points, dim, generator=g) * 2 - 1).to(device)
+    q = (torch.rand(num_queries, dim, generator=g) * 2 - 1).to(device)
+    db = DCI(dim, 3, 15, device=device)
+    db.add(data)
+    db.query_device(q[:256])
+    torch.cuda.synchronize()
+    t0 = time.time()
+    db.query_device(q)
+    torch.cuda.synchronize()
+    return round(num_queries / (time.time() - t0), 1)
+
+
 def cpu_baseline_subprocess(resolution, batch, lpips_weight, timeout_s=600):
     """Runs cpu_baseline() in a child process that never touches HIP (devices hidden), with a time
     limit, so that a slow host cannot hold the benchmark hostage."""
     import subprocess
     code = ('import json,sys; sys.path.insert(0, %r); import bench; '
-            'print("CPU_BASELINE " + json.dumps(bench.cpu_baseline(%d, %d, %r)))' % (ROOT, resolution, batch, lpips_weight))
+            'b = bench.cpu_baseline(%d, %d, %r); b["knn"] = bench.knn_cpu_baseline(); '
+            'print("CPU_BASELINE " + json.dumps(b))' % (ROOT, resolution, batch, lpips_weight))
     env = dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
     try:
         r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=timeout_s, env=env)
@@ -381,6 +426,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             log('timing the CPU oracle baseline')
             out['cpu_baseline'] = cpu_baseline_subprocess(args.resolution, 2 if args.resolution >= 128 else B, args.lpips_weight)
+            knn = out['cpu_baseline'].get('knn')
+            if isinstance(knn, dict) and knn.get('value'):
+                knn['gpu_queries_per_s'] = knn_gpu(device, knn['num_points'], knn['dim'])
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()

@@ -13,8 +13,9 @@ and ignored: the search is exact, so every reference setting maps to the same (b
 answer.  Extension: `add` / `query` also accept device tensors, so candidates generated on the GPU
 never visit the host (the reference materialises a 118 GB fp64 array, training_loop.py:358).
 
-Only `num_neighbours == 1` (the default, non-exclusive IMLE assignment, training_loop.py:398) is
-built on the HIP path.
+`num_neighbours == 1` (the default, non-exclusive IMLE assignment, training_loop.py:398) runs entirely in the streaming
+HIP kernel; `num_neighbours > 1` (the exclusive variant, :382-396) screens with the same MFMA products and re-ranks a
+short list exactly with torch ops.
 """
 import numpy as np
 import torch
@@ -101,12 +102,17 @@ class DCI(object):
             raise RuntimeError('DCI.query() on an empty database')
         if num_neighbours < 0:
             num_neighbours = self.num_points
-        if num_neighbours != 1:
-            raise NotImplementedError('only num_neighbours=1 is built on the hip path (got %d)' % num_neighbours)
-        idx, dist = self.query_device(self._to_device(query, check=False))
+        num_neighbours = min(num_neighbours, self.num_points)
+        q = self._to_device(query, check=False)
+        if num_neighbours == 1:
+            idx, dist = self.query_device(q)
+            idx = idx.cpu().numpy().astype(np.int32)
+            dist = dist.cpu().numpy().astype(np.float64)
+            return [idx[i:i + 1] for i in range(idx.shape[0])], [dist[i:i + 1] for i in range(dist.shape[0])]
+        idx, dist = self.query_device_k(q, num_neighbours)
         idx = idx.cpu().numpy().astype(np.int32)
         dist = dist.cpu().numpy().astype(np.float64)
-        return [idx[i:i + 1] for i in range(idx.shape[0])], [dist[i:i + 1] for i in range(dist.shape[0])]
+        return [idx[i] for i in range(idx.shape[0])], [dist[i] for i in range(dist.shape[0])]
 
     def query_device(self, q):
         """q: device fp32 [nq, dim] -> (int64 idx [nq], fp64 Euclidean dist [nq]) on the device."""
@@ -120,6 +126,48 @@ class DCI(object):
                 hip_ops.nn1_update_raw(qs, qn, self._data[c0:c0 + self.cand_chunk], self._norms[c0:c0 + self.cand_chunk],
                                        best_d2[q0:q0 + self.query_chunk], best_idx[q0:q0 + self.query_chunk], c0)
         return unpack_best(best_d2, best_idx)
+
+    def query_device_k(self, q, k, margin=8, rerank_chunk=64):
+        """k > 1 neighbours (the exclusive IMLE assignment asks for num_samples_factor of them, training_loop.py:386):
+        (int64 idx [nq, k], fp64 Euclidean dist [nq, k]), ascending, ties to the lower index.  Screening on the fp32 MFMA
+        products keeps the k + margin best candidates per query over all candidate batches; those are then measured exactly
+        (direct differences in fp64, compute_dist of dci_code/src/util.c:62-69) and re-ranked -- the same two-step rule as the
+        1-NN kernel, with the exact pass done by torch ops (a non-default path: the reference's default is k = 1)."""
+        nq = int(q.shape[0])
+        n = self.num_points
+        keep = min(n, k + margin)
+        out_i = torch.empty((nq, k), device=self.device, dtype=torch.int64)
+        out_d = torch.empty((nq, k), device=self.device, dtype=torch.float64)
+        for q0 in range(0, nq, self.query_chunk):
+            qs = q[q0:q0 + self.query_chunk]
+            qn = hip_ops.row_sqnorm_raw(qs).double()
+            best_v = None
+            best_i = None
+            for c0 in range(0, n, self.cand_chunk):
+                cs = self._data[c0:c0 + self.cand_chunk]
+                dots = hip_ops.conv2d_raw(qs.reshape(qs.shape[0], self.dim, 1, 1), cs.reshape(1, 1, cs.shape[0], self.dim),
+                                          hip_ops.ConvGeom(1, 1, 1, 1, 0, 0), (1, 1), cs.shape[0], w_transposed=True).reshape(qs.shape[0], -1)
+                d2 = qn[:, None] + self._norms[c0:c0 + self.cand_chunk].double()[None, :] - 2.0 * dots.double()
+                d2 = torch.where(torch.isfinite(d2), d2, torch.full_like(d2, float('inf')))
+                ci = torch.arange(c0, c0 + cs.shape[0], device=self.device)[None, :].expand_as(d2)
+                if best_v is not None:
+                    d2 = torch.cat([best_v, d2], dim=1)
+                    ci = torch.cat([best_i, ci], dim=1)
+                v, j = torch.topk(d2, min(keep, d2.shape[1]), dim=1, largest=False)
+                best_v, best_i = v, torch.gather(ci, 1, j)
+            # exact fp64 distances of the survivors, re-ranked by (distance, index)
+            for r0 in range(0, qs.shape[0], rerank_chunk):
+                qq = qs[r0:r0 + rerank_chunk].double()
+                ii = best_i[r0:r0 + rerank_chunk]
+                diff = self._data[ii.reshape(-1)].double().reshape(ii.shape[0], ii.shape[1], self.dim) - qq[:, None, :]
+                e = (diff * diff).sum(dim=2)
+                e = torch.where(torch.isfinite(e), e, torch.full_like(e, float('inf')))
+                order = torch.argsort(ii, dim=1, stable=True)                       # lower index first among equal distances
+                e, ii = torch.gather(e, 1, order), torch.gather(ii, 1, order)
+                order = torch.argsort(e, dim=1, stable=True)
+                out_i[q0 + r0:q0 + r0 + qq.shape[0]] = torch.gather(ii, 1, order)[:, :k]
+                out_d[q0 + r0:q0 + r0 + qq.shape[0]] = torch.sqrt(torch.gather(e, 1, order)[:, :k])
+        return out_i, out_d
 
     def clear(self):
         self._data = None

@@ -125,8 +125,26 @@ def combine_best_(best_d2, best_idx, world):
     return best_d2, best_idx
 
 
+def exclusive_assignment(knn_idx, knn_dist):
+    """training_loop.py:382-396: walk the reals in data-set order; each takes its nearest candidate that no earlier real has
+    taken among its k nearest, or its very nearest when all k are taken.  knn_idx / knn_dist: [data_size, k] ascending."""
+    taken = set()
+    idx_out = np.empty(knn_idx.shape[0], dtype=np.int64)
+    dist_out = np.empty(knn_idx.shape[0], dtype=np.float64)
+    for i in range(knn_idx.shape[0]):
+        pick = 0
+        for j in range(knn_idx.shape[1]):
+            if int(knn_idx[i, j]) not in taken:
+                pick = j
+                break
+        idx_out[i] = knn_idx[i, pick]
+        dist_out[i] = knn_dist[i, pick]
+        taken.add(int(knn_idx[i, pick]))
+    return idx_out, dist_out
+
+
 def imle_refresh(G, training_set_rec, latent_candidates, label_candidates, data_size, minibatch_size, candidate_batch_size,
-                 drange_net, device, rank=0, world=1, query_chunk=4096, infer_minibatch=None, projector=None):
+                 drange_net, device, rank=0, world=1, query_chunk=4096, infer_minibatch=None, projector=None, exclusive_k=0):
     """IMLE assignment (:357-406, non-exclusive): every real image (dataset order, [-1,1] range, flattened CHW;
     times `projector` [C*H*W, proj_dim] when random projection is on, :377-380) gets the index of its nearest generated
     candidate and the Euclidean distance.  Candidates are generated batch by batch with G (training weights, validation
@@ -153,6 +171,7 @@ def imle_refresh(G, training_set_rec, latent_candidates, label_candidates, data_
     rnorm = hip_ops.row_sqnorm_raw(reals)
     best_d2, best_idx = hip_ops.nn1_state(data_size, device)
     nbatches = (num_cand + candidate_batch_size - 1) // candidate_batch_size
+    resident = [] if exclusive_k > 1 else None      # exclusive assignment: this rank's candidates stay on the device (59 GB for CelebA-128)
     with torch.no_grad():
         for b in range(rank, nbatches, world):
             c0 = b * candidate_batch_size
@@ -171,10 +190,37 @@ def imle_refresh(G, training_set_rec, latent_candidates, label_candidates, data_
                 raise FloatingPointError('IMLE refresh: the generator produced non-finite candidate images (batch %d)' % b)
             if projector is not None:
                 cand = hip_ops.matmul(cand, projector)                           # :365
+            if resident is not None:
+                resident.append((c0, cand))
+                continue
             cnorm = hip_ops.row_sqnorm_raw(cand)
             for q0 in range(0, data_size, query_chunk):
                 hip_ops.nn1_update_raw(reals[q0:q0 + query_chunk], rnorm[q0:q0 + query_chunk], cand, cnorm,
                                        best_d2[q0:q0 + query_chunk], best_idx[q0:q0 + query_chunk], c0)
+    if resident is not None:
+        # k nearest candidates of every real over this rank's shard, merged over the ranks, then the reference's greedy
+        # exclusive pick on the host (identical on every rank: same inputs)
+        db = DCI(pdim, device=device)
+        base = torch.cat([torch.arange(c0, c0 + c.shape[0], device=device) for c0, c in resident]) if resident else torch.zeros(0, dtype=torch.int64, device=device)
+        k = int(exclusive_k)
+        if resident:
+            db._data = torch.cat([c for _, c in resident], dim=0)
+            db._norms = hip_ops.row_sqnorm_raw(db._data)
+            li, ld = db.query_device_k(reals, min(k, db.num_points))
+            gi = base[li]
+        else:
+            gi = torch.zeros((data_size, 0), dtype=torch.int64, device=device); ld = torch.zeros((data_size, 0), dtype=torch.float64, device=device)
+        if gi.shape[1] < k:     # a shard smaller than k: pad with "no candidate"
+            pad = k - gi.shape[1]
+            gi = torch.cat([gi, torch.full((data_size, pad), 2 ** 31 - 1, dtype=torch.int64, device=device)], dim=1)
+            ld = torch.cat([ld, torch.full((data_size, pad), float('inf'), dtype=torch.float64, device=device)], dim=1)
+        if world > 1:
+            all_i = [torch.empty_like(gi) for _ in range(world)]; all_d = [torch.empty_like(ld) for _ in range(world)]
+            torch.distributed.all_gather(all_i, gi); torch.distributed.all_gather(all_d, ld)
+            gi, ld = torch.cat(all_i, dim=1), torch.cat(all_d, dim=1)
+            o = torch.argsort(gi, dim=1, stable=True); gi, ld = torch.gather(gi, 1, o), torch.gather(ld, 1, o)
+            o = torch.argsort(ld, dim=1, stable=True); gi, ld = torch.gather(gi, 1, o)[:, :k], torch.gather(ld, 1, o)[:, :k]
+        return exclusive_assignment(gi.cpu().numpy(), ld.cpu().numpy())
     combine_best_(best_d2, best_idx, world)
     idx, dist = unpack_best(best_d2, best_idx)
     return idx.cpu().numpy(), dist.cpu().numpy().astype(np.float64)
@@ -231,8 +277,6 @@ def training_loop(
     ):
 
     hooks = hooks or {}
-    if exclusive_retrieved_code:
-        raise NotImplementedError('exclusive_retrieved_code needs k-NN with k>1; only the default 1-NN path is built')
 
     # Initialize (tflib.init_tf: rnd.np_random_seed, tfutil.py:122-147).
     rank, world = _dist_info()
@@ -459,7 +503,8 @@ def training_loop(
     def search(latents, label_candidates, minibatch_size):
         t0 = time.time()
         out = imle_refresh(G, training_set_rec, latents, label_candidates, data_size, minibatch_size, candidate_batch_size,
-                           drange_net, device, rank=rank, world=world, projector=projector)
+                           drange_net, device, rank=rank, world=world, projector=projector,
+                           exclusive_k=num_samples_factor if exclusive_retrieved_code else 0)      # :382-386
         torch.cuda.synchronize()
         if 'on_refresh' in hooks:
             hooks['on_refresh'](time.time() - t0)

@@ -633,3 +633,27 @@ def test_simple_adam_class_matches_reference_arithmetic(cuda_device):
         oa.apply(wa, ga); ob.apply(wb, gb)
     assert rel_err(a.detach().reshape(-1), wa) < 2e-6 and rel_err(b.detach(), wb) < 2e-6
     assert len(opt.variables()) == 5
+
+
+def test_knn_k_neighbours_vs_oracle(cuda_device):
+    """DCI.query(num_neighbours = k > 1) (the exclusive IMLE variant asks for num_samples_factor neighbours,
+    training_loop.py:386): indices, order and fp64 distances against the brute-force oracle, including a planted near-tie
+    and an exact duplicate (lower index first), across several candidate batches."""
+    from tests.imle_cases import exact_knn
+    from inclusivegan_amd.dci_code.dci import DCI
+    rng = np.random.RandomState(3)
+    data = rng.uniform(-1, 1, size=(700, 3 * 16 * 16)).astype(np.float32)
+    q = rng.uniform(-1, 1, size=(33, data.shape[1])).astype(np.float32)
+    data[41] = q[0]; data[41, 5] += 0.25                       # very close to query 0
+    data[300] = data[41]                                       # exact duplicate: 41 must come before 300
+    data[555] = q[0]; data[555, 9] += np.float32(0.25 * (1 + 2.0 ** -12))      # near-tie behind them
+    db = DCI(data.shape[1], 3, 15, device=cuda_device)
+    db.cand_chunk = 256
+    db.add(torch.from_numpy(data).to(cuda_device))
+    k = 10
+    idx, dist = db.query(torch.from_numpy(q).to(cuda_device), num_neighbours=k, field_of_view=200, prop_to_retrieve=1.0)
+    oi, od = exact_knn(data, q, k)
+    assert len(idx) == 33 and idx[0].dtype == np.int32 and dist[0].dtype == np.float64 and idx[0].shape == (k,)
+    assert np.array_equal(np.stack(idx), oi)
+    assert np.abs(np.stack(dist) - od).max() <= 1e-12 * od.max()
+    assert list(idx[0][:3]) == [41, 300, 555]

@@ -1,28 +1,38 @@
 #!/bin/bash
 # Collects the evidence set of profiles/ on a GPU box (run through gpurun from the repo root):
-#   bench line (default flags), rocprofv3 kernel stats of the same command, per-layer conv microbenchmark,
-#   per-shape conv accounting of one iteration, and the PMC passes (MFMA busy, HBM bytes) on the headline shape.
+#   bench line (default flags), rocprofv3 kernel stats + steady-state kernel breakdown of the same command, the stamped per-shape
+#   conv table, per-layer sustained microbenchmark, single-kernel microbenchmarks, PMC passes (MFMA busy, stall mix, HBM-side
+#   traffic with / without the XCD-aware block order, upfirdn traffic), full-size IMLE refresh.
 # Everything lands in gpurun_out/prof_<tag>/; copy what should be judged into profiles/.
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=$PWD/gpurun_out/prof_$TAG
+R=$PWD
 mkdir -p $OUT
 export TMPDIR=/tmp
-python bench.py 2>$OUT/bench.err | tail -1 > $OUT/bench_n1.json
-python tools/conv_bench.py 6 10 > $OUT/conv_layers_microbench.txt 2>/dev/null
-python tools/conv_shapes.py > $OUT/conv_shapes.txt 2>/dev/null
-python tools/kernel_bench.py conv 6 20 > $OUT/kernel_bench.txt 2>/dev/null
-python tools/kernel_bench.py upfirdn 6 20 >> $OUT/kernel_bench.txt 2>/dev/null
-python tools/kernel_bench.py epilogue 6 20 >> $OUT/kernel_bench.txt 2>/dev/null
+python bench.py --conv-shapes $OUT/conv_shapes.txt 2>$OUT/bench.err | tail -1 > $OUT/bench_n1.json
+python tools/conv_layers.py 0.2 > $OUT/conv_layers.txt 2>/dev/null
+python tools/kernel_bench.py upfirdn 6 40 > $OUT/kernel_bench.txt 2>/dev/null
+python tools/kernel_bench.py epilogue 6 40 >> $OUT/kernel_bench.txt 2>/dev/null
+python tools/conv_sustain.py 1.5 2 4 6 8 12 >> $OUT/kernel_bench.txt 2>/dev/null
+python tools/conv_phases.py 2 4 6 12 > $OUT/conv_phases.txt 2>/dev/null
+tools/mfma_rate 2 > $OUT/mfma_rate.txt 2>&1
+python tools/refresh_fullsize.py > $OUT/refresh_fullsize.json 2>$OUT/refresh_fullsize.err
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb_$TAG -o bench -- python3 $OLDPWD/bench.py --no-cpu-baseline > $OUT/bench_profiled.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb_$TAG -o bench -- python3 $R/bench.py --no-cpu-baseline > $OUT/bench_profiled.log 2>&1
 cp $(find /tmp/pb_$TAG -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-trace --output-format csv -d /tmp/pmc1_$TAG -- python3 $OLDPWD/tools/kernel_bench.py conv 6 5 > /dev/null 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc2_$TAG -- python3 $OLDPWD/tools/kernel_bench.py conv 6 5 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc3_$TAG -- python3 $OLDPWD/tools/kernel_bench.py conv 6 5 > /dev/null 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc4_$TAG -- python3 $OLDPWD/tools/kernel_bench.py upfirdn 6 5 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc5_$TAG -- python3 $OLDPWD/tools/kernel_bench.py upfirdn 6 5 > /dev/null 2>&1
-cd $OLDPWD
-for i in 1 2 3; do python tools/pmc_summary.py /tmp/pmc${i}_$TAG conv_fwd_kernel; done > $OUT/pmc.txt
-for i in 4 5; do python tools/pmc_summary.py /tmp/pmc${i}_$TAG upfirdn2d; done >> $OUT/pmc.txt
+cd $R
 python tools/prof_summary.py $OUT/bench_kernel_stats.csv 45 > $OUT/bench_kernel_stats_summary.txt
-ls -la $OUT
+cd /tmp
+rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_$TAG -o kt -- python3 $R/bench.py --no-cpu-baseline --no-roofline --steps 24 > $OUT/bench_traced.log 2>&1
+cd $R
+python tools/gpu_idle.py $(find /tmp/kt_$TAG -name "*kernel_trace.csv" | head -1) 0.3 12 > $OUT/bench_steady_state.txt 2>&1
+tools/pmc_conv.sh $OUT/pmc 6 > /dev/null 2>&1
+cd /tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmcu_${c}_$TAG -- python3 $R/tools/kernel_bench.py upfirdn 6 5 > /dev/null 2>&1
+  python3 $R/tools/pmc_summary.py /tmp/pmcu_${c}_$TAG upfirdn2d > $OUT/pmc/pmc_upfirdn_$c.txt 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmcb_${c}_$TAG -- python3 $R/bench.py --no-cpu-baseline --no-roofline --steps 6 --warmup 2 > /dev/null 2>&1
+  python3 $R/tools/pmc_summary.py /tmp/pmcb_${c}_$TAG conv_fwd > $OUT/pmc/pmc_bench_$c.txt 2>&1
+done
+cd $R
+ls -la $OUT $OUT/pmc
