@@ -626,6 +626,13 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_dma_kernel(ConvArgs a) {
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
     const int up = 1 << a.up_shift;
+    auto stamp = [&](int k) {       // diagnostic only (a.diag == nullptr in every normal launch), as in conv_fwd_kernel
+        if (a.diag != nullptr && (threadIdx.x >> 6) == 0) {
+            const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+            if ((threadIdx.x & 63) == 0) a.diag[(size_t)blockIdx.x * 4 + k] = t;
+        }
+    };
+    stamp(0);
     int bid = blockIdx.x;
     if (a.xcd_remap && bid < a.full_tiles) {
         const int per_class = a.nx * a.ny;
@@ -793,6 +800,7 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_dma_kernel(ConvArgs a) {
 
     if (c_begin < c_end) dma_chunk(0);
     __syncthreads();                         // vmcnt(0): chunk c_begin has landed; the scale row and row tables are visible
+    stamp(1);
     int sc_ci = c_begin - (c_begin / a.cpt) * a.cpt;   // channel chunk (within the tap) of the chunk being computed
     read_q(0, 0, sc_ci);
     read_q(0, 1, sc_ci);
@@ -815,6 +823,7 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_dma_kernel(ConvArgs a) {
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    stamp(2);
     // ---- epilogue (as conv_fwd_kernel) ----
     if (sliced && nsplit > 1) {
         float* wst = a.y + ((size_t)(tile - a.full_tiles) * a.splits + split) * (BM * BN);
@@ -851,6 +860,7 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_dma_kernel(ConvArgs a) {
             out[(size_t)pix * a.Cout + co] = v;
         }
     }
+    stamp(3);
 }
 
 // Fix-up of the sliced tail tiles: y[tile] = alpha * out_scale * sum_slices ws[tile][slice]  (fixed order).

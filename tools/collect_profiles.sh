@@ -1,8 +1,7 @@
 #!/bin/bash
 # Collects the evidence set of profiles/ on a GPU box (run through gpurun from the repo root):
 #   bench line (default flags), rocprofv3 kernel stats + steady-state kernel breakdown of the same command, the stamped per-shape
-#   conv table, per-layer sustained microbenchmark, single-kernel microbenchmarks, PMC passes (MFMA busy, stall mix, HBM-side
-#   traffic with / without the XCD-aware block order, upfirdn traffic), full-size IMLE refresh.
+#   conv table, per-layer sustained microbenchmark, single-kernel microbenchmarks, full-size IMLE refresh.
 # Everything lands in gpurun_out/prof_<tag>/; copy what should be judged into profiles/.
 TAG=${1:-r02}
 OUT=$PWD/gpurun_out/prof_$TAG
@@ -26,13 +25,5 @@ cd /tmp
 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_$TAG -o kt -- python3 $R/bench.py --no-cpu-baseline --no-roofline --steps 24 > $OUT/bench_traced.log 2>&1
 cd $R
 python tools/gpu_idle.py $(find /tmp/kt_$TAG -name "*kernel_trace.csv" | head -1) 0.3 12 > $OUT/bench_steady_state.txt 2>&1
-tools/pmc_conv.sh $OUT/pmc 6 > /dev/null 2>&1
-cd /tmp
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmcu_${c}_$TAG -- python3 $R/tools/kernel_bench.py upfirdn 6 5 > /dev/null 2>&1
-  python3 $R/tools/pmc_summary.py /tmp/pmcu_${c}_$TAG upfirdn2d > $OUT/pmc/pmc_upfirdn_$c.txt 2>&1
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmcb_${c}_$TAG -- python3 $R/bench.py --no-cpu-baseline --no-roofline --steps 6 --warmup 2 > /dev/null 2>&1
-  python3 $R/tools/pmc_summary.py /tmp/pmcb_${c}_$TAG conv_fwd > $OUT/pmc/pmc_bench_$c.txt 2>&1
-done
-cd $R
-ls -la $OUT $OUT/pmc
+ls -la $OUT
+# counter passes: tools/collect_pmc.sh <tag> (its own gpurun call; they take as long as everything above)

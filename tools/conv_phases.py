@@ -54,7 +54,7 @@ def main():
         # concurrency profile: how many workgroups are inside their main loop over time
         edges = np.linspace(t0, t0 + span, 21)
         active = [int(((t[:, 1] <= e) & (t[:, 2] > e)).sum()) for e in edges]
-        print('   workgroups inside the main loop at 5 %% steps of the span:', active)
+        print('   workgroups inside the main loop at 5 % steps of the span:', active)
         if loop_stamps:
             ph = raw[tiles * 4:].reshape(tiles, 8, 4).astype(np.float64) / 36.0      # cycles per chunk
             med = np.median(ph.reshape(-1, 4), axis=0)

@@ -27,7 +27,8 @@ def main():
     for _ in range(2):
         run()
     torch.cuda.synchronize()
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True,
+                 experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
         run()
         torch.cuda.synchronize()
     # map: correlation of launches to python stacks via the CPU op events' stacks
@@ -44,8 +45,13 @@ def main():
                 continue
             total_glue += dur
             frame = next((f for f in (ev.stack or []) if 'inclusivegan_amd' in f and 'tfutil.py' not in f), None)
-            if frame is None:
-                frame = 'autograd engine / %s' % ev.name
+            if frame is None:       # backward (engine thread) or no Python stack: name the enclosing autograd node / Function instead
+                par, chain = ev.cpu_parent, []
+                while par is not None:
+                    if not par.name.startswith('aten::'):
+                        chain.append(par.name.replace('autograd::engine::evaluate_function: ', 'bwd of '))
+                    par = par.cpu_parent
+                frame = (chain[-1] if chain else 'top level') + '  ' + str(ev.input_shapes)[:60]
             frame = frame.replace(ROOT + '/', '')
             a = agg[(name[:44], ev.name[:30], frame[:110])]
             a[0] += 1; a[1] += dur

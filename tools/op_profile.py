@@ -31,18 +31,16 @@ def build(op, res=128, B=6):
     def run():
         if op.startswith('G'):
             D.requires_grad_(False)
-            G.zero_grad()
             loss, reg = L.G_logistic_ns_rec_interp_arb_pathreg(G, D, lp, ts, B, r1, lab, z1, r2, lab, z2, NN_rec_lpips_weight=2.5,
                                                                 phase='loss' if op == 'G_train' else 'reg')
             v = loss if op == 'G_train' else reg * 4
-            torch.autograd.backward(v.mean(), inputs=list(G.trainables.values()))
+            torch.autograd.grad(v.mean(), [p for p in G.trainables.values() if p.requires_grad], allow_unused=True)      # as Optimizer.differentiate
             D.requires_grad_(True)
         else:
             G.requires_grad_(False)
-            D.zero_grad()
             loss, reg = L.D_logistic_r1(G, D, ts, B, reals, lab2, gamma=100, phase='loss' if op == 'D_train' else 'reg')
             v = loss if op == 'D_train' else reg * 16
-            torch.autograd.backward(v.mean(), inputs=list(D.trainables.values()))
+            torch.autograd.grad(v.mean(), [p for p in D.trainables.values() if p.requires_grad], allow_unused=True)
             G.requires_grad_(True)
 
     return run
