@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 /* Bumped whenever a struct layout or a signature changes (2: fused conv epilogue fields, fp64 nearest-neighbour state). */
-#define IGAN_ABI_VERSION 2
+#define IGAN_ABI_VERSION 3
 
 typedef void* igan_stream_t; /* hipStream_t */
 
@@ -295,6 +295,25 @@ int igan_lpips_layer_fwd(igan_stream_t stream, const float* fa, const float* fb,
                          float* partial, int N, int HW, int C);
 int igan_lpips_layer_bwd(igan_stream_t stream, const float* fa, const float* fb, const float* lin,
                          const float* g, float* dfa, int N, int HW, int C);
+/* The same over a table of P sample pairs: row p compares sample ia[p] of fa with sample ib[p] of fb (NULL table =
+ * identity) -- all four distances of the G loss (rec_1/real_1, rec_2/real_2, interp/real_2, interp/real_1, loss.py:31,41) in
+ * one launch per layer.  Forward writes partial[p * partial_stride + j], j < blocks (caller picks blocks <= HW and lays the
+ * layers' columns side by side so that one row sum finishes the distance).  Backward writes (accumulate = 0) or adds
+ * (accumulate = 1) g[p] * d(distance sum)/d fa into sample ia[p] of dfa; two rows of one launch must not name the same
+ * ia[p]. */
+int igan_lpips_pairs_fwd(igan_stream_t stream, const float* fa, const float* fb, const float* lin, const int* ia,
+                         const int* ib, float* partial, int partial_stride, int blocks, int P, int HW, int C);
+int igan_lpips_pairs_bwd(igan_stream_t stream, const float* fa, const float* fb, const float* lin, const int* ia,
+                         const int* ib, const float* g, float* dfa, int accumulate, int P, int HW, int C);
+
+/* 2x2 max-pool between the VGG blocks of the LPIPS network (inside lpips.get_output_for, training/loss.py:31,41;
+ * the network pickle is absent from the reference tree: restated) on channel-minor x [N, H, W, C] -> y [N, H/2, W/2, C],
+ * and its gradient fused with the sum over the pooled map's two consumers (the map is also an LPIPS tap):
+ *     dx = dskip + route(dy to the first maximum of each window in order (0,0) (0,1) (1,0) (1,1); NaN wins)
+ * dskip may be NULL (= 0); dx may alias dskip.  H, W even, C % 4 == 0. */
+int igan_maxpool2x2_fwd(igan_stream_t stream, const float* x, float* y, int N, int H, int W, int C);
+int igan_maxpool2x2_bwd(igan_stream_t stream, const float* x, const float* dy, const float* dskip, float* dx,
+                        int N, int H, int W, int C);
 
 /* ------------------------------------------------------------------------
  * minibatch_stddev_layer statistics (networks_stylegan2.py:132-144), NHWC input

@@ -111,7 +111,7 @@ class TapsParams(ctypes.Structure):
                 ('taps', ctypes.c_int), ('n', ctypes.c_int), ('scale', ctypes.c_float)]
 
 
-ABI_VERSION = 2      # include/igan_hip.h IGAN_ABI_VERSION
+ABI_VERSION = 3      # include/igan_hip.h IGAN_ABI_VERSION
 STRUCTS = (UpFirDn2DParams, FusedBiasActParams, Conv2DParams, Conv2DWgradParams, DenseParams, DenseWgradParams, TapsParams)   # igan_struct_size ids
 
 DENSE_MAX_GROUPS = 24
@@ -150,6 +150,10 @@ SIGNATURES = {
     'igan_lpips_layer_blocks': (_I, [_I, _I]),
     'igan_lpips_layer_fwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I]),
     'igan_lpips_layer_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I]),
+    'igan_lpips_pairs_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
+    'igan_lpips_pairs_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I]),
+    'igan_maxpool2x2_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I]),
+    'igan_maxpool2x2_bwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I]),
     'igan_mbstd_workspace_floats': (_SZ, [_I, _I, _I, _I, _I]),
     'igan_mbstd_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I]),
     'igan_mbstd_bwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I]),

@@ -22,8 +22,12 @@ struct LpArgs {
     const float* fb;
     const float* lin;     // [C], already non-negative
     const float* g;       // backward: [N] upstream gradient (already divided by HW by the caller)
-    float* out;           // forward: partial [N][blocks]; backward: dfa [N,HW,C]
+    float* out;           // forward: partial [N][stride] (columns 0..blocks-1 written); backward: dfa [*,HW,C]
     int HW, C, blocks;
+    const int* ia;        // pair tables (nullable = identity): row n compares sample ia[n] of fa with sample ib[n] of fb;
+    const int* ib;        // the gradient of row n goes to sample ia[n] of dfa
+    int stride;           // forward: floats between consecutive rows of partial
+    int accumulate;       // backward: dfa += instead of dfa =
 };
 
 template <int V>   // float4 per lane per pixel: 1 (C <= 256) or 2 (C == 512)
@@ -48,6 +52,7 @@ __global__ __launch_bounds__(256) void lpips_kernel(LpArgs a) {
     const int lane_c = lane % gw;                    // float4 column (first of V)
     const int sub = lane / gw;                       // pixel within the wave step
     const int n = blockIdx.y;
+    const int na = a.ia ? a.ia[n] : n, nb = a.ib ? a.ib[n] : n;
     const int per_block = (a.HW + a.blocks - 1) / a.blocks;
     const int p0 = blockIdx.x * per_block;
     const int p1 = min(p0 + per_block, a.HW);
@@ -59,10 +64,10 @@ __global__ __launch_bounds__(256) void lpips_kernel(LpArgs a) {
     for (int pb = p0 + wave * ppw; pb < p1; pb += 4 * ppw) {   // wave-uniform trip count
         const int p = pb + sub;
         const bool ok = p < p1;                      // tail lanes still take part in the shuffles
-        const size_t pix = (size_t)n * a.HW + (ok ? p : p0);
+        const size_t pix = (size_t)na * a.HW + (ok ? p : p0);
         float4 xa[V], xb[V];
         load_px<V>(a.fa, pix, a.C, lane_c, xa);
-        load_px<V>(a.fb, pix, a.C, lane_c, xb);
+        load_px<V>(a.fb, (size_t)nb * a.HW + (ok ? p : p0), a.C, lane_c, xb);
         float sa = 0.f, sb = 0.f;
 #pragma unroll
         for (int v = 0; v < V; v++) {
@@ -98,9 +103,15 @@ __global__ __launch_bounds__(256) void lpips_kernel(LpArgs a) {
                 const float sc = gn * ia;
                 float4* o = reinterpret_cast<float4*>(a.out + pix * a.C);
 #pragma unroll
-                for (int v = 0; v < V; v++)
-                    o[lane_c + v * 64] = make_float4(sc * (q[v].x - u[v].x * dot), sc * (q[v].y - u[v].y * dot),
-                                                     sc * (q[v].z - u[v].z * dot), sc * (q[v].w - u[v].w * dot));
+                for (int v = 0; v < V; v++) {
+                    float4 r = make_float4(sc * (q[v].x - u[v].x * dot), sc * (q[v].y - u[v].y * dot),
+                                           sc * (q[v].z - u[v].z * dot), sc * (q[v].w - u[v].w * dot));
+                    if (a.accumulate) {
+                        const float4 old = o[lane_c + v * 64];
+                        r = make_float4(old.x + r.x, old.y + r.y, old.z + r.z, old.w + r.w);
+                    }
+                    o[lane_c + v * 64] = r;
+                }
             }
         }
     }
@@ -109,7 +120,7 @@ __global__ __launch_bounds__(256) void lpips_kernel(LpArgs a) {
         acc = group_sum(acc, 64);
         if (lane == 0) red[wave] = acc;
         __syncthreads();
-        if (threadIdx.x == 0) a.out[(size_t)n * a.blocks + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        if (threadIdx.x == 0) a.out[(size_t)n * a.stride + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
     }
 }
 
@@ -135,11 +146,27 @@ extern "C" int igan_lpips_layer_fwd(igan_stream_t stream_, const float* fa, cons
     IGAN_REQUIRE(fa && fb && lin && partial, "lpips_layer_fwd: null buffer");
     if (int rc = lp_check(N, HW, C)) return rc;
     IGAN_REQUIRE((((uintptr_t)fa | (uintptr_t)fb | (uintptr_t)lin) & 15) == 0, "lpips_layer_fwd: buffers must be 16-byte aligned");
-    LpArgs a{fa, fb, lin, nullptr, partial, HW, C, lp_blocks(N, HW)};
+    const int blocks = lp_blocks(N, HW);
+    LpArgs a{fa, fb, lin, nullptr, partial, HW, C, blocks, nullptr, nullptr, blocks, 0};
     dim3 grid(a.blocks, N);
     if (C == 512) hipLaunchKernelGGL((lpips_kernel<2, false>), grid, dim3(256), 0, (hipStream_t)stream_, a);
     else hipLaunchKernelGGL((lpips_kernel<1, false>), grid, dim3(256), 0, (hipStream_t)stream_, a);
     IGAN_LAUNCH_CHECK("lpips_layer_fwd launch");
+    return IGAN_OK;
+}
+
+extern "C" int igan_lpips_pairs_fwd(igan_stream_t stream_, const float* fa, const float* fb, const float* lin, const int* ia,
+                                    const int* ib, float* partial, int partial_stride, int blocks, int P, int HW, int C) {
+    using namespace igan;
+    IGAN_REQUIRE(fa && fb && lin && partial, "lpips_pairs_fwd: null buffer");
+    if (int rc = lp_check(P, HW, C)) return rc;
+    IGAN_REQUIRE(blocks >= 1 && blocks <= HW && partial_stride >= blocks, "lpips_pairs_fwd: need 1 <= blocks <= HW and partial_stride >= blocks");
+    IGAN_REQUIRE((((uintptr_t)fa | (uintptr_t)fb | (uintptr_t)lin) & 15) == 0, "lpips_pairs_fwd: buffers must be 16-byte aligned");
+    LpArgs a{fa, fb, lin, nullptr, partial, HW, C, blocks, ia, ib, partial_stride, 0};
+    dim3 grid(blocks, P);
+    if (C == 512) hipLaunchKernelGGL((lpips_kernel<2, false>), grid, dim3(256), 0, (hipStream_t)stream_, a);
+    else hipLaunchKernelGGL((lpips_kernel<1, false>), grid, dim3(256), 0, (hipStream_t)stream_, a);
+    IGAN_LAUNCH_CHECK("lpips_pairs_fwd launch");
     return IGAN_OK;
 }
 
@@ -149,10 +176,26 @@ extern "C" int igan_lpips_layer_bwd(igan_stream_t stream_, const float* fa, cons
     IGAN_REQUIRE(fa && fb && lin && g && dfa, "lpips_layer_bwd: null buffer");
     if (int rc = lp_check(N, HW, C)) return rc;
     IGAN_REQUIRE((((uintptr_t)fa | (uintptr_t)fb | (uintptr_t)lin | (uintptr_t)dfa) & 15) == 0, "lpips_layer_bwd: buffers must be 16-byte aligned");
-    LpArgs a{fa, fb, lin, g, dfa, HW, C, lp_blocks(N, HW)};
+    const int blocks = lp_blocks(N, HW);
+    LpArgs a{fa, fb, lin, g, dfa, HW, C, blocks, nullptr, nullptr, blocks, 0};
     dim3 grid(a.blocks, N);
     if (C == 512) hipLaunchKernelGGL((lpips_kernel<2, true>), grid, dim3(256), 0, (hipStream_t)stream_, a);
     else hipLaunchKernelGGL((lpips_kernel<1, true>), grid, dim3(256), 0, (hipStream_t)stream_, a);
     IGAN_LAUNCH_CHECK("lpips_layer_bwd launch");
+    return IGAN_OK;
+}
+
+extern "C" int igan_lpips_pairs_bwd(igan_stream_t stream_, const float* fa, const float* fb, const float* lin, const int* ia,
+                                    const int* ib, const float* g, float* dfa, int accumulate, int P, int HW, int C) {
+    using namespace igan;
+    IGAN_REQUIRE(fa && fb && lin && g && dfa, "lpips_pairs_bwd: null buffer");
+    if (int rc = lp_check(P, HW, C)) return rc;
+    IGAN_REQUIRE((((uintptr_t)fa | (uintptr_t)fb | (uintptr_t)lin | (uintptr_t)dfa) & 15) == 0, "lpips_pairs_bwd: buffers must be 16-byte aligned");
+    const int blocks = lp_blocks(P, HW);
+    LpArgs a{fa, fb, lin, g, dfa, HW, C, blocks, ia, ib, blocks, accumulate ? 1 : 0};
+    dim3 grid(blocks, P);
+    if (C == 512) hipLaunchKernelGGL((lpips_kernel<2, true>), grid, dim3(256), 0, (hipStream_t)stream_, a);
+    else hipLaunchKernelGGL((lpips_kernel<1, true>), grid, dim3(256), 0, (hipStream_t)stream_, a);
+    IGAN_LAUNCH_CHECK("lpips_pairs_bwd launch");
     return IGAN_OK;
 }

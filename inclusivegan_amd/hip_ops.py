@@ -65,10 +65,19 @@ def _needed(ctx, i):
     if not ctx.needs_input_grad[i]:
         return False
     try:
-        node = ctx.next_functions[i][0]
+        # next_functions has one entry per TENSOR input of forward (None / non-tensor arguments are skipped), in order
+        mask = getattr(ctx, 'input_is_tensor', None)
+        j = i if mask is None else sum(1 for m in mask[:i] if m)
+        node = ctx.next_functions[j][0]
         return node is not None and torch._C._will_engine_execute_node(node)
     except Exception:
         return True
+
+
+def _mark_inputs(ctx, *inputs):
+    """Record which forward arguments are tensors, for Functions whose tensor arguments are not a prefix of the argument list
+    (optional tensors that may be None, leading configuration arguments): `_needed` needs it to find an input's graph edge."""
+    ctx.input_is_tensor = [isinstance(t, torch.Tensor) for t in inputs]
 
 
 def nhwc(x):
@@ -290,6 +299,7 @@ class BiasActNoiseFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, b, noise, strength, act_idx, alpha, gain):
+        _mark_inputs(ctx, x, b, noise, strength, act_idx, alpha, gain)
         y = bias_act_noise_fwd_raw(x, noise, strength, b, act_idx, alpha, gain)
         ctx.save_for_backward(y, noise)
         ctx.cfg = (act_idx, alpha, gain)
@@ -994,6 +1004,7 @@ class StyleModAllFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cfg, *tensors):
+        _mark_inputs(ctx, cfg, *tensors)
         L = len(cfg)
         layers = [tensors[5 * i:5 * i + 5] for i in range(L)]
         ys = [_row_major(t[0]) for t in layers]
@@ -1153,6 +1164,116 @@ class LpipsLayerFn(torch.autograd.Function):
                 _abi.check(lib.igan_lpips_layer_bwd(_stream(), _ptr(p), _ptr(q), _ptr(lin), _ptr(g), _ptr(d), n, h * w, c))
                 outs[i] = d
         return outs[0], outs[1], None
+
+
+_pair_tables = {}
+
+
+def _lpips_pair_tables(n, device):
+    """int32 sample tables of the G loss's four LPIPS distances (see LpipsPairsFn), created once per (n, device)."""
+    key = (n, str(device))
+    if key not in _pair_tables:
+        r = np.arange(n)
+        ia = np.concatenate([np.arange(3 * n), 2 * n + r]).astype(np.int32)
+        ib = np.concatenate([np.arange(2 * n), n + r, r]).astype(np.int32)
+        _pair_tables[key] = (torch.from_numpy(ia).to(device), torch.from_numpy(ib).to(device))
+    return _pair_tables[key]
+
+
+class LpipsPairsFn(torch.autograd.Function):
+    """All LPIPS distances of the G loss (training/loss.py:31,41) in one Function, over every feature layer:
+        rows [0, 2n)  : d(f_gen[i], f_real[i])            (rec_1 vs real_1, rec_2 vs real_2)
+        rows [2n, 3n) : d(f_gen[2n + i], f_real[n + i])   (interp vs real_2)
+        rows [3n, 4n) : d(f_gen[2n + i], f_real[i])       (interp vs real_1)
+    f_gen: per layer [3n, C, H, W] (rec_1, rec_2, interp stacked on the batch axis), f_real: per layer [2n, C, H, W];
+    lins: per layer [C] = |lin| / (C * H * W) (the spatial mean folded into the weights: H * W is a power of two, so the
+    values are those of dividing afterwards).  One launch per layer (igan_lpips_pairs_fwd: sample-pair tables), the layers'
+    block sums side by side in one [4n, width] array and ONE row sum; no slices, no concatenation.  Backward: per layer one
+    launch for rows [0, 3n) writing the whole gradient w.r.t. f_gen and one for rows [3n, 4n) adding the interpolated
+    images' second contribution.   apply(*lins, *f_gen, *f_real, n, num_layers) -> [4n].  (Tensors first: _needed() indexes
+    ctx.next_functions, which counts tensor inputs only.)"""
+
+    @staticmethod
+    def forward(ctx, *args):
+        n, L = args[-2], args[-1]
+        lins, fg, fr = args[:L], args[L:2 * L], args[2 * L:3 * L]
+        lib = _abi.get_plugin()
+        fg = [nhwc(t) for t in fg]
+        fr = [nhwc(t) for t in fr]
+        lins = [t.contiguous() for t in lins]
+        _require_cuda_f32(*fg, *fr, *lins)
+        ia, ib = _lpips_pair_tables(n, fg[0].device)
+        geo = []
+        for a, b in zip(fg, fr):
+            assert a.shape[0] == 3 * n and b.shape[0] == 2 * n and a.shape[1:] == b.shape[1:]
+            c, hw = a.shape[1], a.shape[2] * a.shape[3]
+            geo.append((c, hw, lib.igan_lpips_layer_blocks(4 * n, hw)))
+        width = sum(g[2] for g in geo)
+        partial = torch.empty((4 * n, width), device=fg[0].device, dtype=torch.float32)
+        col = 0
+        st = _stream()
+        for a, b, lin, (c, hw, blocks) in zip(fg, fr, lins, geo):
+            _abi.check(lib.igan_lpips_pairs_fwd(st, _ptr(a), _ptr(b), _ptr(lin), _ptr(ia), _ptr(ib), partial.data_ptr() + 4 * col,
+                                                width, blocks, 4 * n, hw, c))
+            col += blocks
+        ctx.save_for_backward(*lins, *fg, *fr)
+        ctx.n, ctx.L, ctx.geo = n, L, geo
+        return partial.sum(dim=1)
+
+    @staticmethod
+    def backward(ctx, g):
+        if torch.is_grad_enabled():
+            raise NotImplementedError('LPIPS distance: second-order gradients are not built (the reconstruction term is first-order)')
+        n, L = ctx.n, ctx.L
+        t = ctx.saved_tensors
+        lins, fg, fr = t[:L], t[L:2 * L], t[2 * L:3 * L]
+        lib = _abi.get_plugin()
+        g = g.contiguous()
+        ia, ib = _lpips_pair_tables(n, g.device)
+        st = _stream()
+        outs = []
+        for i, (a, b, lin, (c, hw, _)) in enumerate(zip(fg, fr, lins, ctx.geo)):
+            if not _needed(ctx, L + i):
+                outs.append(None)
+                continue
+            d = torch.empty_like(a)
+            _abi.check(lib.igan_lpips_pairs_bwd(st, _ptr(a), _ptr(b), _ptr(lin), _ptr(ia), _ptr(ib), _ptr(g), _ptr(d), 0, 3 * n, hw, c))
+            _abi.check(lib.igan_lpips_pairs_bwd(st, _ptr(a), _ptr(b), _ptr(lin), ia.data_ptr() + 4 * 3 * n, ib.data_ptr() + 4 * 3 * n,
+                                                g.data_ptr() + 4 * 3 * n, _ptr(d), 1, n, hw, c))
+            outs.append(d)
+        return (None,) * L + tuple(outs) + (None,) * L + (None, None)
+
+
+class PoolTapFn(torch.autograd.Function):
+    """x -> (x, maxpool2x2(x)): a VGG feature map that is both an LPIPS tap and the input of the next block.  One Function
+    owns both consumers so that the backward is one pass, dx = d_tap + route(d_pooled) (igan_maxpool2x2_bwd), instead of a
+    pooling gradient at full resolution followed by the autograd engine's add."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = _abi.get_plugin()
+        _require_cuda_f32(x)
+        x = nhwc(x)
+        n, c, h, w = x.shape
+        y = empty_nchw(n, c, h // 2, w // 2, x)
+        _abi.check(lib.igan_maxpool2x2_fwd(_stream(), _ptr(x), _ptr(y), n, h, w, c))
+        ctx.save_for_backward(x)
+        return x.view_as(x), y
+
+    @staticmethod
+    def backward(ctx, g_tap, g_pool):
+        if torch.is_grad_enabled():
+            raise NotImplementedError('VGG max-pool: second-order gradients are not built (the reconstruction term is first-order)')
+        x, = ctx.saved_tensors
+        if g_pool is None:
+            return g_tap
+        lib = _abi.get_plugin()
+        n, c, h, w = x.shape
+        g_pool = nhwc(g_pool)
+        skip = nhwc(g_tap) if g_tap is not None else None
+        dx = torch.empty_like(x)
+        _abi.check(lib.igan_maxpool2x2_bwd(_stream(), _ptr(x), _ptr(g_pool), _ptr(skip), _ptr(dx), n, h, w, c))
+        return dx
 
 
 # ----------------------------------------------------------------------------

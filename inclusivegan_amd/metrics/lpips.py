@@ -20,6 +20,8 @@ All 13 convolutions run on the package's f32-MFMA implicit-GEMM kernel with the 
 bias+ReLU kernel behind them; images are evaluated at native resolution (no resize on the
 training path).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -53,6 +55,7 @@ def _conv_relu(x, fmaps, name):
 
 
 _const_cache = {}
+_FUSED = os.environ.get('IGAN_LPIPS_FUSED', '1') != '0'      # A/B switch: pair-table distances + pool/tap Function
 
 
 def _consts(dev):
@@ -73,26 +76,62 @@ def vgg_features(images):
     x = x.contiguous(memory_format=torch.channels_last) if x.device.type != 'meta' else x
     feats = []
     for bi, (block, chans) in enumerate(_VGG_CFG):
-        if bi > 0:
-            x = torch.nn.functional.max_pool2d(x, 2)
         for li, c in enumerate(chans):
             x = _conv_relu(x, c, '%s_%d' % (block, li + 1))
-        feats.append(x)
+        if bi + 1 == len(_VGG_CFG):
+            feats.append(x)
+        elif x.is_cuda and int(x.shape[2]) % 2 == 0 and int(x.shape[3]) % 2 == 0 and _FUSED:
+            tap, x = hip_ops.PoolTapFn.apply(x)       # the tap and the 2x2 max-pool that feeds the next block: one backward pass
+            feats.append(tap)
+        else:                                         # template (meta) pass
+            feats.append(x)
+            x = torch.nn.functional.max_pool2d(x, 2)
     return feats
+
+
+def _lin_weights(i, c, hw):
+    """|lin_i| / (C * H * W): the non-negative 1x1 weights of layer i with the spatial mean folded in (H * W is a power of two on
+    this path, so the result equals dividing the distance afterwards).  Constant: computed once per variable version (kept on
+    the variable), never inside a stream capture."""
+    lin = get_variable('lin%d/weight' % i, shape=[c], initializer=('normal', 1.0), trainable=False)     # seeded |N(0,1)|/c
+    if lin.device.type == 'meta':
+        return lin
+    cache = getattr(lin, '_igan_lin_weights', None)
+    if cache is None or cache[0] != lin._version:
+        cache = (lin._version, {})
+        lin._igan_lin_weights = cache
+    hit = cache[1].get(hw)
+    if hit is None:
+        with torch.no_grad():
+            hit = torch.abs(lin) / c / float(hw)
+        if not (lin.is_cuda and torch.cuda.is_current_stream_capturing()):
+            cache[1][hw] = hit
+    return hit
 
 
 def feature_distance(feats_a, feats_b):
     """sum_layers mean_hw sum_c lin_c (fa - fb)^2  -> [N]."""
     total = None
     for i, (fa, fb) in enumerate(zip(feats_a, feats_b)):
-        c = int(fa.shape[1])
-        # seeded non-negative lin weights |N(0,1)|/c, stored as a constant
-        lin = get_variable('lin%d/weight' % i, shape=[c], initializer=('normal', 1.0), trainable=False)
-        lin = torch.abs(lin) / c
         # normalise over channels, squared difference, lin weighting, spatial mean: one fused pass
-        d = hip_ops.LpipsLayerFn.apply(fa, fb, lin) / float(fa.shape[2] * fa.shape[3])
+        d = hip_ops.LpipsLayerFn.apply(fa, fb, _lin_weights(i, int(fa.shape[1]), int(fa.shape[2] * fa.shape[3])))
         total = d if total is None else total + d
     return total
+
+
+def pair_distances(feats_gen, feats_real, n):
+    """The four distances of the G loss on features of [rec_1, rec_2, interp] (3n images) and [real_1, real_2] (2n):
+    -> (d(rec_1, real_1) [n], d(rec_2, real_2) [n], d(interp, real_2) [n], d(interp, real_1) [n])  (loss.py:31,41)."""
+    L = len(feats_gen)
+    lins = [_lin_weights(i, int(f.shape[1]), int(f.shape[2] * f.shape[3])) for i, f in enumerate(feats_gen)]
+    if feats_gen[0].device.type == 'meta':
+        return tuple(torch.empty((n,), device='meta') for _ in range(4))
+    if not _FUSED:      # A/B switch: the per-pair form on batch slices
+        r1 = [f[:n] for f in feats_real]; r2 = [f[n:] for f in feats_real]
+        g1 = [f[:n] for f in feats_gen]; g2 = [f[n:2 * n] for f in feats_gen]; gi = [f[2 * n:] for f in feats_gen]
+        return (feature_distance(g1, r1), feature_distance(g2, r2), feature_distance(gi, r2), feature_distance(gi, r1))
+    d = hip_ops.LpipsPairsFn.apply(*lins, *feats_gen, *feats_real, n, L)
+    return d.view(4, n).unbind(0)
 
 
 def vgg16_zhang_perceptual(images_a, images_b, resolution=64, **_kwargs):
@@ -110,3 +149,8 @@ def features_of(lpips_net, images):
 def distance_of(lpips_net, feats_a, feats_b):
     with tfutil.variable_store(lpips_net):
         return feature_distance(feats_a, feats_b)
+
+
+def pair_distances_of(lpips_net, feats_gen, feats_real, n):
+    with tfutil.variable_store(lpips_net):
+        return pair_distances(feats_gen, feats_real, n)

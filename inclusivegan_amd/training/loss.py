@@ -62,15 +62,15 @@ def _G_loss_impl(G, D, lpips, training_set, minibatch_size, reals_rec_1, labels_
             with torch.no_grad():
                 f_real = lpips_mod.features_of(lpips, reals_255)
             f_gen = lpips_mod.features_of(lpips, gen_255)
-            f_real_1 = [f[:n] for f in f_real]; f_real_2 = [f[n:] for f in f_real]
-            f_rec_1 = [f[:n] for f in f_gen]; f_rec_2 = [f[n:2 * n] for f in f_gen]; f_interp = [f[2 * n:] for f in f_gen]
+            # the four distances (rec_1/real_1, rec_2/real_2 :31; interp/real_2, interp/real_1 :41) in one pass over the features
+            d_rec_1, d_rec_2, d_interp_2, d_interp_1 = lpips_mod.pair_distances_of(lpips, f_gen, f_real, n)
 
-            loss_NN_rec_lpips = (lpips_mod.distance_of(lpips, f_rec_1, f_real_1) + lpips_mod.distance_of(lpips, f_rec_2, f_real_2)) * 0.5   # :31
+            loss_NN_rec_lpips = (d_rec_1 + d_rec_2) * 0.5   # :31
             loss_NN_rec_lpips = loss_NN_rec_lpips * NN_rec_lpips_weight
             loss_NN_rec_lpips = autosummary('Loss/loss_NN_rec_lpips', loss_NN_rec_lpips)
             loss = loss_addup(loss, loss_NN_rec_lpips)
 
-            loss_NN_interp_lpips = tflib.lerp(lpips_mod.distance_of(lpips, f_interp, f_real_2), lpips_mod.distance_of(lpips, f_interp, f_real_1), interp_factors.squeeze(1))   # :41
+            loss_NN_interp_lpips = tflib.lerp(d_interp_2, d_interp_1, interp_factors.squeeze(1))   # :41
             loss_NN_interp_lpips = loss_NN_interp_lpips * (NN_rec_lpips_weight * 0.4)
             loss_NN_interp_lpips = autosummary('Loss/loss_NN_interp_lpips', loss_NN_interp_lpips)
             loss = loss_addup(loss, loss_NN_interp_lpips)

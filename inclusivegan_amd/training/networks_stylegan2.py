@@ -540,12 +540,21 @@ def D_stylegan2_feature(
         t = x
         with variable_scope('Conv0'):
             x = conv2d_bias_act_layer(x, fmaps=nf(res-1), kernel=3, act=act)
+        if architecture == 'resnet':
+            # (x + t) * (1 / sqrt(2))  (:452-455) with the factor carried by the two branches' own multipliers -- the
+            # activation gain of Conv1_down and the equalised-LR coefficient of Skip (a FIR tap scale) -- so that neither the
+            # forward nor the backward spends a pass over the activations on it.
+            from ..dnnlib.tflib.ops.fused_bias_act import activation_funcs
+            c = 1 / np.sqrt(2)
+            with variable_scope('Conv1_down'):
+                x = conv2d_bias_act_layer(x, fmaps=nf(res-2), kernel=3, down=True, resample_kernel=resample_kernel, act=act,
+                                          gain=float(activation_funcs[act].def_gain * c))
+            with variable_scope('Skip'):
+                t = conv2d_layer(t, fmaps=nf(res-2), kernel=1, down=True, resample_kernel=resample_kernel, gain=c)
+                x = x + t
+            return x
         with variable_scope('Conv1_down'):
             x = conv2d_bias_act_layer(x, fmaps=nf(res-2), kernel=3, down=True, resample_kernel=resample_kernel, act=act)
-        if architecture == 'resnet':
-            with variable_scope('Skip'):
-                t = conv2d_layer(t, fmaps=nf(res-2), kernel=1, down=True, resample_kernel=resample_kernel)
-                x = (x + t) * (1 / np.sqrt(2))
         return x
     def downsample(y):
         with variable_scope('Downsample'):

@@ -539,6 +539,62 @@ def test_lpips_layer_distance(shape, cuda_device):
     assert torch.equal(gag2, gag)
 
 
+def test_lpips_pair_table_matches_layer_function(cuda_device):
+    """The G loss's four distances in one Function (sample-pair tables, all layers, one row sum) against the per-pair
+    LpipsLayerFn on batch slices -- which test_lpips_layer_distance pins to the oracle -- forward and the gradient w.r.t. the
+    generated features (the interpolated images get two contributions)."""
+    from inclusivegan_amd import hip_ops
+    n = 3
+    rng = np.random.RandomState(5)
+    shapes = [(64, 16, 16), (128, 8, 8), (512, 4, 4)]
+    fg = [to_nhwc_cuda(torch.from_numpy(np.maximum(rng.randn(3 * n, *sh), 0).astype(np.float32)), cuda_device).requires_grad_(True) for sh in shapes]
+    fr = [to_nhwc_cuda(torch.from_numpy(np.maximum(rng.randn(2 * n, *sh) + 0.2, 0).astype(np.float32)), cuda_device) for sh in shapes]
+    lins = [torch.from_numpy((np.abs(rng.randn(sh[0])) / sh[0] / (sh[1] * sh[2])).astype(np.float32)).to(cuda_device) for sh in shapes]
+    g = torch.from_numpy(rng.randn(4 * n).astype(np.float32)).to(cuda_device)
+    d = hip_ops.LpipsPairsFn.apply(*lins, *fg, *fr, n, len(shapes))
+    grads = torch.autograd.grad(d, fg, g)
+    ref = torch.zeros(4 * n, device=cuda_device)
+    fg2 = [t.detach().clone().requires_grad_(True) for t in fg]
+    for a, b, lin in zip(fg2, fr, lins):
+        ref = ref + torch.cat([hip_ops.LpipsLayerFn.apply(a[:2 * n], b, lin), hip_ops.LpipsLayerFn.apply(a[2 * n:], b[n:], lin),
+                               hip_ops.LpipsLayerFn.apply(a[2 * n:], b[:n], lin)])
+    grads2 = torch.autograd.grad(ref, fg2, g)
+    assert rel_err(d, ref) < 1e-6
+    for ga, gb in zip(grads, grads2):
+        assert rel_err(ga, gb) < 1e-6
+    # reals are constants: no gradient is produced for them, and a layer whose features need none is skipped
+    assert all(not t.requires_grad for t in fr)
+
+
+@pytest.mark.parametrize('shape', [(3, 64, 16, 16), (2, 128, 6, 10), (1, 512, 2, 2)])
+def test_maxpool_tap_matches_oracle(shape, cuda_device):
+    """x -> (tap, 2x2 max-pool) and the fused gradient d_tap + route(d_pool) against the framework pooling the oracle uses
+    (oracle/lpips.py:27) on CPU, bit for bit, with the ties ReLU produces (windows of equal values, all-zero windows)."""
+    from inclusivegan_amd import hip_ops
+    N, C, H, W = shape
+    rng = np.random.RandomState(H * W)
+    x = np.maximum(rng.randn(N, C, H, W), 0).astype(np.float32)
+    x[0, :, 0:2, 0:2] = 0.0
+    x[0, 1, 0:2, 2:4] = 0.75                                    # a window of four equal positive values
+    g_tap = rng.randn(N, C, H, W).astype(np.float32)
+    g_pool = rng.randn(N, C, H // 2, W // 2).astype(np.float32)
+    xo = torch.from_numpy(x).requires_grad_(True)
+    yo = torch.nn.functional.max_pool2d(xo, 2)
+    (gxo,) = torch.autograd.grad([xo * 1.0, yo], [xo], [torch.from_numpy(g_tap), torch.from_numpy(g_pool)])
+    xg = to_nhwc_cuda(torch.from_numpy(x), cuda_device).requires_grad_(True)
+    tap, yg = hip_ops.PoolTapFn.apply(xg)
+    assert torch.equal(tap.cpu(), xo.detach()) and torch.equal(yg.cpu(), yo.detach())
+    (gxg,) = torch.autograd.grad([tap, yg], [xg], [to_nhwc_cuda(torch.from_numpy(g_tap), cuda_device), to_nhwc_cuda(torch.from_numpy(g_pool), cuda_device)])
+    assert torch.equal(gxg.cpu(), gxo)
+    # the pooled branch alone (last use of a tap without a distance), and the tap alone
+    tap, yg = hip_ops.PoolTapFn.apply(xg)
+    (g1,) = torch.autograd.grad([yg], [xg], [to_nhwc_cuda(torch.from_numpy(g_pool), cuda_device)])
+    (g1o,) = torch.autograd.grad([torch.nn.functional.max_pool2d(xo, 2)], [xo], [torch.from_numpy(g_pool)])
+    assert torch.equal(g1.cpu(), g1o)
+    with pytest.raises(ValueError):
+        hip_ops.PoolTapFn.apply(torch.zeros(1, 64, 3, 4, device=cuda_device).contiguous(memory_format=torch.channels_last))
+
+
 def test_lpips_layer_argument_errors(cuda_device):
     from inclusivegan_amd import hip_ops
     x = torch.zeros(1, 96, 4, 4, device=cuda_device).contiguous(memory_format=torch.channels_last)
