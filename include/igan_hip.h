@@ -381,6 +381,11 @@ int igan_adam_step(igan_stream_t stream, float* w, const float* g, float* m, flo
                    float* pow_state, const int* skip_flag);
 int igan_ema(igan_stream_t stream, float* dst, const float* src, int n, float beta);
 
+/* Running mean of a training scalar (role of dnnlib/tflib/autosummary.py:45-74): acc[0] += number of finite values among
+ * x[0..n), acc[1] += their sum (double accumulators that live across hipGraph replays; non-finite values are ignored, :64).
+ * One launch, fixed-order reduction. */
+int igan_summary_accumulate(igan_stream_t stream, const float* x, int n, double* acc);
+
 #ifdef __cplusplus
 }
 #endif

@@ -165,6 +165,7 @@ SIGNATURES = {
     'igan_finite_check': (_I, [_P, _P, _I, _P]),
     'igan_adam_step': (_I, [_P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _P, _P]),
     'igan_ema': (_I, [_P, _P, _P, _I, _F]),
+    'igan_summary_accumulate': (_I, [_P, _P, _I, _P]),
 }
 
 _lib = None

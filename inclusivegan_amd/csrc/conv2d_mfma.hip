@@ -40,6 +40,7 @@
 #include "igan_common.h"
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -72,6 +73,7 @@ struct ConvArgs {
     int vecY;               // 8 B output stores usable (Cout even, y / out_scale 8 B aligned)
     float alpha;            // output multiplier (applied here when splits == 1, else by the reduce kernel)
     int xcd_remap;          // XCD-aware block order (remap_xcd)
+    int b_scale;            // LDS-DMA kernel: one-sample tiles apply the modulation to the B fragments (A/B switch IGAN_CONV_BSCALE)
     int walk;               // walking address computation usable (16 B paths, Cin % 32 == 0)
     int stagger;            // start delay (64-cycle quanta) of the workgroup in the upper LDS slot (0 = none)
     unsigned long long* diag;   // diagnostic build-in: 4 time stamps (100 MHz ticks) per workgroup, or nullptr
@@ -768,17 +770,23 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_dma_kernel(ConvArgs a) {
         const int m = min(m0 + wm * 64 + tm * 32 + l31, Mcls - 1);
         srow[tm] = SC ? (m / (QH * QW) - n_lo) * a.Cin + 16 * h : 0;
     }
-    auto read_q = [&](int stage, int q, int ci_chunk) {
+    // Where the modulation multiply happens.  A tile whose 128 rows belong to ONE sample (every layer from 16x16 up) can scale the
+    // B fragments by s[k] instead of the A fragments: sum_k (x[m,k] s[k]) w[k,n] = sum_k x[m,k] (s[k] w[k,n]) -- 16 multiplies and
+    // 4 scale reads per lane and chunk instead of 32 and 8 (the B fragment is half the size of the two A fragments).  Tiles that
+    // straddle samples (8x8 and below) keep the row-wise A form.  Either way each product is one fp32 rounding before the MFMA.
+    const bool b_scaled = SC && (n_lo == (min(m0 + BM, Mcls) - 1) / (QH * QW));
+    auto read_q = [&](auto bs_tag, int stage, int q, int ci_chunk) {
+        constexpr bool BS = decltype(bs_tag)::value;
         const float* A = As + stage * A_STAGE;
         const float* B = Bs + stage * B_STAGE;
 #pragma unroll
         for (int tm = 0; tm < TM; tm++) {
             const int row = wm * 64 + tm * 32 + l31;
             float4 sv = make_float4(1.f, 1.f, 1.f, 1.f);
-            if constexpr (SC) sv = *reinterpret_cast<const float4*>(s_tab + srow[tm] + ci_chunk * BK + 4 * q);
+            if constexpr (SC && !BS) sv = *reinterpret_cast<const float4*>(s_tab + srow[tm] + ci_chunk * BK + 4 * q);
             const float4 v = *reinterpret_cast<const float4*>(A + row * BK + (((4 * h + q) ^ ((row >> 1) & 7)) << 2));
-            afq[q][tm][0] = SC ? v.x * sv.x : v.x; afq[q][tm][1] = SC ? v.y * sv.y : v.y;
-            afq[q][tm][2] = SC ? v.z * sv.z : v.z; afq[q][tm][3] = SC ? v.w * sv.w : v.w;
+            afq[q][tm][0] = (SC && !BS) ? v.x * sv.x : v.x; afq[q][tm][1] = (SC && !BS) ? v.y * sv.y : v.y;
+            afq[q][tm][2] = (SC && !BS) ? v.z * sv.z : v.z; afq[q][tm][3] = (SC && !BS) ? v.w * sv.w : v.w;
         }
         if constexpr (!WT) {
 #pragma unroll
@@ -787,6 +795,10 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_dma_kernel(ConvArgs a) {
             const int row = wn * 32 + l31;
             const float4 v = *reinterpret_cast<const float4*>(B + row * BK + (((4 * h + q) ^ ((row >> 1) & 7)) << 2));
             bfq[q][0] = v.x; bfq[q][1] = v.y; bfq[q][2] = v.z; bfq[q][3] = v.w;
+        }
+        if constexpr (SC && BS) {
+            const float4 sv = *reinterpret_cast<const float4*>(s_tab + 16 * h + ci_chunk * BK + 4 * q);
+            bfq[q][0] *= sv.x; bfq[q][1] *= sv.y; bfq[q][2] *= sv.z; bfq[q][3] *= sv.w;
         }
     };
     auto mma_q = [&](int q) {
@@ -801,27 +813,31 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_dma_kernel(ConvArgs a) {
     if (c_begin < c_end) dma_chunk(0);
     __syncthreads();                         // vmcnt(0): chunk c_begin has landed; the scale row and row tables are visible
     stamp(1);
-    int sc_ci = c_begin - (c_begin / a.cpt) * a.cpt;   // channel chunk (within the tap) of the chunk being computed
-    read_q(0, 0, sc_ci);
-    read_q(0, 1, sc_ci);
-    for (int c = c_begin; c < c_end; c++) {
-        const int cur = (c - c_begin) & 1;
-        dma_chunk(cur ^ 1);                  // chunk c+1 (past the end: out-of-range or harmless, lands in the idle stage)
-        __builtin_amdgcn_sched_barrier(0);
-        read_q(cur, 2, sc_ci);
-        read_q(cur, 3, sc_ci);
-        mma_q(0);
-        mma_q(1);
-        mma_q(2);
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();                     // vmcnt(0) lgkmcnt(0) + barrier: chunk c+1 landed, everyone done reading stage `cur`
-        __builtin_amdgcn_sched_barrier(0);
-        sc_ci = next_ci(sc_ci);
-        read_q(cur ^ 1, 0, sc_ci);
-        read_q(cur ^ 1, 1, sc_ci);
-        mma_q(3);
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    auto main_loop = [&](auto bs_tag) {
+        int sc_ci = c_begin - (c_begin / a.cpt) * a.cpt;   // channel chunk (within the tap) of the chunk being computed
+        read_q(bs_tag, 0, 0, sc_ci);
+        read_q(bs_tag, 0, 1, sc_ci);
+        for (int c = c_begin; c < c_end; c++) {
+            const int cur = (c - c_begin) & 1;
+            dma_chunk(cur ^ 1);                  // chunk c+1 (past the end: out-of-range or harmless, lands in the idle stage)
+            __builtin_amdgcn_sched_barrier(0);
+            read_q(bs_tag, cur, 2, sc_ci);
+            read_q(bs_tag, cur, 3, sc_ci);
+            mma_q(0);
+            mma_q(1);
+            mma_q(2);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();                     // vmcnt(0) lgkmcnt(0) + barrier: chunk c+1 landed, everyone done reading stage `cur`
+            __builtin_amdgcn_sched_barrier(0);
+            sc_ci = next_ci(sc_ci);
+            read_q(bs_tag, cur ^ 1, 0, sc_ci);
+            read_q(bs_tag, cur ^ 1, 1, sc_ci);
+            mma_q(3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if (SC && b_scaled && a.b_scale) main_loop(std::true_type{});
+    else main_loop(std::false_type{});
 
     stamp(2);
     // ---- epilogue (as conv_fwd_kernel) ----
@@ -1494,6 +1510,8 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
         a.diag = g_conv_diag;
         static const int stagger = getenv("IGAN_CONV_STAGGER") ? atoi(getenv("IGAN_CONV_STAGGER")) : 0;     // experiment
         a.stagger = stagger;
+        static const bool bscale = !(getenv("IGAN_CONV_BSCALE") && atoi(getenv("IGAN_CONV_BSCALE")) == 0);     // A/B switch
+        a.b_scale = bscale ? 1 : 0;
         a.walk = (walk && a.vecA && a.vecB && (a.in_scale == nullptr || a.vecS) && (p->Cin % BK == 0)) ? 1 : 0;
     }
     a.bias = p->bias; a.act = p->act; a.act_alpha = p->act_alpha; a.act_gain = p->act_gain;

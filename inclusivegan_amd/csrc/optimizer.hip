@@ -107,7 +107,40 @@ __global__ __launch_bounds__(256) void ema_kernel(float* dst, const float* src, 
 
 inline int stream_grid(int n4) { return std::max(1, std::min(igan::ceil_div(n4, 256), 256 * 8)); }
 
+// Running mean bookkeeping of a training scalar (dnnlib/tflib/autosummary.py:45-74: [count, sum] of the finite values, :64):
+// acc[0] += number of finite x[i], acc[1] += their sum, in double, one workgroup, fixed-order tree (bit-reproducible).
+__global__ __launch_bounds__(256) void summary_accumulate_kernel(const float* __restrict__ x, int n, double* __restrict__ acc) {
+    __shared__ double s_cnt[256];
+    __shared__ double s_sum[256];
+    double cnt = 0.0, sum = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float v = x[i];
+        if (isfinite(v)) { cnt += 1.0; sum += (double)v; }
+    }
+    s_cnt[threadIdx.x] = cnt;
+    s_sum[threadIdx.x] = sum;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            s_cnt[threadIdx.x] += s_cnt[threadIdx.x + w];
+            s_sum[threadIdx.x] += s_sum[threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { acc[0] += s_cnt[0]; acc[1] += s_sum[0]; }
+}
+
 }  // namespace
+
+extern "C" int igan_summary_accumulate(igan_stream_t stream_, const float* x, int n, double* acc) {
+    using namespace igan;
+    IGAN_REQUIRE(x && acc, "summary_accumulate: null buffer");
+    IGAN_REQUIRE(n >= 0, "summary_accumulate: negative size");
+    if (n == 0) return IGAN_OK;
+    hipLaunchKernelGGL(summary_accumulate_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream_, x, n, acc);
+    IGAN_LAUNCH_CHECK("summary_accumulate launch");
+    return IGAN_OK;
+}
 
 extern "C" int igan_finite_check(igan_stream_t stream_, const float* g, int n, int* flag) {
     using namespace igan;

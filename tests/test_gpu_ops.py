@@ -713,3 +713,27 @@ def test_knn_k_neighbours_vs_oracle(cuda_device):
     assert np.array_equal(np.stack(idx), oi)
     assert np.abs(np.stack(dist) - od).max() <= 1e-12 * od.max()
     assert list(idx[0][:3]) == [41, 300, 555]
+
+
+# ----------------------------------------------------------------------------- training-scalar bookkeeping
+def test_autosummary_device_accumulator(cuda_device):
+    """dnnlib/tflib/autosummary.py:45-74: [count, sum] of the finite values, accumulated across calls, mean at flush; the
+    device path (one kernel per call) against the same bookkeeping done on the host in double."""
+    from inclusivegan_amd.dnnlib.tflib import autosummary as AS
+    AS._acc.pop('Test/x', None)
+    rng = np.random.RandomState(3)
+    want_c, want_s = 0.0, 0.0
+    for n in (6, 12, 1000):
+        x = rng.randn(n).astype(np.float32)
+        x[::5] = np.nan if n == 12 else x[::5]
+        if n == 1000:
+            x[7] = np.inf
+        ok = np.isfinite(x)
+        want_c += ok.sum(); want_s += x[ok].astype(np.float64).sum()
+        t = torch.from_numpy(x).to(cuda_device)
+        assert AS.autosummary('Test/x', t) is t
+    acc = AS._acc['Test/x'].cpu().numpy()
+    assert acc[0] == want_c and abs(acc[1] - want_s) <= 1e-12 * max(1.0, abs(want_s))
+    out = AS.flush()
+    assert abs(out['Test/x'] - want_s / want_c) < 1e-12
+    assert float(AS._acc['Test/x'].abs().sum()) == 0.0

@@ -16,7 +16,7 @@ from torch.profiler import profile, ProfilerActivity  # noqa: E402
 import op_profile  # noqa: E402
 from prof_summary import short  # noqa: E402
 
-OWN = ('conv_fwd_kernel', 'conv_wgrad_kernel', 'conv_fixup', 'plain_reduce', 'upfirdn2d', 'ban_', 'fba_kernel', 'scale_dot', 'lpips_kernel',
+OWN = ('conv_fwd', 'maxpool2x2', 'conv_wgrad_kernel', 'conv_fixup', 'plain_reduce', 'upfirdn2d', 'ban_', 'fba_kernel', 'scale_dot', 'lpips_kernel',
        'mbstd', 'dense_small', 'thin_', 'adam', 'finite_check', 'ema_kernel', 'sumsq', 'bcast_mul', 'row_sqnorm', 'nn1', 'stamp', 'bias_grad')
 
 
