@@ -610,7 +610,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 8 : ((WM * WN == 8)
 //  * The modulation scale is applied to the A fragments after the LDS read (the products x*s are the same single roundings as
 //    in the staged kernel); the scale rows of the samples the tile touches sit in LDS (at most 2048 floats: the host checks),
 //    and 16 B paths with Cin % 32 == 0 (`walk`) are required.
-template <bool WT, bool SC>
+//  * SPLIT (measure-only variant behind IGAN_CONV_BF16X3=1, never the default): the fp32 fragments are split in registers into two
+//    bf16 pieces each, x = x0 + x1 with x0 = bf16(x), x1 = bf16(x - x0), and a product runs as three v_mfma_f32_32x32x16_bf16
+//    (a1 b0 + a0 b1 + a0 b0, fp32 accumulate) instead of eight v_mfma_f32_32x32x2_f32: 12 matrix instructions of 32 cycles per
+//    chunk and wave instead of 32 of 64.  Not fp32-exact (~7x the rounding error of the fp32 FMA chain); the accumulator layout,
+//    and with it the whole epilogue, is the same.  A lane's eight k values of a 16-deep step are quarters (2s, 2s+1) of its half.
+template <bool WT, bool SC, bool SPLIT = false>
 __global__ __launch_bounds__(512, 4) void conv_fwd_dma_kernel(ConvArgs a) {
     constexpr int BM = 128, BN = 128, WN = 4, TM = 2, TN = 1;
     constexpr int A_STAGE = BM * BK, B_STAGE = BK * BN;          // floats per stage (16 KiB each)
@@ -809,6 +814,28 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_dma_kernel(ConvArgs a) {
                 acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(afq[q][tm][j], bfq[q][j], acc[tm][0], 0, 0, 0);
     };
     auto next_ci = [&](int ci) { return (ci + 1 == a.cpt) ? 0 : ci + 1; };
+    typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+    auto split8 = [&](const float (&lo4)[4], const float (&hi4)[4], bf16x8& p0, bf16x8& p1) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float x = j < 4 ? lo4[j] : hi4[j - 4];
+            const __bf16 b0 = (__bf16)x;                 // v_cvt_pk_bf16_f32: round to nearest even
+            p0[j] = b0;
+            p1[j] = (__bf16)(x - (float)b0);
+        }
+    };
+    auto mma_split_step = [&](int s) {       // k step s of the chunk: quarters 2s, 2s+1
+        bf16x8 b0, b1;
+        split8(bfq[2 * s], bfq[2 * s + 1], b0, b1);
+#pragma unroll
+        for (int tm = 0; tm < TM; tm++) {
+            bf16x8 a0, a1;
+            split8(afq[2 * s][tm], afq[2 * s + 1][tm], a0, a1);
+            acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[tm][0], 0, 0, 0);      // small terms first
+            acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[tm][0], 0, 0, 0);
+            acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[tm][0], 0, 0, 0);
+        }
+    };
 
     if (c_begin < c_end) dma_chunk(0);
     __syncthreads();                         // vmcnt(0): chunk c_begin has landed; the scale row and row tables are visible
@@ -823,16 +850,26 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_dma_kernel(ConvArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             read_q(bs_tag, cur, 2, sc_ci);
             read_q(bs_tag, cur, 3, sc_ci);
-            mma_q(0);
-            mma_q(1);
-            mma_q(2);
+            if constexpr (SPLIT) {
+                mma_split_step(0);
+            } else {
+                mma_q(0);
+                mma_q(1);
+                mma_q(2);
+            }
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();                     // vmcnt(0) lgkmcnt(0) + barrier: chunk c+1 landed, everyone done reading stage `cur`
             __builtin_amdgcn_sched_barrier(0);
             sc_ci = next_ci(sc_ci);
-            read_q(bs_tag, cur ^ 1, 0, sc_ci);
-            read_q(bs_tag, cur ^ 1, 1, sc_ci);
-            mma_q(3);
+            if constexpr (SPLIT) {
+                mma_split_step(1);               // quarters 2, 3 (read before the barrier) while the next chunk's first reads land
+                read_q(bs_tag, cur ^ 1, 0, sc_ci);
+                read_q(bs_tag, cur ^ 1, 1, sc_ci);
+            } else {
+                read_q(bs_tag, cur ^ 1, 0, sc_ci);
+                read_q(bs_tag, cur ^ 1, 1, sc_ci);
+                mma_q(3);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -1441,7 +1478,9 @@ extern "C" int igan_conv2d_kernel_name(const igan_conv2d_params* p, char* buf, i
     const bool vecB = ((wt ? p->Cin : p->Cout) % 4 == 0) && (((uintptr_t)p->w & 15) == 0);
     const bool vec = vecA && vecB && (p->in_scale == nullptr || vecS);
     if (use_dma_kernel(p, t, walk_ok(p))) {
-        snprintf(buf, (size_t)buflen, "conv_fwd_dma_kernel<%s, %s>", wt ? "true" : "false", p->in_scale ? "true" : "false");
+        const bool split = getenv("IGAN_CONV_BF16X3") && atoi(getenv("IGAN_CONV_BF16X3")) != 0;
+        snprintf(buf, (size_t)buflen, split ? "conv_fwd_dma_kernel<%s, %s, true>" : "conv_fwd_dma_kernel<%s, %s>", wt ? "true" : "false",
+                 p->in_scale ? "true" : "false");
         return IGAN_OK;
     }
     int wm = 2, wn = 2;
@@ -1521,7 +1560,17 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
     const bool vec = a.vecA && a.vecB && (a.in_scale == nullptr || a.vecS);
     bool launched = false;
     if (use_dma_kernel(p, t, a.walk != 0)) {       // LDS-DMA form of the 128x128 tile
-        if (wt) {
+        // measure-only: IGAN_CONV_BF16X3=1 runs these launches on the bf16 matrix pipe with split operands (not fp32-exact)
+        static const bool split = getenv("IGAN_CONV_BF16X3") && atoi(getenv("IGAN_CONV_BF16X3")) != 0;
+        if (split) {
+            if (wt) {
+                if (a.in_scale) hipLaunchKernelGGL((conv_fwd_dma_kernel<true, true, true>), grid, dim3(512), 0, stream, a);
+                else hipLaunchKernelGGL((conv_fwd_dma_kernel<true, false, true>), grid, dim3(512), 0, stream, a);
+            } else {
+                if (a.in_scale) hipLaunchKernelGGL((conv_fwd_dma_kernel<false, true, true>), grid, dim3(512), 0, stream, a);
+                else hipLaunchKernelGGL((conv_fwd_dma_kernel<false, false, true>), grid, dim3(512), 0, stream, a);
+            }
+        } else if (wt) {
             if (a.in_scale) hipLaunchKernelGGL((conv_fwd_dma_kernel<true, true>), grid, dim3(512), 0, stream, a);
             else hipLaunchKernelGGL((conv_fwd_dma_kernel<true, false>), grid, dim3(512), 0, stream, a);
         } else {
