@@ -610,13 +610,15 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 8 : ((WM * WN == 8)
 //  * The modulation scale is applied to the A fragments after the LDS read (the products x*s are the same single roundings as
 //    in the staged kernel); the scale rows of the samples the tile touches sit in LDS (at most 2048 floats: the host checks),
 //    and 16 B paths with Cin % 32 == 0 (`walk`) are required.
-//  * SPLIT (measure-only variant behind IGAN_CONV_BF16X3=1, never the default): the fp32 fragments are split in registers into two
-//    bf16 pieces each, x = x0 + x1 with x0 = bf16(x), x1 = bf16(x - x0), and a product runs as three v_mfma_f32_32x32x16_bf16
-//    (a1 b0 + a0 b1 + a0 b0, fp32 accumulate) instead of eight v_mfma_f32_32x32x2_f32: 12 matrix instructions of 32 cycles per
-//    chunk and wave instead of 32 of 64.  Not fp32-exact (~7x the rounding error of the fp32 FMA chain); the accumulator layout,
-//    and with it the whole epilogue, is the same.  A lane's eight k values of a 16-deep step are quarters (2s, 2s+1) of its half.
-template <bool WT, bool SC, bool SPLIT = false>
+//  * PIECES = 2 / 3 (measure-only variants behind IGAN_CONV_BF16X3=1 / =6, never the default): the fp32 fragments are split in
+//    registers into bf16 pieces, x = x0 + x1 (+ x2) with x0 = bf16(x), x1 = bf16(x - x0), ..., and a product runs as the three
+//    (a1 b0 + a0 b1 + a0 b0) or six (all a_i b_j, i + j <= 2) v_mfma_f32_32x32x16_bf16 with fp32 accumulation instead of eight
+//    v_mfma_f32_32x32x2_f32: 12 / 24 matrix instructions of 32 cycles per chunk and wave instead of 32 of 64.  Not fp32-exact
+//    (two pieces: ~7x the rounding error of the fp32 FMA chain; three: about the chain's); the accumulator layout, and with it the
+//    whole epilogue, is the same.  A lane's eight k values of a 16-deep step are quarters (2s, 2s+1) of its half.
+template <bool WT, bool SC, int PIECES = 0>      // PIECES: 0 = fp32 MFMA (the product path), 2 / 3 = bf16 pieces per operand (measure-only)
 __global__ __launch_bounds__(512, 4) void conv_fwd_dma_kernel(ConvArgs a) {
+    constexpr bool SPLIT = PIECES != 0;
     constexpr int BM = 128, BN = 128, WN = 4, TM = 2, TN = 1;
     constexpr int A_STAGE = BM * BK, B_STAGE = BK * BN;          // floats per stage (16 KiB each)
     constexpr int SMAX = 2048;                                   // scale rows of the tile's samples: (samples per tile) * Cin <= SMAX, checked by the host
@@ -815,25 +817,32 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_dma_kernel(ConvArgs a) {
     };
     auto next_ci = [&](int ci) { return (ci + 1 == a.cpt) ? 0 : ci + 1; };
     typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-    auto split8 = [&](const float (&lo4)[4], const float (&hi4)[4], bf16x8& p0, bf16x8& p1) {
+    constexpr int NP = SPLIT ? PIECES : 1;
+    auto split8 = [&](const float (&lo4)[4], const float (&hi4)[4], bf16x8 (&pc)[NP]) {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            const float x = j < 4 ? lo4[j] : hi4[j - 4];
-            const __bf16 b0 = (__bf16)x;                 // v_cvt_pk_bf16_f32: round to nearest even
-            p0[j] = b0;
-            p1[j] = (__bf16)(x - (float)b0);
+            float r = j < 4 ? lo4[j] : hi4[j - 4];
+#pragma unroll
+            for (int p = 0; p < NP; p++) {
+                const __bf16 b = (__bf16)r;              // v_cvt_pk_bf16_f32: round to nearest even
+                pc[p][j] = b;
+                if (p + 1 < NP) r -= (float)b;
+            }
         }
     };
     auto mma_split_step = [&](int s) {       // k step s of the chunk: quarters 2s, 2s+1
-        bf16x8 b0, b1;
-        split8(bfq[2 * s], bfq[2 * s + 1], b0, b1);
+        bf16x8 b[NP];
+        split8(bfq[2 * s], bfq[2 * s + 1], b);
 #pragma unroll
         for (int tm = 0; tm < TM; tm++) {
-            bf16x8 a0, a1;
-            split8(afq[2 * s][tm], afq[2 * s + 1][tm], a0, a1);
-            acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[tm][0], 0, 0, 0);      // small terms first
-            acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[tm][0], 0, 0, 0);
-            acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[tm][0], 0, 0, 0);
+            bf16x8 av[NP];
+            split8(afq[2 * s][tm], afq[2 * s + 1][tm], av);
+            // all products a_i b_j with i + j < PIECES, smallest first
+#pragma unroll
+            for (int o = NP - 1; o >= 0; o--)
+#pragma unroll
+                for (int i = 0; i <= o; i++)
+                    acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], b[o - i], acc[tm][0], 0, 0, 0);
         }
     };
 
@@ -1478,9 +1487,9 @@ extern "C" int igan_conv2d_kernel_name(const igan_conv2d_params* p, char* buf, i
     const bool vecB = ((wt ? p->Cin : p->Cout) % 4 == 0) && (((uintptr_t)p->w & 15) == 0);
     const bool vec = vecA && vecB && (p->in_scale == nullptr || vecS);
     if (use_dma_kernel(p, t, walk_ok(p))) {
-        const bool split = getenv("IGAN_CONV_BF16X3") && atoi(getenv("IGAN_CONV_BF16X3")) != 0;
-        snprintf(buf, (size_t)buflen, split ? "conv_fwd_dma_kernel<%s, %s, true>" : "conv_fwd_dma_kernel<%s, %s>", wt ? "true" : "false",
-                 p->in_scale ? "true" : "false");
+        const int split = getenv("IGAN_CONV_BF16X3") ? atoi(getenv("IGAN_CONV_BF16X3")) : 0;
+        snprintf(buf, (size_t)buflen, split == 6 ? "conv_fwd_dma_kernel<%s, %s, 3>" : split ? "conv_fwd_dma_kernel<%s, %s, 2>" : "conv_fwd_dma_kernel<%s, %s>",
+                 wt ? "true" : "false", p->in_scale ? "true" : "false");
         return IGAN_OK;
     }
     int wm = 2, wn = 2;
@@ -1560,15 +1569,24 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
     const bool vec = a.vecA && a.vecB && (a.in_scale == nullptr || a.vecS);
     bool launched = false;
     if (use_dma_kernel(p, t, a.walk != 0)) {       // LDS-DMA form of the 128x128 tile
-        // measure-only: IGAN_CONV_BF16X3=1 runs these launches on the bf16 matrix pipe with split operands (not fp32-exact)
-        static const bool split = getenv("IGAN_CONV_BF16X3") && atoi(getenv("IGAN_CONV_BF16X3")) != 0;
-        if (split) {
+        // measure-only: IGAN_CONV_BF16X3=1 (two bf16 pieces per operand, three products) / IGAN_CONV_BF16X3=6 (three pieces, six
+        // products) run these launches on the bf16 matrix pipe; not fp32-exact
+        static const int split = getenv("IGAN_CONV_BF16X3") ? atoi(getenv("IGAN_CONV_BF16X3")) : 0;
+        if (split == 6) {
             if (wt) {
-                if (a.in_scale) hipLaunchKernelGGL((conv_fwd_dma_kernel<true, true, true>), grid, dim3(512), 0, stream, a);
-                else hipLaunchKernelGGL((conv_fwd_dma_kernel<true, false, true>), grid, dim3(512), 0, stream, a);
+                if (a.in_scale) hipLaunchKernelGGL((conv_fwd_dma_kernel<true, true, 3>), grid, dim3(512), 0, stream, a);
+                else hipLaunchKernelGGL((conv_fwd_dma_kernel<true, false, 3>), grid, dim3(512), 0, stream, a);
             } else {
-                if (a.in_scale) hipLaunchKernelGGL((conv_fwd_dma_kernel<false, true, true>), grid, dim3(512), 0, stream, a);
-                else hipLaunchKernelGGL((conv_fwd_dma_kernel<false, false, true>), grid, dim3(512), 0, stream, a);
+                if (a.in_scale) hipLaunchKernelGGL((conv_fwd_dma_kernel<false, true, 3>), grid, dim3(512), 0, stream, a);
+                else hipLaunchKernelGGL((conv_fwd_dma_kernel<false, false, 3>), grid, dim3(512), 0, stream, a);
+            }
+        } else if (split != 0) {
+            if (wt) {
+                if (a.in_scale) hipLaunchKernelGGL((conv_fwd_dma_kernel<true, true, 2>), grid, dim3(512), 0, stream, a);
+                else hipLaunchKernelGGL((conv_fwd_dma_kernel<true, false, 2>), grid, dim3(512), 0, stream, a);
+            } else {
+                if (a.in_scale) hipLaunchKernelGGL((conv_fwd_dma_kernel<false, true, 2>), grid, dim3(512), 0, stream, a);
+                else hipLaunchKernelGGL((conv_fwd_dma_kernel<false, false, 2>), grid, dim3(512), 0, stream, a);
             }
         } else if (wt) {
             if (a.in_scale) hipLaunchKernelGGL((conv_fwd_dma_kernel<true, true>), grid, dim3(512), 0, stream, a);
