@@ -1259,6 +1259,207 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_wgr
     }
 }
 
+// Weight-gradient kernel, LDS-DMA form (128 x 128 tile of (ci, co), 8 waves = 2 x 4 of 64 x 32, K = pixels in chunks of 32).
+//  * Both operands are pixel-major rows of channels, so a chunk is 32 rows x 512 B per operand and a DMA instruction
+//    (`buffer_load_dwordx4 ... lds`, 64 lanes x 16 B = 1 KiB) fetches two whole pixel rows of the tile straight into the unpadded
+//    [pixel][128] LDS image -- no staging registers, no ds_write; padding taps, rows past the end and channels past Cin / Cout
+//    are out-of-range offsets that land as zeros.  The fragment reads are the K-major ones of conv_wgrad_kernel (a lane's two
+//    ci tiles adjacent: ds_read_b64), conflict-free without padding (16 lanes = 128 contiguous bytes per LDS cycle).
+//  * The reduction axis is cut per SAMPLE: a sample's QH * QW pixels are padded to whole chunks (zero rows), so a chunk never
+//    straddles two samples: the modulation factors of a chunk -- s[n][ci] for a lane's two ci rows, d[n][co] for its co column --
+//    are three registers, reloaded from an LDS table when the sample changes, and multiply the fragments after the LDS read (no
+//    scale loads or scale addresses in the loop).  The scale rows of the (at most WG_SMAX) samples a block touches sit in LDS;
+//    the host checks that bound and the padding overhead (use_wgrad_dma).
+constexpr int WG_SMAX = 8;
+template <int SCM>
+__global__ __launch_bounds__(512, 4) void conv_wgrad_dma_kernel(WgradArgs a) {
+    constexpr int BM = 128, BN = 128, WN = 4, TM = 2, LD = 128;
+    constexpr int STAGE = BK * LD;                                  // floats per operand stage (16 KiB)
+    __shared__ __attribute__((aligned(1024))) float smem[4 * STAGE + (SCM ? 2 * WG_SMAX * 128 : 4)];
+    float* As = smem;
+    float* Bs = smem + 2 * STAGE;
+    float* s_tab = smem + 4 * STAGE;                                // [WG_SMAX][128] in_scale rows of this ci tile
+    float* d_tab = s_tab + WG_SMAX * 128;                           // [WG_SMAX][128] out_scale rows of this co tile
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int up = 1 << a.up_shift;
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    int tap = bz / a.splits, split = bz - tap * a.splits;
+    if (a.xcd_remap) {      // as conv_wgrad_kernel: tap fastest, so the blocks of one pixel slice share an XCD's L2
+        const int gx = gridDim.x, gy = gridDim.y, taps = a.KH * a.KW;
+        const int lin = remap_xcd(bx + gx * (by + gy * bz), gx * gy * (int)gridDim.z);
+        tap = lin % taps;
+        int rest = lin / taps;
+        bx = rest % gx; rest /= gx;
+        by = rest % gy;
+        split = rest / gy;
+    }
+    const int ky = tap / a.KW, kx = tap - ky * a.KW;
+    const int py = (a.pad_y - ky) & (up - 1);
+    const int px = (a.pad_x - kx) & (up - 1);
+    const int QH = (a.OH - py + up - 1) >> a.up_shift;
+    const int QW = (a.OW - px + up - 1) >> a.up_shift;
+    const int P = (QH > 0 && QW > 0) ? QH * QW : 0;                 // pixels per sample in this tap's parity class
+    const int cps = (P + BK - 1) / BK;                              // chunks per sample (last one zero-padded)
+    const int chunks = a.N * cps;
+    const int c_begin = (int)(((long long)split * chunks) / a.splits);
+    const int c_end = (int)(((long long)(split + 1) * chunks) / a.splits);
+    const int m0 = bx * BM, n0 = by * BN;
+    const int s_in = (up == 1) ? a.stride : 1;
+    const int cy = (up == 1) ? ky - a.pad_y : (py + ky - a.pad_y) >> 1;
+    const int cx = (up == 1) ? kx - a.pad_x : (px + kx - a.pad_x) >> 1;
+
+    // ---- DMA lane geometry: wave w fills pixel rows 2w, 2w+1 (+16 i) of the chunk; lane -> row (lane >> 5), 16 B segment lane & 31
+    const int seg = lane & 31;
+    const int ci = m0 + 4 * seg, co = n0 + 4 * seg;
+    const bool ci_ok = ci < a.Cin, co_ok = co < a.Cout;             // Cin, Cout % 4 == 0 on this path
+    const int dQW = max(QW, 1);
+    const int st_b = BK % dQW, st_a2 = BK / dQW;                    // a chunk advances a row by BK pixels = st_a2 rows + st_b columns
+    int rp[2], rqy[2], rqx[2];                                      // pixel index inside the sample, and its (qy, qx)
+    int base_qy[2], base_qx[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int r = 2 * wave + (lane >> 5) + 16 * i;
+        base_qy[i] = r / dQW; base_qx[i] = r - base_qy[i] * dQW;
+    }
+    int ld_n = (c_begin < c_end) ? c_begin / cps : 0;
+    int ld_j = (c_begin < c_end) ? c_begin - ld_n * cps : 0;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int r = 2 * wave + (lane >> 5) + 16 * i + ld_j * BK;
+        rp[i] = r; rqy[i] = r / dQW; rqx[i] = r - rqy[i] * dQW;
+    }
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, (unsigned)a.N * a.H * a.W * a.Cin * 4u);
+    const __amdgpu_buffer_rsrc_t rdy = make_rsrc(a.dy, (unsigned)a.N * a.OH * a.OW * a.Cout * 4u);
+    typedef __attribute__((address_space(3))) void lds_void;
+    auto dma_chunk = [&](int stage, bool live) {       // 4 wave instructions: 2 KiB of x rows, 2 KiB of dy rows
+        unsigned offA[2], offB[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int iy = __mul24(rqy[i], s_in) + cy, ix = __mul24(rqx[i], s_in) + cx;
+            const bool in_sample = live & (rp[i] < P);
+            const bool okA = in_sample & ci_ok & ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);
+            offA[i] = okA ? (unsigned)(((ld_n * a.H + iy) * a.W + ix) * a.Cin + ci) * 4u : OOB;
+            const int oy = __mul24(rqy[i], up) + py, ox = __mul24(rqx[i], up) + px;
+            offB[i] = (in_sample & co_ok) ? (unsigned)(((ld_n * a.OH + oy) * a.OW + ox) * a.Cout + co) * 4u : OOB;
+        }
+        float* A = As + stage * STAGE + wave * 2 * LD;
+        float* B = Bs + stage * STAGE + wave * 2 * LD;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)A, 16, offA[0], 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(A + 16 * LD), 16, offA[1], 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (lds_void*)B, 16, offB[0], 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (lds_void*)(B + 16 * LD), 16, offB[1], 0, 0, 0);
+        // walk to the next chunk: BK pixels further inside the sample, or the first chunk of the next sample
+        ++ld_j;
+        const bool wrap = ld_j == cps;
+        ld_j = wrap ? 0 : ld_j;
+        ld_n += wrap ? 1 : 0;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            int qx = rqx[i] + st_b;
+            const int c1 = (qx >= QW) ? 1 : 0;
+            qx -= c1 ? QW : 0;
+            rp[i] = wrap ? (rp[i] - (cps - 1) * BK) : rp[i] + BK;
+            rqy[i] = wrap ? base_qy[i] : rqy[i] + st_a2 + c1;
+            rqx[i] = wrap ? base_qx[i] : qx;
+        }
+    };
+
+    // ---- per-sample scale rows of this tile (SCM: an absent scale is a row of ones)
+    const int n_first = (c_begin < c_end) ? c_begin / cps : 0;
+    if constexpr (SCM != 0) {
+        const int n_last = (c_begin < c_end) ? (c_end - 1) / cps : 0;
+        const int cnt = (n_last - n_first + 1) * 128;               // <= WG_SMAX * 128: checked by the host
+        for (int i = tid; i < cnt; i += 512) {
+            const int k = i >> 7, j = i & 127;
+            s_tab[i] = (a.in_scale != nullptr && m0 + j < a.Cin) ? a.in_scale[(n_first + k) * a.Cin + m0 + j] : 1.0f;
+            d_tab[i] = (a.out_scale != nullptr && n0 + j < a.Cout) ? a.out_scale[(n_first + k) * a.Cout + n0 + j] : 1.0f;
+        }
+    }
+
+    f32x16 acc[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[tm][r] = 0.0f;
+
+    // Fragments in quarters of the chunk (k rows 16 h + 4 q .. + 3: four ds_read_b64 of the two ci tiles, four ds_read_b32 of the co
+    // tile), read so that they straddle the barrier, as in conv_fwd_dma_kernel:
+    //     [DMA chunk c+1] [read Q2, Q3 of c] [MFMA Q0 Q1 Q2 of c] [vmcnt(0) + barrier] [read Q0, Q1 of c+1] [MFMA Q3 of c]
+    // The per-sample factors of the chunk being read (this lane's two ci rows and its co column) multiply the fragments.
+    float afq[4][TM][4], bfq[4][4];
+    float sv0 = 1.0f, sv1 = 1.0f, dv = 1.0f;
+    auto load_scales = [&](int n) {
+        if constexpr (SCM != 0) {
+            const float2 v = *reinterpret_cast<const float2*>(s_tab + (n - n_first) * 128 + wm * 64 + TM * l31);
+            sv0 = v.x; sv1 = v.y;
+            dv = d_tab[(n - n_first) * 128 + wn * 32 + l31];
+        }
+    };
+    auto read_q = [&](int stage, int q) {
+        const float* A = As + stage * STAGE + wm * 64 + TM * l31;
+        const float* B = Bs + stage * STAGE + wn * 32 + l31;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int krow = 16 * h + 4 * q + j;
+            const float2 v = *reinterpret_cast<const float2*>(A + krow * LD);
+            afq[q][0][j] = SCM ? v.x * sv0 : v.x; afq[q][1][j] = SCM ? v.y * sv1 : v.y;
+            bfq[q][j] = SCM ? B[krow * LD] * dv : B[krow * LD];
+        }
+    };
+    auto mma_q = [&](int q) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int tm = 0; tm < TM; tm++)
+                acc[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(afq[q][tm][j], bfq[q][j], acc[tm], 0, 0, 0);
+    };
+
+    if (c_begin < c_end) dma_chunk(0, true);
+    __syncthreads();                    // vmcnt(0): the first chunk has landed; the scale rows are visible
+    int cur_n = n_first, cur_j = (c_begin < c_end) ? c_begin - n_first * cps : 0;
+    load_scales(cur_n);
+    read_q(0, 0);
+    read_q(0, 1);
+    for (int c = c_begin; c < c_end; c++) {
+        const int cur = (c - c_begin) & 1;
+        dma_chunk(cur ^ 1, c + 1 < c_end);
+        __builtin_amdgcn_sched_barrier(0);
+        read_q(cur, 2);
+        read_q(cur, 3);
+        mma_q(0);
+        mma_q(1);
+        mma_q(2);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                // vmcnt(0) lgkmcnt(0) + barrier: chunk c+1 landed, everyone done reading stage `cur`
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (SCM != 0) {
+            ++cur_j;
+            if (cur_j == cps) { cur_j = 0; ++cur_n; if (c + 1 < c_end) load_scales(cur_n); }
+        }
+        read_q(cur ^ 1, 0);
+        read_q(cur ^ 1, 1);
+        mma_q(3);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- epilogue (as conv_wgrad_kernel)
+    const size_t wsize = (size_t)a.KH * a.KW * a.Cin * a.Cout;
+    float* out = a.out + (a.splits > 1 ? (size_t)split * wsize : (size_t)0) + (size_t)tap * a.Cin * a.Cout;
+    const float alpha = (a.splits == 1) ? a.alpha : 1.0f;
+    const int cc = n0 + wn * 32 + l31;
+#pragma unroll
+    for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int cir = m0 + wm * 64 + tile_row<TM, true>(tm, (r & 3) + 8 * (r >> 2) + 4 * h);
+            if (cir < a.Cin && cc < a.Cout) out[(size_t)cir * a.Cout + cc] = acc[tm][r] * alpha;
+        }
+}
+
 // y[i] = alpha * sum_k ws[k][i], fixed order.  Four partial sums so that four loads are in flight per lane (a single
 // running sum is `splits` dependent L2 round trips: 256 slices took 200 us for a 1.5 KB result).
 __global__ __launch_bounds__(256) void plain_reduce_kernel(const float* ws, float* y, int total, int splits, float alpha) {
@@ -1655,6 +1856,29 @@ WgTile pick_wg_tile(int Cin, int Cout) {
     return t;
 }
 
+// Does this weight gradient take the LDS-DMA kernel?  16 B rows (Cin, Cout % 4 == 0, aligned operands), a per-sample chunk padding
+// of at most 1/8 of the work, and -- with scales -- at most WG_SMAX samples under one block's slice of the pixel axis.
+bool use_wgrad_dma(const igan_conv2d_wgrad_params* p, int splits) {
+    static const bool dma = getenv("IGAN_WGRAD_DMA") && atoi(getenv("IGAN_WGRAD_DMA")) != 0;      // experiment, off: measured -2 % on the plain layer mix, 0 on the step
+    if (!dma) return false;
+    if (p->Cin % 4 != 0 || p->Cout % 4 != 0 || (((uintptr_t)p->x | (uintptr_t)p->dy) & 15) != 0) return false;
+    const int up = p->up;
+    int min_cps = 1 << 30;
+    for (int c = 0; c < up * up; c++) {
+        const int qh = (p->OH - c / up + up - 1) / up, qw = (p->OW - c % up + up - 1) / up;
+        if (qh <= 0 || qw <= 0) return false;
+        const int P = qh * qw, cps = (P + BK - 1) / BK;
+        if ((long long)cps * BK * 8 > (long long)P * 9) return false;          // padding <= 12.5 %
+        min_cps = std::min(min_cps, cps);
+    }
+    if (p->in_scale || p->out_scale) {
+        const long long chunks = (long long)p->N * min_cps;                   // the class with the shortest samples has the most per block
+        const long long per_block = (chunks + splits - 1) / splits + 1;
+        if ((per_block + min_cps - 1) / min_cps + 1 > WG_SMAX) return false;
+    }
+    return true;
+}
+
 int wgrad_splits(const igan_conv2d_wgrad_params* p) {
     // One block per (tap, Cin tile, Cout tile, pixel slice).  The kernel runs 2 workgroups per CU
     // (LDS / VGPR), i.e. 512 co-resident workgroups on 256 CUs: size the grid to whole rounds of 512
@@ -1743,6 +1967,18 @@ extern "C" int igan_conv2d_wgrad(igan_stream_t stream_, const igan_conv2d_wgrad_
     dim3 grid(ceil_div(p->Cin, t.BM), ceil_div(p->Cout, t.BN), p->KH * p->KW * splits);
     const bool vec = a.vecA && a.vecB && (a.in_scale == nullptr || a.vecSA) && (a.out_scale == nullptr || a.vecSB);
     const int scm = (a.in_scale && a.out_scale) ? 1 : ((a.in_scale || a.out_scale) ? 2 : 0);
+    if (t.BM == 128 && t.BN == 128 && use_wgrad_dma(p, splits)) {       // LDS-DMA form, scales folded per sample
+        if (scm == 0) hipLaunchKernelGGL((conv_wgrad_dma_kernel<0>), grid, dim3(512), 0, stream, a);
+        else hipLaunchKernelGGL((conv_wgrad_dma_kernel<1>), grid, dim3(512), 0, stream, a);
+        IGAN_LAUNCH_CHECK("conv2d_wgrad (LDS-DMA) launch");
+        if (splits > 1) {
+            const int total = (int)wsize;
+            const int rg = std::min(ceil_div(total, 256), 2048);
+            hipLaunchKernelGGL(plain_reduce_kernel, dim3(rg), dim3(256), 0, stream, (const float*)p->workspace, p->dw, total, splits, p->alpha);
+            IGAN_LAUNCH_CHECK("conv2d_wgrad reduce launch");
+        }
+        return IGAN_OK;
+    }
     // 8 waves pay on the short pixel axes (32x32 and below: +1.5 %), 4 waves on the 128x128 layers (+3-4 %): measured, tools/conv_bench.py
     const bool long_axis = (long long)p->OH * p->OW >= 128LL * 128LL;
     if (t.BM == 128 && t.BN == 128 && eight_waves("IGAN_WGRAD_8WAVE") && !long_axis) launch_wgrad<128, 128, 2, 4>(stream, a, grid, vec, scm);
