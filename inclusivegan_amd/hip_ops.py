@@ -737,6 +737,11 @@ class ModConv2dFn(torch.autograd.Function):
             # be differentiated again.  (A nested autograd.grad over a recomputed forward would follow
             # d's history into s and w and count that path twice.)
             dx = dw = ds = dd = None
+            if (not need_w) and d is not None and _MODCONV_GRAD_FN and x.shape[1] % 4 == 0 and y.shape[1] % 4 == 0:
+                # path-length regulariser (loss.py:64-66): only (dx, ds, dd) are wanted and must be differentiable once more --
+                # the fused first-order kernels as a Function whose own backward is written out with the same kernels
+                dx, ds, dd = ModConvGradFn.apply(dy, x, w, s, d, y, geom, in_hw, ctx.out_hw)
+                return (dx if need_x else None), None, (ds if need_s else None), (dd if need_d else None), None, None
             dyd = dy * d[:, :, None, None] if d is not None else dy
             if need_x or need_s:
                 dxs = ConvDgradFn.apply(dyd, w, geom, in_hw)
@@ -774,6 +779,75 @@ class ModConv2dFn(torch.autograd.Function):
             else:
                 dd = (dy * y).sum(dim=(2, 3)) / d
         return dx, dw, ds, dd, None, None
+
+
+_MODCONV_GRAD_FN = os.environ.get('IGAN_MODCONV_GRAD_FN', '1') != '0'      # A/B switch
+
+
+class ModConvGradFn(torch.autograd.Function):
+    """(dx, ds, dd) = gradients of y = d * conv(x * s, w) w.r.t. (x, s, d) for an upstream dy, as ONE differentiable op: the backward
+    of ModConv2dFn when it has to be differentiated again (create_graph=True: path-length regulariser, loss.py:64-66).
+        u = dy * d,   t = dgrad(u, w),   dx = t * s,   ds = sum_hw t * x,   dd = sum_hw dy * z,   z = conv(x * s, w) = y / d
+    forward = the fused first-order kernels.  backward (cotangents g_dx, g_ds, g_dd; not differentiable again):
+        g_t  = g_dx * s + g_ds * x
+        g_dy = d * conv(g_t, w) + g_dd * z                      g_d = sum_hw conv(g_t, w) * dy
+        g_w  = wgrad(g_t, u) + wgrad(x * s, g_dd * dy)
+        g_x  = g_ds * t + s * dgrad(g_dd * dy, w)               g_s = sum_hw g_dx * t + sum_hw x * dgrad(g_dd * dy, w)
+    -- every convolution and every reduction over pixels is one of the library's kernels with the scales folded in, instead of
+    the dozens of element-wise passes per layer the generic composite needs."""
+
+    @staticmethod
+    def forward(ctx, dy, x, w, s, d, y, geom, in_hw, out_hw):
+        dy = nhwc(dy)
+        t = conv2d_raw(dy, w, dgrad_geom(geom), in_hw, w.shape[2], w_transposed=True, in_scale=d)
+        ds, _ = scale_dot_raw(x, t, None)
+        dx = t * s[:, :, None, None]
+        dd = scale_dot_raw(dy, y)[0] / d
+        ctx.save_for_backward(dy, x, w, s, d, y, t)
+        ctx.geom, ctx.in_hw, ctx.out_hw = geom, in_hw, out_hw
+        return dx, ds, dd
+
+    @staticmethod
+    def backward(ctx, g_dx, g_ds, g_dd):
+        if torch.is_grad_enabled():
+            raise NotImplementedError('modulated conv: third-order gradients are not built')
+        dy, x, w, s, d, y, t = ctx.saved_tensors
+        geom = ctx.geom
+        need_dy, need_x, need_w, need_s, need_d = [_needed(ctx, i) for i in range(5)]
+        g_dy = g_x = g_w = g_s = g_d = None
+        if g_dx is not None or g_ds is not None:
+            if g_dx is not None:
+                g_t = nhwc(g_dx) * s[:, :, None, None]
+                if g_ds is not None:
+                    g_t = torch.addcmul(g_t, x, g_ds[:, :, None, None])
+            else:
+                g_t = x * g_ds[:, :, None, None]
+            if need_dy or need_d:
+                g_dy = conv2d_raw(g_t, w, geom, ctx.out_hw, w.shape[3], out_scale=d)          # d * conv(g_t, w)
+                if need_d:
+                    g_d = scale_dot_raw(g_dy, dy)[0] / d
+            if need_w:
+                g_w = conv2d_wgrad_raw(g_t, dy, geom, out_scale=d)
+            if need_s and g_dx is not None:
+                g_s = scale_dot_raw(g_dx, t)[0]
+            if need_x and g_ds is not None:
+                g_x = t * g_ds[:, :, None, None]
+        if g_dd is not None:
+            g_dd = g_dd.contiguous()
+            if need_x or need_s:
+                g_xs = conv2d_raw(dy, w, dgrad_geom(geom), ctx.in_hw, w.shape[2], w_transposed=True, in_scale=g_dd)
+                gs2, gx2 = scale_dot_raw(x, g_xs, s, want_scaled=need_x)
+                if need_s:
+                    g_s = gs2 if g_s is None else g_s + gs2
+                if need_x:
+                    g_x = gx2 if g_x is None else g_x + gx2
+            if need_w:
+                gw2 = conv2d_wgrad_raw(x, dy, geom, in_scale=s, out_scale=g_dd)
+                g_w = gw2 if g_w is None else g_w + gw2
+            if need_dy:
+                gdy2 = y * (g_dd / d)[:, :, None, None]
+                g_dy = gdy2 if g_dy is None else g_dy + gdy2
+        return g_dy, g_x, g_w, g_s, g_d, None, None, None, None
 
 
 def modconv_composite(x, w, s, d, geom, out_hw):
