@@ -20,6 +20,17 @@ def test_rccl_group_and_graph_capture_coexist(cuda_device):
     assert 'ok ' in r.stdout and 'True' in r.stdout
 
 
+def test_rccl_allreduce_inside_captured_graph(cuda_device):
+    """The form the gradient exchange takes under RCCL: asynchronous all-reduces of bucket chunks issued from inside a captured
+    region, waited at its end, replayed.  One rank (the collective degenerates to a copy but takes the same capture path); the
+    communicator must stay usable afterwards."""
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'dist_capture_probe.py')], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert 'replays correct = True' in r.stdout and 'RESULT capturable' in r.stdout and 'eager all-reduce after the capture: ok 8.0' in r.stdout
+
+
 def _run_world2(mode, tmp_path, timeout=900):
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'dist_worker.py'), mode, str(r), '2', str(port), str(tmp_path)],
