@@ -925,6 +925,258 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_dma_kernel(ConvArgs a) {
     stamp(3);
 }
 
+// LDS-DMA form with a deeper pipeline (experiment behind IGAN_CONV_DMA4=1): K chunks of 16 instead of 32 and FOUR stages, the
+// DMA running three chunks ahead.  With two stages the barrier that ends a chunk also waits for the NEXT chunk's data
+// (`vmcnt(0)`), so an L2 miss (first touch of an input row: ~2 us) stalls the workgroup unless the other resident workgroup
+// happens to have MFMAs ready; here the barrier waits only for the chunk issued three iterations ago (`vmcnt(4)`: the two
+// youngest chunks, two DMA instructions each, stay in flight).  Same LDS footprint (4 x 16 KiB), same tile, same epilogue.
+//  * stage images: A [128 rows][16 k] (64 B rows, the 16 B k-segment q of row r at slot q ^ ((r >> 2) & 3): ds_read_b128 of 16
+//    consecutive rows touches 16 distinct slots of 256 B), B [16 k][128 n] plain, or (transposed weights) [128 n][16 k] like A.
+//  * a wave's DMA share per chunk: 16 A rows (one instruction) and 2 k rows / 16 n rows of B (one instruction).
+//  * per chunk and wave 16 MFMAs in two quarters of 4 k steps:  [DMA c+3] [MFMA Q0 of c] [vmcnt(4) + barrier] [read Q0, Q1 of
+//    c+1] [MFMA Q1 of c].
+template <bool WT, bool SC>
+__global__ __launch_bounds__(512, 4) void conv_fwd_dma4_kernel(ConvArgs a) {
+    constexpr int BM = 128, BN = 128, WN = 4, TM = 2, DK = 16, NST = 4;
+    constexpr int A_ST = BM * DK, B_ST = DK * BN;                // floats per stage and operand (8 KiB each)
+    constexpr int SMAX = 2048;
+    __shared__ __attribute__((aligned(1024))) float smem[NST * (A_ST + B_ST) + SMAX + 2 * BM];
+    float* As = smem;
+    float* Bs = smem + NST * A_ST;
+    float* s_tab = smem + NST * (A_ST + B_ST);
+    int* row_pix = reinterpret_cast<int*>(s_tab + SMAX);
+    int* row_n = row_pix + BM;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int up = 1 << a.up_shift;
+    int bid = blockIdx.x;
+    if (a.xcd_remap && bid < a.full_tiles) {
+        const int per_class = a.nx * a.ny;
+        const int lo = (bid / per_class) * per_class;
+        bid = lo + remap_xcd(bid - lo, min(per_class, a.full_tiles - lo));
+    }
+    const bool sliced = bid >= a.full_tiles;
+    const int tail = bid - a.full_tiles;
+    const int tile = sliced ? a.full_tiles + tail / a.splits : bid;
+    const int split = sliced ? tail % a.splits : 0;
+    const int nsplit = sliced ? a.splits : 1;
+    const int mt = tile % a.nx, nt = (tile / a.nx) % a.ny, cls = tile / (a.nx * a.ny);
+    const int py = cls >> a.up_shift, px = cls & (up - 1);
+    const int QH = (a.OH - py + up - 1) >> a.up_shift;
+    const int QW = (a.OW - px + up - 1) >> a.up_shift;
+    const int Mcls = a.N * QH * QW;
+    const int m0 = mt * BM;
+    if (m0 >= Mcls) return;
+    const int n0 = nt * BN;
+    const int ky0 = (a.pad_y - py * a.stride) & (up - 1);
+    const int kx0 = (a.pad_x - px * a.stride) & (up - 1);
+    const int nky = (ky0 < a.KH) ? ((a.KH - ky0 + up - 1) >> a.up_shift) : 0;
+    const int nkx = (kx0 < a.KW) ? ((a.KW - kx0 + up - 1) >> a.up_shift) : 0;
+    const int cpt = 2 * a.cpt;                                   // 16-deep chunks per tap (Cin % 32 == 0 on this path)
+    const int chunks32 = nky * nkx * a.cpt;                      // the tile list slices in units of 32-deep chunks (host plan)
+    const int c_begin = 2 * (int)(((long long)split * chunks32) / nsplit);
+    const int c_end = 2 * (int)(((long long)(split + 1) * chunks32) / nsplit);
+
+    if (tid < BM) {
+        const int m = m0 + tid;
+        int pix = -1, nn = 0;
+        if (m < Mcls) {
+            nn = m / (QH * QW);
+            const int r = m - nn * (QH * QW);
+            const int qy = r / QW, qx = r - qy * QW;
+            pix = (nn * a.OH + (qy * up + py)) * a.OW + (qx * up + px);
+        }
+        row_pix[tid] = pix;
+        row_n[tid] = nn;
+    }
+    const int n_lo = m0 / (QH * QW);
+    const int n_hi = (min(m0 + BM, Mcls) - 1) / (QH * QW);
+    if constexpr (SC) {
+        const int cnt = (n_hi - n_lo + 1) * a.Cin;
+        for (int i = tid; i < cnt; i += 512) s_tab[i] = a.in_scale[n_lo * a.Cin + i];
+    }
+
+    // ---- DMA lane geometry: A (and transposed B): wave w fills rows [16w, 16w + 16): lane -> row 16w + (lane >> 2), slot lane & 3
+    const int arow = wave * 16 + (lane >> 2);
+    const int aseg = (lane & 3) ^ ((arow >> 2) & 3);
+    int rn, rby, rbx;
+    bool rok;
+    {
+        const int m = m0 + arow;
+        rok = m < Mcls;
+        const int mm = rok ? m : 0;
+        const int nn = mm / (QH * QW);
+        const int r = mm - nn * (QH * QW);
+        const int qy = r / QW, qx = r - qy * QW;
+        rn = nn;
+        rby = (qy * up + py) * a.stride - a.pad_y;
+        rbx = (qx * up + px) * a.stride - a.pad_x;
+    }
+    int ld_t0 = (c_begin < c_end) ? c_begin / cpt : 0;
+    int ld_cc = (c_begin < c_end) ? c_begin - ld_t0 * cpt : 0;
+    int ld_ta = (c_begin < c_end) ? ld_t0 / nkx : 0;
+    int ld_tb = (c_begin < c_end) ? ld_t0 - ld_ta * nkx : 0;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, (unsigned)a.N * a.H * a.W * a.Cin * 4u);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.w, (unsigned)a.KH * a.KW * a.Cin * a.Cout * 4u);
+    unsigned offA = OOB, offB = OOB;
+    bool fresh = true;
+    const unsigned stepB = WT ? 64u : (unsigned)(DK * a.Cout) * 4u;
+    auto decode_tap = [&]() {
+        const int ky = ky0 + (ld_ta << a.up_shift), kx = kx0 + (ld_tb << a.up_shift);
+        const int vy = rby + ky, vx = rbx + kx;
+        const int iy = vy >> a.up_shift, ix = vx >> a.up_shift;
+        const bool ok = rok & (vy >= 0) & (vx >= 0) & (iy < a.H) & (ix < a.W);
+        offA = ok ? (unsigned)(((rn * a.H + iy) * a.W + ix) * a.Cin + ld_cc * DK + 4 * aseg) * 4u : OOB;
+        if constexpr (!WT) {    // wave w fills k rows 2w, 2w+1: lane -> k row (lane >> 5), 4 columns at 4 * (lane & 31)
+            const int cik = ld_cc * DK + wave * 2 + (lane >> 5);
+            const int co = n0 + 4 * (lane & 31);
+            offB = (co < a.Cout) ? (unsigned)(((ky * a.KW + kx) * a.Cin + cik) * a.Cout + co) * 4u : OOB;
+        } else {                // like A: n rows, swizzled k segments
+            const int co = n0 + arow;
+            offB = (co < a.Cout) ? (unsigned)((((a.KH - 1 - ky) * a.KW + (a.KW - 1 - kx)) * a.Cout + co) * a.Cin + ld_cc * DK + 4 * aseg) * 4u : OOB;
+        }
+    };
+    typedef __attribute__((address_space(3))) void lds_void;
+    auto dma_chunk = [&](int stage, bool live) {       // 2 wave instructions: 1 KiB of A, 1 KiB of B
+        if (fresh | (ld_cc == 0)) decode_tap();
+        fresh = false;
+        float* A = As + stage * A_ST + wave * 16 * DK;
+        float* B = Bs + stage * B_ST + (WT ? wave * 16 * DK : wave * 2 * BN);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)A, 16, live ? offA : OOB, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)B, 16, live ? offB : OOB, 0, 0, 0);
+        offA += 64u; offB += stepB;                    // OOB + cpt * 64 stays out of range
+        ++ld_cc;
+        const int w1 = (ld_cc == cpt) ? 1 : 0;
+        ld_cc = w1 ? 0 : ld_cc;
+        ld_tb += w1;
+        const int w2 = (ld_tb == nkx) ? 1 : 0;
+        ld_tb = w2 ? 0 : ld_tb;
+        ld_ta += w2;
+    };
+
+    f32x16 acc[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[tm][r] = 0.0f;
+
+    const bool b_scaled = SC && (n_lo == n_hi) && a.b_scale;
+    float afq[2][2][TM][4], bfq[2][2][4];              // [buffer][quarter]: the chunk being multiplied and the next one
+    int srow[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; tm++) {
+        const int m = min(m0 + wm * 64 + tm * 32 + l31, Mcls - 1);
+        srow[tm] = SC ? (m / (QH * QW) - n_lo) * a.Cin + 8 * h : 0;
+    }
+    auto read_q = [&](auto bs_tag, int buf, int stage, int q, int ci_chunk) {
+        constexpr bool BS = decltype(bs_tag)::value;
+        const float* A = As + stage * A_ST;
+        const float* B = Bs + stage * B_ST;
+#pragma unroll
+        for (int tm = 0; tm < TM; tm++) {
+            const int row = wm * 64 + tm * 32 + l31;
+            float4 sv = make_float4(1.f, 1.f, 1.f, 1.f);
+            if constexpr (SC && !BS) sv = *reinterpret_cast<const float4*>(s_tab + srow[tm] + ci_chunk * DK + 4 * q);
+            const float4 v = *reinterpret_cast<const float4*>(A + row * DK + (((2 * h + q) ^ ((row >> 2) & 3)) << 2));
+            afq[buf][q][tm][0] = (SC && !BS) ? v.x * sv.x : v.x; afq[buf][q][tm][1] = (SC && !BS) ? v.y * sv.y : v.y;
+            afq[buf][q][tm][2] = (SC && !BS) ? v.z * sv.z : v.z; afq[buf][q][tm][3] = (SC && !BS) ? v.w * sv.w : v.w;
+        }
+        if constexpr (!WT) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) bfq[buf][q][j] = B[(8 * h + 4 * q + j) * BN + wn * 32 + l31];
+        } else {
+            const int row = wn * 32 + l31;
+            const float4 v = *reinterpret_cast<const float4*>(B + row * DK + (((2 * h + q) ^ ((row >> 2) & 3)) << 2));
+            bfq[buf][q][0] = v.x; bfq[buf][q][1] = v.y; bfq[buf][q][2] = v.z; bfq[buf][q][3] = v.w;
+        }
+        if constexpr (SC && BS) {
+            const float4 sv = *reinterpret_cast<const float4*>(s_tab + 8 * h + ci_chunk * DK + 4 * q);
+            bfq[buf][q][0] *= sv.x; bfq[buf][q][1] *= sv.y; bfq[buf][q][2] *= sv.z; bfq[buf][q][3] *= sv.w;
+        }
+    };
+    auto mma_q = [&](int buf, int q) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int tm = 0; tm < TM; tm++)
+                acc[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(afq[buf][q][tm][j], bfq[buf][q][j], acc[tm], 0, 0, 0);
+    };
+
+    // prologue: three chunks in flight, wait for the first
+    dma_chunk(0, c_begin < c_end);
+    dma_chunk(1, c_begin + 1 < c_end);
+    dma_chunk(2, c_begin + 2 < c_end);
+    __builtin_amdgcn_s_waitcnt(0x0F70 | 4);            // vmcnt(4): all but the two youngest chunks (2 instructions each) have landed
+    __syncthreads();                                   // (also makes the scale row and the row tables visible)
+    auto main_loop = [&](auto bs_tag) {
+        int sc_ci = (c_begin < c_end) ? c_begin - (c_begin / cpt) * cpt : 0;
+        read_q(bs_tag, 0, 0, 0, sc_ci);
+        read_q(bs_tag, 0, 0, 1, sc_ci);
+        auto body = [&](int c, auto buf_tag) {
+            constexpr int BUF = decltype(buf_tag)::value;
+            const int st = (c - c_begin) & 3;
+            dma_chunk((st + 3) & 3, c + 3 < c_end);    // that stage was last read during chunk c-1: everyone passed the last barrier since
+            __builtin_amdgcn_sched_barrier(0);
+            mma_q(BUF, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0x0070 | 4);    // vmcnt(4) lgkmcnt(0): chunk c+1 landed; my reads of the stage the next DMA overwrites are done
+            __builtin_amdgcn_s_barrier();              // chunk c+1 is in LDS for everybody
+            __builtin_amdgcn_sched_barrier(0);
+            sc_ci = (sc_ci + 1 == cpt) ? 0 : sc_ci + 1;
+            read_q(bs_tag, BUF ^ 1, (st + 1) & 3, 0, sc_ci);
+            read_q(bs_tag, BUF ^ 1, (st + 1) & 3, 1, sc_ci);
+            mma_q(BUF, 1);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        for (int c = c_begin; c < c_end; c += 2) {     // c_end - c_begin is even (two 16-deep chunks per 32-deep one)
+            body(c, std::integral_constant<int, 0>{});
+            body(c + 1, std::integral_constant<int, 1>{});
+        }
+    };
+    if (SC && b_scaled) main_loop(std::true_type{});
+    else main_loop(std::false_type{});
+
+    // ---- epilogue (as conv_fwd_dma_kernel) ----
+    if (sliced && nsplit > 1) {
+        float* wst = a.y + ((size_t)(tile - a.full_tiles) * a.splits + split) * (BM * BN);
+#pragma unroll
+        for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                wst[row * BN + wn * 32 + l31] = acc[tm][r];
+            }
+        return;
+    }
+    float* out = a.out;
+    const bool scale = a.out_scale != nullptr;
+    const float alpha = a.alpha;
+    const int co = n0 + wn * 32 + l31;
+    const bool in = co < a.Cout;
+    const int n_first = row_n[0], n_last = row_n[min(BM, Mcls - m0) - 1];
+    const bool one_sample = n_first == n_last;
+    const float mul = (scale && one_sample && in) ? a.out_scale[n_first * a.Cout + co] : 1.0f;
+    const float bia = (a.act && a.bias && in) ? a.bias[co] : 0.0f;
+    const bool row_scale = scale && !one_sample;
+#pragma unroll
+    for (int tm = 0; tm < TM; tm++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int pix = row_pix[row];
+            if (pix < 0 || !in) continue;
+            float v = acc[tm][r] * alpha;
+            if (scale && one_sample) v *= mul;
+            if (row_scale) v *= a.out_scale[row_n[row] * a.Cout + co];
+            if (a.act) v = epi_act(a.act, v + bia, a.act_alpha) * a.act_gain;
+            out[(size_t)pix * a.Cout + co] = v;
+        }
+    }
+}
+
 // Fix-up of the sliced tail tiles: y[tile] = alpha * out_scale * sum_slices ws[tile][slice]  (fixed order).
 // grid = (tail tiles, row groups of RP rows); the partial tiles are dense [BM][BN] images, rows map to
 // output pixels exactly as in the main kernel.
@@ -1598,6 +1850,11 @@ bool use_dma_kernel(const igan_conv2d_params* p, const FwdTile& t, bool walk) {
     return true;
 }
 
+bool dma4_enabled() {
+    static const bool on = getenv("IGAN_CONV_DMA4") && atoi(getenv("IGAN_CONV_DMA4")) != 0;      // experiment switch
+    return on;
+}
+
 bool walk_ok(const igan_conv2d_params* p) {
     static const bool walk = !(getenv("IGAN_CONV_WALK") && atoi(getenv("IGAN_CONV_WALK")) == 0);     // A/B switch
     const bool wt = p->w_transposed != 0;
@@ -1788,6 +2045,14 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
             } else {
                 if (a.in_scale) hipLaunchKernelGGL((conv_fwd_dma_kernel<false, true, 2>), grid, dim3(512), 0, stream, a);
                 else hipLaunchKernelGGL((conv_fwd_dma_kernel<false, false, 2>), grid, dim3(512), 0, stream, a);
+            }
+        } else if (dma4_enabled()) {      // experiment: 16-deep chunks, four stages
+            if (wt) {
+                if (a.in_scale) hipLaunchKernelGGL((conv_fwd_dma4_kernel<true, true>), grid, dim3(512), 0, stream, a);
+                else hipLaunchKernelGGL((conv_fwd_dma4_kernel<true, false>), grid, dim3(512), 0, stream, a);
+            } else {
+                if (a.in_scale) hipLaunchKernelGGL((conv_fwd_dma4_kernel<false, true>), grid, dim3(512), 0, stream, a);
+                else hipLaunchKernelGGL((conv_fwd_dma4_kernel<false, false>), grid, dim3(512), 0, stream, a);
             }
         } else if (wt) {
             if (a.in_scale) hipLaunchKernelGGL((conv_fwd_dma_kernel<true, true>), grid, dim3(512), 0, stream, a);
