@@ -74,6 +74,7 @@ struct ConvArgs {
     float alpha;            // output multiplier (applied here when splits == 1, else by the reduce kernel)
     int xcd_remap;          // XCD-aware block order (remap_xcd)
     int b_scale;            // LDS-DMA kernel: one-sample tiles apply the modulation to the B fragments (A/B switch IGAN_CONV_BSCALE)
+    int prio;               // LDS-DMA kernel: raised issue priority during the tile prologue (A/B switch IGAN_CONV_PROLOGUE_PRIO)
     int walk;               // walking address computation usable (16 B paths, Cin % 32 == 0)
     int stagger;            // start delay (64-cycle quanta) of the workgroup in the upper LDS slot (0 = none)
     unsigned long long* diag;   // diagnostic build-in: 4 time stamps (100 MHz ticks) per workgroup, or nullptr
@@ -595,6 +596,17 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 8 : ((WM * WN == 8)
 }
 
 // ------------------------------------------------------------------------------
+// m / d for 0 <= m < 2^24, d >= 1, with inv = 1.0f / d: the float quotient is within one of the true one (a handful of
+// instructions instead of the ~30 of the generic 32-bit division; a tile's prologue has eight of them per lane).
+__device__ __forceinline__ int div_small(int m, int d, float inv) {
+    int q = (int)((float)m * inv);
+    int r = m - q * d;
+    if (r < 0) { q -= 1; r += d; }
+    if (r >= d) { q += 1; r -= d; }
+    q += (r >= d) ? 1 : 0;          // the estimate is within one; the second step is margin
+    return q;
+}
+
 // Forward-type kernel, LDS-DMA form (128x128x32 tile, 8 waves = 2 x 4 of 64x32).  Same tile list, same MFMA order per
 // accumulator and therefore the same results bit for bit as conv_fwd_kernel<128,128,2,4>; what changes is how a chunk gets
 // into LDS.  In the register-staged kernel every wave spends 600-1250 cycles per chunk between its two MFMA halves waiting
@@ -642,6 +654,9 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_dma_kernel(ConvArgs a) {
         }
     };
     stamp(0);
+    // The prologue of a tile (a few hundred scalar / vector instructions) runs beside the partner workgroup's MFMA stream, and at
+    // equal priority it takes 18 us instead of 3: let it win the issue arbitration until the first chunk is on its way.
+    if (a.prio) __builtin_amdgcn_s_setprio(3);
     int bid = blockIdx.x;
     if (a.xcd_remap && bid < a.full_tiles) {
         const int per_class = a.nx * a.ny;
@@ -666,28 +681,11 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_dma_kernel(ConvArgs a) {
     const int nky = (ky0 < a.KH) ? ((a.KH - ky0 + up - 1) >> a.up_shift) : 0;
     const int nkx = (kx0 < a.KW) ? ((a.KW - kx0 + up - 1) >> a.up_shift) : 0;
     const int chunks = nky * nkx * a.cpt;
-    const int c_begin = (int)(((long long)split * chunks) / nsplit);
-    const int c_end = (int)(((long long)(split + 1) * chunks) / nsplit);
+    const int c_begin = sliced ? (split * chunks) / nsplit : 0;           // split * chunks < 2^31: splits <= 256, chunks < 2^20
+    const int c_end = sliced ? ((split + 1) * chunks) / nsplit : chunks;
 
-    if (tid < BM) {
-        const int m = m0 + tid;
-        int pix = -1, nn = 0;
-        if (m < Mcls) {
-            nn = m / (QH * QW);
-            const int r = m - nn * (QH * QW);
-            const int qy = r / QW, qx = r - qy * QW;
-            pix = (nn * a.OH + (qy * up + py)) * a.OW + (qx * up + px);
-        }
-        row_pix[tid] = pix;
-        row_n[tid] = nn;
-    }
-    const int n_lo = m0 / (QH * QW);                 // first sample of the tile
-    if constexpr (SC) {   // scale rows of the samples this tile touches (consecutive; their number is bounded by the host)
-        const int n_hi = (min(m0 + BM, Mcls) - 1) / (QH * QW);
-        const int cnt = (n_hi - n_lo + 1) * a.Cin;
-        for (int i = tid; i < cnt; i += 512) s_tab[i] = a.in_scale[n_lo * a.Cin + i];
-    }
-
+    const float inv_hw = 1.0f / (float)(QH * QW), inv_w = 1.0f / (float)QW;     // Mcls < 2^24 (checked by the host: 2 GiB operands)
+    const int n_lo = div_small(m0, QH * QW, inv_hw);                 // first sample of the tile
     // ---- DMA lane geometry.  A (and transposed B): wave w fills rows [8w, 8w+8) and [64 + 8w, ...): lane -> row = lane >> 3,
     // LDS slot = lane & 7, fetched k-segment = slot ^ ((row >> 1) & 7).
     int rn[2], rby[2], rbx[2];
@@ -699,9 +697,9 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_dma_kernel(ConvArgs a) {
         const int m = m0 + row;
         rok[i] = m < Mcls;
         const int mm = rok[i] ? m : 0;
-        const int nn = mm / (QH * QW);
+        const int nn = div_small(mm, QH * QW, inv_hw);
         const int r = mm - nn * (QH * QW);
-        const int qy = r / QW, qx = r - qy * QW;
+        const int qy = div_small(r, QW, inv_w), qx = r - qy * QW;
         rn[i] = nn;
         rby[i] = (qy * up + py) * a.stride - a.pad_y;
         rbx[i] = (qx * up + px) * a.stride - a.pad_x;
@@ -771,17 +769,12 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_dma_kernel(ConvArgs a) {
     //     [DMA chunk c+1] [read Q2, Q3 of c] [MFMA Q0 Q1 Q2 of c] [vmcnt(0) + barrier] [read Q0, Q1 of c+1] [MFMA Q3 of c]
     // the 8 MFMAs of Q3 cover the LDS latency of the next chunk's first reads, and the DMA has 24 MFMA slots to land.
     float afq[4][TM][4], bfq[4][4];
-    int srow[TM];        // offset of this lane's rows' scale rows in s_tab (rows of one tile can belong to different samples)
-#pragma unroll
-    for (int tm = 0; tm < TM; tm++) {
-        const int m = min(m0 + wm * 64 + tm * 32 + l31, Mcls - 1);
-        srow[tm] = SC ? (m / (QH * QW) - n_lo) * a.Cin + 16 * h : 0;
-    }
+    int srow[TM];        // offset of this lane's rows' scale rows in s_tab (rows of one tile can belong to different samples); set below
     // Where the modulation multiply happens.  A tile whose 128 rows belong to ONE sample (every layer from 16x16 up) can scale the
     // B fragments by s[k] instead of the A fragments: sum_k (x[m,k] s[k]) w[k,n] = sum_k x[m,k] (s[k] w[k,n]) -- 16 multiplies and
     // 4 scale reads per lane and chunk instead of 32 and 8 (the B fragment is half the size of the two A fragments).  Tiles that
     // straddle samples (8x8 and below) keep the row-wise A form.  Either way each product is one fp32 rounding before the MFMA.
-    const bool b_scaled = SC && (n_lo == (min(m0 + BM, Mcls) - 1) / (QH * QW));
+    const bool b_scaled = SC && (n_lo == div_small(min(m0 + BM, Mcls) - 1, QH * QW, inv_hw));
     auto read_q = [&](auto bs_tag, int stage, int q, int ci_chunk) {
         constexpr bool BS = decltype(bs_tag)::value;
         const float* A = As + stage * A_STAGE;
@@ -846,9 +839,52 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_dma_kernel(ConvArgs a) {
         }
     };
 
-    if (c_begin < c_end) dma_chunk(0);
-    __syncthreads();                         // vmcnt(0): chunk c_begin has landed; the scale row and row tables are visible
+#ifdef IGAN_PROLOGUE_STAMPS      // diagnostic build: slot 1 = tables computed / first DMA about to be issued, slot 2 = first barrier passed
     stamp(1);
+    unsigned long long pw[4];
+    pw[0] = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (c_begin < c_end) dma_chunk(0);
+    // Everything the first chunk's DMA does not need is computed while it is in flight: the epilogue's row tables and the scale
+    // rows (the prologue of a tile runs beside the partner workgroup's MFMA stream and is several times slower than on an idle CU).
+#pragma unroll
+    for (int tm = 0; tm < TM; tm++) {
+        const int m = min(m0 + wm * 64 + tm * 32 + l31, Mcls - 1);
+        srow[tm] = SC ? (div_small(m, QH * QW, inv_hw) - n_lo) * a.Cin + 16 * h : 0;
+    }
+    if (tid < BM) {
+        const int m = m0 + tid;
+        int pix = -1, nn = 0;
+        if (m < Mcls) {
+            nn = div_small(m, QH * QW, inv_hw);
+            const int r = m - nn * (QH * QW);
+            const int qy = div_small(r, QW, inv_w), qx = r - qy * QW;
+            pix = (nn * a.OH + (qy * up + py)) * a.OW + (qx * up + px);
+        }
+        row_pix[tid] = pix;
+        row_n[tid] = nn;
+    }
+    if constexpr (SC) {   // scale rows of the samples this tile touches (consecutive; their number is bounded by the host)
+        const int n_hi = div_small(min(m0 + BM, Mcls) - 1, QH * QW, inv_hw);
+        const int cnt = (n_hi - n_lo + 1) * a.Cin;
+        for (int i = tid; i < cnt; i += 512) s_tab[i] = a.in_scale[n_lo * a.Cin + i];
+    }
+
+#ifdef IGAN_PROLOGUE_STAMPS
+    pw[1] = __builtin_amdgcn_s_memrealtime();            // tables done, loads issued
+    __builtin_amdgcn_s_waitcnt(0);
+    pw[2] = __builtin_amdgcn_s_memrealtime();            // this wave's loads landed
+#endif
+    __syncthreads();                         // vmcnt(0): chunk c_begin has landed; the scale row and row tables are visible
+    if (a.prio) __builtin_amdgcn_s_setprio(0);
+#ifdef IGAN_PROLOGUE_STAMPS
+    pw[3] = __builtin_amdgcn_s_memrealtime();            // barrier passed
+    if (a.diag != nullptr && lane == 0 && wave < 8)
+        for (int k = 0; k < 4; k++) a.diag[(size_t)gridDim.x * 4 + ((size_t)blockIdx.x * 8 + wave) * 4 + k] = pw[k];
+    stamp(2);
+#else
+    stamp(1);
+#endif
     auto main_loop = [&](auto bs_tag) {
         int sc_ci = c_begin - (c_begin / a.cpt) * a.cpt;   // channel chunk (within the tap) of the chunk being computed
         read_q(bs_tag, 0, 0, sc_ci);
@@ -885,7 +921,9 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_dma_kernel(ConvArgs a) {
     if (SC && b_scaled && a.b_scale) main_loop(std::true_type{});
     else main_loop(std::false_type{});
 
+#ifndef IGAN_PROLOGUE_STAMPS
     stamp(2);
+#endif
     // ---- epilogue (as conv_fwd_kernel) ----
     if (sliced && nsplit > 1) {
         float* wst = a.y + ((size_t)(tile - a.full_tiles) * a.splits + split) * (BM * BN);
@@ -923,258 +961,6 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_dma_kernel(ConvArgs a) {
         }
     }
     stamp(3);
-}
-
-// LDS-DMA form with a deeper pipeline (experiment behind IGAN_CONV_DMA4=1): K chunks of 16 instead of 32 and FOUR stages, the
-// DMA running three chunks ahead.  With two stages the barrier that ends a chunk also waits for the NEXT chunk's data
-// (`vmcnt(0)`), so an L2 miss (first touch of an input row: ~2 us) stalls the workgroup unless the other resident workgroup
-// happens to have MFMAs ready; here the barrier waits only for the chunk issued three iterations ago (`vmcnt(4)`: the two
-// youngest chunks, two DMA instructions each, stay in flight).  Same LDS footprint (4 x 16 KiB), same tile, same epilogue.
-//  * stage images: A [128 rows][16 k] (64 B rows, the 16 B k-segment q of row r at slot q ^ ((r >> 2) & 3): ds_read_b128 of 16
-//    consecutive rows touches 16 distinct slots of 256 B), B [16 k][128 n] plain, or (transposed weights) [128 n][16 k] like A.
-//  * a wave's DMA share per chunk: 16 A rows (one instruction) and 2 k rows / 16 n rows of B (one instruction).
-//  * per chunk and wave 16 MFMAs in two quarters of 4 k steps:  [DMA c+3] [MFMA Q0 of c] [vmcnt(4) + barrier] [read Q0, Q1 of
-//    c+1] [MFMA Q1 of c].
-template <bool WT, bool SC>
-__global__ __launch_bounds__(512, 4) void conv_fwd_dma4_kernel(ConvArgs a) {
-    constexpr int BM = 128, BN = 128, WN = 4, TM = 2, DK = 16, NST = 4;
-    constexpr int A_ST = BM * DK, B_ST = DK * BN;                // floats per stage and operand (8 KiB each)
-    constexpr int SMAX = 2048;
-    __shared__ __attribute__((aligned(1024))) float smem[NST * (A_ST + B_ST) + SMAX + 2 * BM];
-    float* As = smem;
-    float* Bs = smem + NST * A_ST;
-    float* s_tab = smem + NST * (A_ST + B_ST);
-    int* row_pix = reinterpret_cast<int*>(s_tab + SMAX);
-    int* row_n = row_pix + BM;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, h = lane >> 5;
-    const int wm = wave / WN, wn = wave % WN;
-    const int up = 1 << a.up_shift;
-    int bid = blockIdx.x;
-    if (a.xcd_remap && bid < a.full_tiles) {
-        const int per_class = a.nx * a.ny;
-        const int lo = (bid / per_class) * per_class;
-        bid = lo + remap_xcd(bid - lo, min(per_class, a.full_tiles - lo));
-    }
-    const bool sliced = bid >= a.full_tiles;
-    const int tail = bid - a.full_tiles;
-    const int tile = sliced ? a.full_tiles + tail / a.splits : bid;
-    const int split = sliced ? tail % a.splits : 0;
-    const int nsplit = sliced ? a.splits : 1;
-    const int mt = tile % a.nx, nt = (tile / a.nx) % a.ny, cls = tile / (a.nx * a.ny);
-    const int py = cls >> a.up_shift, px = cls & (up - 1);
-    const int QH = (a.OH - py + up - 1) >> a.up_shift;
-    const int QW = (a.OW - px + up - 1) >> a.up_shift;
-    const int Mcls = a.N * QH * QW;
-    const int m0 = mt * BM;
-    if (m0 >= Mcls) return;
-    const int n0 = nt * BN;
-    const int ky0 = (a.pad_y - py * a.stride) & (up - 1);
-    const int kx0 = (a.pad_x - px * a.stride) & (up - 1);
-    const int nky = (ky0 < a.KH) ? ((a.KH - ky0 + up - 1) >> a.up_shift) : 0;
-    const int nkx = (kx0 < a.KW) ? ((a.KW - kx0 + up - 1) >> a.up_shift) : 0;
-    const int cpt = 2 * a.cpt;                                   // 16-deep chunks per tap (Cin % 32 == 0 on this path)
-    const int chunks32 = nky * nkx * a.cpt;                      // the tile list slices in units of 32-deep chunks (host plan)
-    const int c_begin = 2 * (int)(((long long)split * chunks32) / nsplit);
-    const int c_end = 2 * (int)(((long long)(split + 1) * chunks32) / nsplit);
-
-    if (tid < BM) {
-        const int m = m0 + tid;
-        int pix = -1, nn = 0;
-        if (m < Mcls) {
-            nn = m / (QH * QW);
-            const int r = m - nn * (QH * QW);
-            const int qy = r / QW, qx = r - qy * QW;
-            pix = (nn * a.OH + (qy * up + py)) * a.OW + (qx * up + px);
-        }
-        row_pix[tid] = pix;
-        row_n[tid] = nn;
-    }
-    const int n_lo = m0 / (QH * QW);
-    const int n_hi = (min(m0 + BM, Mcls) - 1) / (QH * QW);
-    if constexpr (SC) {
-        const int cnt = (n_hi - n_lo + 1) * a.Cin;
-        for (int i = tid; i < cnt; i += 512) s_tab[i] = a.in_scale[n_lo * a.Cin + i];
-    }
-
-    // ---- DMA lane geometry: A (and transposed B): wave w fills rows [16w, 16w + 16): lane -> row 16w + (lane >> 2), slot lane & 3
-    const int arow = wave * 16 + (lane >> 2);
-    const int aseg = (lane & 3) ^ ((arow >> 2) & 3);
-    int rn, rby, rbx;
-    bool rok;
-    {
-        const int m = m0 + arow;
-        rok = m < Mcls;
-        const int mm = rok ? m : 0;
-        const int nn = mm / (QH * QW);
-        const int r = mm - nn * (QH * QW);
-        const int qy = r / QW, qx = r - qy * QW;
-        rn = nn;
-        rby = (qy * up + py) * a.stride - a.pad_y;
-        rbx = (qx * up + px) * a.stride - a.pad_x;
-    }
-    int ld_t0 = (c_begin < c_end) ? c_begin / cpt : 0;
-    int ld_cc = (c_begin < c_end) ? c_begin - ld_t0 * cpt : 0;
-    int ld_ta = (c_begin < c_end) ? ld_t0 / nkx : 0;
-    int ld_tb = (c_begin < c_end) ? ld_t0 - ld_ta * nkx : 0;
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, (unsigned)a.N * a.H * a.W * a.Cin * 4u);
-    const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.w, (unsigned)a.KH * a.KW * a.Cin * a.Cout * 4u);
-    unsigned offA = OOB, offB = OOB;
-    bool fresh = true;
-    const unsigned stepB = WT ? 64u : (unsigned)(DK * a.Cout) * 4u;
-    auto decode_tap = [&]() {
-        const int ky = ky0 + (ld_ta << a.up_shift), kx = kx0 + (ld_tb << a.up_shift);
-        const int vy = rby + ky, vx = rbx + kx;
-        const int iy = vy >> a.up_shift, ix = vx >> a.up_shift;
-        const bool ok = rok & (vy >= 0) & (vx >= 0) & (iy < a.H) & (ix < a.W);
-        offA = ok ? (unsigned)(((rn * a.H + iy) * a.W + ix) * a.Cin + ld_cc * DK + 4 * aseg) * 4u : OOB;
-        if constexpr (!WT) {    // wave w fills k rows 2w, 2w+1: lane -> k row (lane >> 5), 4 columns at 4 * (lane & 31)
-            const int cik = ld_cc * DK + wave * 2 + (lane >> 5);
-            const int co = n0 + 4 * (lane & 31);
-            offB = (co < a.Cout) ? (unsigned)(((ky * a.KW + kx) * a.Cin + cik) * a.Cout + co) * 4u : OOB;
-        } else {                // like A: n rows, swizzled k segments
-            const int co = n0 + arow;
-            offB = (co < a.Cout) ? (unsigned)((((a.KH - 1 - ky) * a.KW + (a.KW - 1 - kx)) * a.Cout + co) * a.Cin + ld_cc * DK + 4 * aseg) * 4u : OOB;
-        }
-    };
-    typedef __attribute__((address_space(3))) void lds_void;
-    auto dma_chunk = [&](int stage, bool live) {       // 2 wave instructions: 1 KiB of A, 1 KiB of B
-        if (fresh | (ld_cc == 0)) decode_tap();
-        fresh = false;
-        float* A = As + stage * A_ST + wave * 16 * DK;
-        float* B = Bs + stage * B_ST + (WT ? wave * 16 * DK : wave * 2 * BN);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)A, 16, live ? offA : OOB, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)B, 16, live ? offB : OOB, 0, 0, 0);
-        offA += 64u; offB += stepB;                    // OOB + cpt * 64 stays out of range
-        ++ld_cc;
-        const int w1 = (ld_cc == cpt) ? 1 : 0;
-        ld_cc = w1 ? 0 : ld_cc;
-        ld_tb += w1;
-        const int w2 = (ld_tb == nkx) ? 1 : 0;
-        ld_tb = w2 ? 0 : ld_tb;
-        ld_ta += w2;
-    };
-
-    f32x16 acc[TM];
-#pragma unroll
-    for (int tm = 0; tm < TM; tm++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[tm][r] = 0.0f;
-
-    const bool b_scaled = SC && (n_lo == n_hi) && a.b_scale;
-    float afq[2][2][TM][4], bfq[2][2][4];              // [buffer][quarter]: the chunk being multiplied and the next one
-    int srow[TM];
-#pragma unroll
-    for (int tm = 0; tm < TM; tm++) {
-        const int m = min(m0 + wm * 64 + tm * 32 + l31, Mcls - 1);
-        srow[tm] = SC ? (m / (QH * QW) - n_lo) * a.Cin + 8 * h : 0;
-    }
-    auto read_q = [&](auto bs_tag, int buf, int stage, int q, int ci_chunk) {
-        constexpr bool BS = decltype(bs_tag)::value;
-        const float* A = As + stage * A_ST;
-        const float* B = Bs + stage * B_ST;
-#pragma unroll
-        for (int tm = 0; tm < TM; tm++) {
-            const int row = wm * 64 + tm * 32 + l31;
-            float4 sv = make_float4(1.f, 1.f, 1.f, 1.f);
-            if constexpr (SC && !BS) sv = *reinterpret_cast<const float4*>(s_tab + srow[tm] + ci_chunk * DK + 4 * q);
-            const float4 v = *reinterpret_cast<const float4*>(A + row * DK + (((2 * h + q) ^ ((row >> 2) & 3)) << 2));
-            afq[buf][q][tm][0] = (SC && !BS) ? v.x * sv.x : v.x; afq[buf][q][tm][1] = (SC && !BS) ? v.y * sv.y : v.y;
-            afq[buf][q][tm][2] = (SC && !BS) ? v.z * sv.z : v.z; afq[buf][q][tm][3] = (SC && !BS) ? v.w * sv.w : v.w;
-        }
-        if constexpr (!WT) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) bfq[buf][q][j] = B[(8 * h + 4 * q + j) * BN + wn * 32 + l31];
-        } else {
-            const int row = wn * 32 + l31;
-            const float4 v = *reinterpret_cast<const float4*>(B + row * DK + (((2 * h + q) ^ ((row >> 2) & 3)) << 2));
-            bfq[buf][q][0] = v.x; bfq[buf][q][1] = v.y; bfq[buf][q][2] = v.z; bfq[buf][q][3] = v.w;
-        }
-        if constexpr (SC && BS) {
-            const float4 sv = *reinterpret_cast<const float4*>(s_tab + 8 * h + ci_chunk * DK + 4 * q);
-            bfq[buf][q][0] *= sv.x; bfq[buf][q][1] *= sv.y; bfq[buf][q][2] *= sv.z; bfq[buf][q][3] *= sv.w;
-        }
-    };
-    auto mma_q = [&](int buf, int q) {
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-            for (int tm = 0; tm < TM; tm++)
-                acc[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(afq[buf][q][tm][j], bfq[buf][q][j], acc[tm], 0, 0, 0);
-    };
-
-    // prologue: three chunks in flight, wait for the first
-    dma_chunk(0, c_begin < c_end);
-    dma_chunk(1, c_begin + 1 < c_end);
-    dma_chunk(2, c_begin + 2 < c_end);
-    __builtin_amdgcn_s_waitcnt(0x0F70 | 4);            // vmcnt(4): all but the two youngest chunks (2 instructions each) have landed
-    __syncthreads();                                   // (also makes the scale row and the row tables visible)
-    auto main_loop = [&](auto bs_tag) {
-        int sc_ci = (c_begin < c_end) ? c_begin - (c_begin / cpt) * cpt : 0;
-        read_q(bs_tag, 0, 0, 0, sc_ci);
-        read_q(bs_tag, 0, 0, 1, sc_ci);
-        auto body = [&](int c, auto buf_tag) {
-            constexpr int BUF = decltype(buf_tag)::value;
-            const int st = (c - c_begin) & 3;
-            dma_chunk((st + 3) & 3, c + 3 < c_end);    // that stage was last read during chunk c-1: everyone passed the last barrier since
-            __builtin_amdgcn_sched_barrier(0);
-            mma_q(BUF, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_waitcnt(0x0070 | 4);    // vmcnt(4) lgkmcnt(0): chunk c+1 landed; my reads of the stage the next DMA overwrites are done
-            __builtin_amdgcn_s_barrier();              // chunk c+1 is in LDS for everybody
-            __builtin_amdgcn_sched_barrier(0);
-            sc_ci = (sc_ci + 1 == cpt) ? 0 : sc_ci + 1;
-            read_q(bs_tag, BUF ^ 1, (st + 1) & 3, 0, sc_ci);
-            read_q(bs_tag, BUF ^ 1, (st + 1) & 3, 1, sc_ci);
-            mma_q(BUF, 1);
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        for (int c = c_begin; c < c_end; c += 2) {     // c_end - c_begin is even (two 16-deep chunks per 32-deep one)
-            body(c, std::integral_constant<int, 0>{});
-            body(c + 1, std::integral_constant<int, 1>{});
-        }
-    };
-    if (SC && b_scaled) main_loop(std::true_type{});
-    else main_loop(std::false_type{});
-
-    // ---- epilogue (as conv_fwd_dma_kernel) ----
-    if (sliced && nsplit > 1) {
-        float* wst = a.y + ((size_t)(tile - a.full_tiles) * a.splits + split) * (BM * BN);
-#pragma unroll
-        for (int tm = 0; tm < TM; tm++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                wst[row * BN + wn * 32 + l31] = acc[tm][r];
-            }
-        return;
-    }
-    float* out = a.out;
-    const bool scale = a.out_scale != nullptr;
-    const float alpha = a.alpha;
-    const int co = n0 + wn * 32 + l31;
-    const bool in = co < a.Cout;
-    const int n_first = row_n[0], n_last = row_n[min(BM, Mcls - m0) - 1];
-    const bool one_sample = n_first == n_last;
-    const float mul = (scale && one_sample && in) ? a.out_scale[n_first * a.Cout + co] : 1.0f;
-    const float bia = (a.act && a.bias && in) ? a.bias[co] : 0.0f;
-    const bool row_scale = scale && !one_sample;
-#pragma unroll
-    for (int tm = 0; tm < TM; tm++) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int row = wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            const int pix = row_pix[row];
-            if (pix < 0 || !in) continue;
-            float v = acc[tm][r] * alpha;
-            if (scale && one_sample) v *= mul;
-            if (row_scale) v *= a.out_scale[row_n[row] * a.Cout + co];
-            if (a.act) v = epi_act(a.act, v + bia, a.act_alpha) * a.act_gain;
-            out[(size_t)pix * a.Cout + co] = v;
-        }
-    }
 }
 
 // Fix-up of the sliced tail tiles: y[tile] = alpha * out_scale * sum_slices ws[tile][slice]  (fixed order).
@@ -1511,207 +1297,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_wgr
     }
 }
 
-// Weight-gradient kernel, LDS-DMA form (128 x 128 tile of (ci, co), 8 waves = 2 x 4 of 64 x 32, K = pixels in chunks of 32).
-//  * Both operands are pixel-major rows of channels, so a chunk is 32 rows x 512 B per operand and a DMA instruction
-//    (`buffer_load_dwordx4 ... lds`, 64 lanes x 16 B = 1 KiB) fetches two whole pixel rows of the tile straight into the unpadded
-//    [pixel][128] LDS image -- no staging registers, no ds_write; padding taps, rows past the end and channels past Cin / Cout
-//    are out-of-range offsets that land as zeros.  The fragment reads are the K-major ones of conv_wgrad_kernel (a lane's two
-//    ci tiles adjacent: ds_read_b64), conflict-free without padding (16 lanes = 128 contiguous bytes per LDS cycle).
-//  * The reduction axis is cut per SAMPLE: a sample's QH * QW pixels are padded to whole chunks (zero rows), so a chunk never
-//    straddles two samples: the modulation factors of a chunk -- s[n][ci] for a lane's two ci rows, d[n][co] for its co column --
-//    are three registers, reloaded from an LDS table when the sample changes, and multiply the fragments after the LDS read (no
-//    scale loads or scale addresses in the loop).  The scale rows of the (at most WG_SMAX) samples a block touches sit in LDS;
-//    the host checks that bound and the padding overhead (use_wgrad_dma).
-constexpr int WG_SMAX = 8;
-template <int SCM>
-__global__ __launch_bounds__(512, 4) void conv_wgrad_dma_kernel(WgradArgs a) {
-    constexpr int BM = 128, BN = 128, WN = 4, TM = 2, LD = 128;
-    constexpr int STAGE = BK * LD;                                  // floats per operand stage (16 KiB)
-    __shared__ __attribute__((aligned(1024))) float smem[4 * STAGE + (SCM ? 2 * WG_SMAX * 128 : 4)];
-    float* As = smem;
-    float* Bs = smem + 2 * STAGE;
-    float* s_tab = smem + 4 * STAGE;                                // [WG_SMAX][128] in_scale rows of this ci tile
-    float* d_tab = s_tab + WG_SMAX * 128;                           // [WG_SMAX][128] out_scale rows of this co tile
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, h = lane >> 5;
-    const int wm = wave / WN, wn = wave % WN;
-    const int up = 1 << a.up_shift;
-    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    int tap = bz / a.splits, split = bz - tap * a.splits;
-    if (a.xcd_remap) {      // as conv_wgrad_kernel: tap fastest, so the blocks of one pixel slice share an XCD's L2
-        const int gx = gridDim.x, gy = gridDim.y, taps = a.KH * a.KW;
-        const int lin = remap_xcd(bx + gx * (by + gy * bz), gx * gy * (int)gridDim.z);
-        tap = lin % taps;
-        int rest = lin / taps;
-        bx = rest % gx; rest /= gx;
-        by = rest % gy;
-        split = rest / gy;
-    }
-    const int ky = tap / a.KW, kx = tap - ky * a.KW;
-    const int py = (a.pad_y - ky) & (up - 1);
-    const int px = (a.pad_x - kx) & (up - 1);
-    const int QH = (a.OH - py + up - 1) >> a.up_shift;
-    const int QW = (a.OW - px + up - 1) >> a.up_shift;
-    const int P = (QH > 0 && QW > 0) ? QH * QW : 0;                 // pixels per sample in this tap's parity class
-    const int cps = (P + BK - 1) / BK;                              // chunks per sample (last one zero-padded)
-    const int chunks = a.N * cps;
-    const int c_begin = (int)(((long long)split * chunks) / a.splits);
-    const int c_end = (int)(((long long)(split + 1) * chunks) / a.splits);
-    const int m0 = bx * BM, n0 = by * BN;
-    const int s_in = (up == 1) ? a.stride : 1;
-    const int cy = (up == 1) ? ky - a.pad_y : (py + ky - a.pad_y) >> 1;
-    const int cx = (up == 1) ? kx - a.pad_x : (px + kx - a.pad_x) >> 1;
-
-    // ---- DMA lane geometry: wave w fills pixel rows 2w, 2w+1 (+16 i) of the chunk; lane -> row (lane >> 5), 16 B segment lane & 31
-    const int seg = lane & 31;
-    const int ci = m0 + 4 * seg, co = n0 + 4 * seg;
-    const bool ci_ok = ci < a.Cin, co_ok = co < a.Cout;             // Cin, Cout % 4 == 0 on this path
-    const int dQW = max(QW, 1);
-    const int st_b = BK % dQW, st_a2 = BK / dQW;                    // a chunk advances a row by BK pixels = st_a2 rows + st_b columns
-    int rp[2], rqy[2], rqx[2];                                      // pixel index inside the sample, and its (qy, qx)
-    int base_qy[2], base_qx[2];
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const int r = 2 * wave + (lane >> 5) + 16 * i;
-        base_qy[i] = r / dQW; base_qx[i] = r - base_qy[i] * dQW;
-    }
-    int ld_n = (c_begin < c_end) ? c_begin / cps : 0;
-    int ld_j = (c_begin < c_end) ? c_begin - ld_n * cps : 0;
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const int r = 2 * wave + (lane >> 5) + 16 * i + ld_j * BK;
-        rp[i] = r; rqy[i] = r / dQW; rqx[i] = r - rqy[i] * dQW;
-    }
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, (unsigned)a.N * a.H * a.W * a.Cin * 4u);
-    const __amdgpu_buffer_rsrc_t rdy = make_rsrc(a.dy, (unsigned)a.N * a.OH * a.OW * a.Cout * 4u);
-    typedef __attribute__((address_space(3))) void lds_void;
-    auto dma_chunk = [&](int stage, bool live) {       // 4 wave instructions: 2 KiB of x rows, 2 KiB of dy rows
-        unsigned offA[2], offB[2];
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int iy = __mul24(rqy[i], s_in) + cy, ix = __mul24(rqx[i], s_in) + cx;
-            const bool in_sample = live & (rp[i] < P);
-            const bool okA = in_sample & ci_ok & ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);
-            offA[i] = okA ? (unsigned)(((ld_n * a.H + iy) * a.W + ix) * a.Cin + ci) * 4u : OOB;
-            const int oy = __mul24(rqy[i], up) + py, ox = __mul24(rqx[i], up) + px;
-            offB[i] = (in_sample & co_ok) ? (unsigned)(((ld_n * a.OH + oy) * a.OW + ox) * a.Cout + co) * 4u : OOB;
-        }
-        float* A = As + stage * STAGE + wave * 2 * LD;
-        float* B = Bs + stage * STAGE + wave * 2 * LD;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)A, 16, offA[0], 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(A + 16 * LD), 16, offA[1], 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (lds_void*)B, 16, offB[0], 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (lds_void*)(B + 16 * LD), 16, offB[1], 0, 0, 0);
-        // walk to the next chunk: BK pixels further inside the sample, or the first chunk of the next sample
-        ++ld_j;
-        const bool wrap = ld_j == cps;
-        ld_j = wrap ? 0 : ld_j;
-        ld_n += wrap ? 1 : 0;
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            int qx = rqx[i] + st_b;
-            const int c1 = (qx >= QW) ? 1 : 0;
-            qx -= c1 ? QW : 0;
-            rp[i] = wrap ? (rp[i] - (cps - 1) * BK) : rp[i] + BK;
-            rqy[i] = wrap ? base_qy[i] : rqy[i] + st_a2 + c1;
-            rqx[i] = wrap ? base_qx[i] : qx;
-        }
-    };
-
-    // ---- per-sample scale rows of this tile (SCM: an absent scale is a row of ones)
-    const int n_first = (c_begin < c_end) ? c_begin / cps : 0;
-    if constexpr (SCM != 0) {
-        const int n_last = (c_begin < c_end) ? (c_end - 1) / cps : 0;
-        const int cnt = (n_last - n_first + 1) * 128;               // <= WG_SMAX * 128: checked by the host
-        for (int i = tid; i < cnt; i += 512) {
-            const int k = i >> 7, j = i & 127;
-            s_tab[i] = (a.in_scale != nullptr && m0 + j < a.Cin) ? a.in_scale[(n_first + k) * a.Cin + m0 + j] : 1.0f;
-            d_tab[i] = (a.out_scale != nullptr && n0 + j < a.Cout) ? a.out_scale[(n_first + k) * a.Cout + n0 + j] : 1.0f;
-        }
-    }
-
-    f32x16 acc[TM];
-#pragma unroll
-    for (int tm = 0; tm < TM; tm++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[tm][r] = 0.0f;
-
-    // Fragments in quarters of the chunk (k rows 16 h + 4 q .. + 3: four ds_read_b64 of the two ci tiles, four ds_read_b32 of the co
-    // tile), read so that they straddle the barrier, as in conv_fwd_dma_kernel:
-    //     [DMA chunk c+1] [read Q2, Q3 of c] [MFMA Q0 Q1 Q2 of c] [vmcnt(0) + barrier] [read Q0, Q1 of c+1] [MFMA Q3 of c]
-    // The per-sample factors of the chunk being read (this lane's two ci rows and its co column) multiply the fragments.
-    float afq[4][TM][4], bfq[4][4];
-    float sv0 = 1.0f, sv1 = 1.0f, dv = 1.0f;
-    auto load_scales = [&](int n) {
-        if constexpr (SCM != 0) {
-            const float2 v = *reinterpret_cast<const float2*>(s_tab + (n - n_first) * 128 + wm * 64 + TM * l31);
-            sv0 = v.x; sv1 = v.y;
-            dv = d_tab[(n - n_first) * 128 + wn * 32 + l31];
-        }
-    };
-    auto read_q = [&](int stage, int q) {
-        const float* A = As + stage * STAGE + wm * 64 + TM * l31;
-        const float* B = Bs + stage * STAGE + wn * 32 + l31;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int krow = 16 * h + 4 * q + j;
-            const float2 v = *reinterpret_cast<const float2*>(A + krow * LD);
-            afq[q][0][j] = SCM ? v.x * sv0 : v.x; afq[q][1][j] = SCM ? v.y * sv1 : v.y;
-            bfq[q][j] = SCM ? B[krow * LD] * dv : B[krow * LD];
-        }
-    };
-    auto mma_q = [&](int q) {
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-            for (int tm = 0; tm < TM; tm++)
-                acc[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(afq[q][tm][j], bfq[q][j], acc[tm], 0, 0, 0);
-    };
-
-    if (c_begin < c_end) dma_chunk(0, true);
-    __syncthreads();                    // vmcnt(0): the first chunk has landed; the scale rows are visible
-    int cur_n = n_first, cur_j = (c_begin < c_end) ? c_begin - n_first * cps : 0;
-    load_scales(cur_n);
-    read_q(0, 0);
-    read_q(0, 1);
-    for (int c = c_begin; c < c_end; c++) {
-        const int cur = (c - c_begin) & 1;
-        dma_chunk(cur ^ 1, c + 1 < c_end);
-        __builtin_amdgcn_sched_barrier(0);
-        read_q(cur, 2);
-        read_q(cur, 3);
-        mma_q(0);
-        mma_q(1);
-        mma_q(2);
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();                // vmcnt(0) lgkmcnt(0) + barrier: chunk c+1 landed, everyone done reading stage `cur`
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (SCM != 0) {
-            ++cur_j;
-            if (cur_j == cps) { cur_j = 0; ++cur_n; if (c + 1 < c_end) load_scales(cur_n); }
-        }
-        read_q(cur ^ 1, 0);
-        read_q(cur ^ 1, 1);
-        mma_q(3);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-
-    // ---- epilogue (as conv_wgrad_kernel)
-    const size_t wsize = (size_t)a.KH * a.KW * a.Cin * a.Cout;
-    float* out = a.out + (a.splits > 1 ? (size_t)split * wsize : (size_t)0) + (size_t)tap * a.Cin * a.Cout;
-    const float alpha = (a.splits == 1) ? a.alpha : 1.0f;
-    const int cc = n0 + wn * 32 + l31;
-#pragma unroll
-    for (int tm = 0; tm < TM; tm++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int cir = m0 + wm * 64 + tile_row<TM, true>(tm, (r & 3) + 8 * (r >> 2) + 4 * h);
-            if (cir < a.Cin && cc < a.Cout) out[(size_t)cir * a.Cout + cc] = acc[tm][r] * alpha;
-        }
-}
-
 // y[i] = alpha * sum_k ws[k][i], fixed order.  Four partial sums so that four loads are in flight per lane (a single
 // running sum is `splits` dependent L2 round trips: 256 slices took 200 us for a 1.5 KB result).
 __global__ __launch_bounds__(256) void plain_reduce_kernel(const float* ws, float* y, int total, int splits, float alpha) {
@@ -1838,6 +1423,7 @@ TileList tile_list(const igan_conv2d_params* p, const FwdTile& t, int Mmax, int 
 bool use_dma_kernel(const igan_conv2d_params* p, const FwdTile& t, bool walk) {
     static const bool dma = !(getenv("IGAN_CONV_DMA") && atoi(getenv("IGAN_CONV_DMA")) == 0);      // A/B switch
     if (!dma || t.BM != 128 || t.BN != 128 || !walk || !eight_waves("IGAN_CONV_8WAVE")) return false;
+    if ((long long)p->N * p->OH * p->OW >= (1LL << 24)) return false;          // the kernel's row decode divides in float (div_small)
     if (p->in_scale) {      // the scale rows of all samples a tile can touch must fit the kernel's LDS table (2048 floats)
         const int up = p->up;
         for (int c = 0; c < up * up; c++) {
@@ -1848,11 +1434,6 @@ bool use_dma_kernel(const igan_conv2d_params* p, const FwdTile& t, bool walk) {
         }
     }
     return true;
-}
-
-bool dma4_enabled() {
-    static const bool on = getenv("IGAN_CONV_DMA4") && atoi(getenv("IGAN_CONV_DMA4")) != 0;      // experiment switch
-    return on;
 }
 
 bool walk_ok(const igan_conv2d_params* p) {
@@ -2018,6 +1599,8 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
         a.stagger = stagger;
         static const bool bscale = !(getenv("IGAN_CONV_BSCALE") && atoi(getenv("IGAN_CONV_BSCALE")) == 0);     // A/B switch
         a.b_scale = bscale ? 1 : 0;
+        static const bool pprio = !(getenv("IGAN_CONV_PROLOGUE_PRIO") && atoi(getenv("IGAN_CONV_PROLOGUE_PRIO")) == 0);     // A/B switch
+        a.prio = pprio ? 1 : 0;
         a.walk = (walk && a.vecA && a.vecB && (a.in_scale == nullptr || a.vecS) && (p->Cin % BK == 0)) ? 1 : 0;
     }
     a.bias = p->bias; a.act = p->act; a.act_alpha = p->act_alpha; a.act_gain = p->act_gain;
@@ -2045,14 +1628,6 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
             } else {
                 if (a.in_scale) hipLaunchKernelGGL((conv_fwd_dma_kernel<false, true, 2>), grid, dim3(512), 0, stream, a);
                 else hipLaunchKernelGGL((conv_fwd_dma_kernel<false, false, 2>), grid, dim3(512), 0, stream, a);
-            }
-        } else if (dma4_enabled()) {      // experiment: 16-deep chunks, four stages
-            if (wt) {
-                if (a.in_scale) hipLaunchKernelGGL((conv_fwd_dma4_kernel<true, true>), grid, dim3(512), 0, stream, a);
-                else hipLaunchKernelGGL((conv_fwd_dma4_kernel<true, false>), grid, dim3(512), 0, stream, a);
-            } else {
-                if (a.in_scale) hipLaunchKernelGGL((conv_fwd_dma4_kernel<false, true>), grid, dim3(512), 0, stream, a);
-                else hipLaunchKernelGGL((conv_fwd_dma4_kernel<false, false>), grid, dim3(512), 0, stream, a);
             }
         } else if (wt) {
             if (a.in_scale) hipLaunchKernelGGL((conv_fwd_dma_kernel<true, true>), grid, dim3(512), 0, stream, a);
@@ -2119,29 +1694,6 @@ WgTile pick_wg_tile(int Cin, int Cout) {
     t.BN = (Cout > 32) ? 128 : 32;
     if (t.BM == 32 && t.BN == 32) t.BN = 128;  // only three instantiations exist
     return t;
-}
-
-// Does this weight gradient take the LDS-DMA kernel?  16 B rows (Cin, Cout % 4 == 0, aligned operands), a per-sample chunk padding
-// of at most 1/8 of the work, and -- with scales -- at most WG_SMAX samples under one block's slice of the pixel axis.
-bool use_wgrad_dma(const igan_conv2d_wgrad_params* p, int splits) {
-    static const bool dma = getenv("IGAN_WGRAD_DMA") && atoi(getenv("IGAN_WGRAD_DMA")) != 0;      // experiment, off: measured -2 % on the plain layer mix, 0 on the step
-    if (!dma) return false;
-    if (p->Cin % 4 != 0 || p->Cout % 4 != 0 || (((uintptr_t)p->x | (uintptr_t)p->dy) & 15) != 0) return false;
-    const int up = p->up;
-    int min_cps = 1 << 30;
-    for (int c = 0; c < up * up; c++) {
-        const int qh = (p->OH - c / up + up - 1) / up, qw = (p->OW - c % up + up - 1) / up;
-        if (qh <= 0 || qw <= 0) return false;
-        const int P = qh * qw, cps = (P + BK - 1) / BK;
-        if ((long long)cps * BK * 8 > (long long)P * 9) return false;          // padding <= 12.5 %
-        min_cps = std::min(min_cps, cps);
-    }
-    if (p->in_scale || p->out_scale) {
-        const long long chunks = (long long)p->N * min_cps;                   // the class with the shortest samples has the most per block
-        const long long per_block = (chunks + splits - 1) / splits + 1;
-        if ((per_block + min_cps - 1) / min_cps + 1 > WG_SMAX) return false;
-    }
-    return true;
 }
 
 int wgrad_splits(const igan_conv2d_wgrad_params* p) {
@@ -2232,18 +1784,6 @@ extern "C" int igan_conv2d_wgrad(igan_stream_t stream_, const igan_conv2d_wgrad_
     dim3 grid(ceil_div(p->Cin, t.BM), ceil_div(p->Cout, t.BN), p->KH * p->KW * splits);
     const bool vec = a.vecA && a.vecB && (a.in_scale == nullptr || a.vecSA) && (a.out_scale == nullptr || a.vecSB);
     const int scm = (a.in_scale && a.out_scale) ? 1 : ((a.in_scale || a.out_scale) ? 2 : 0);
-    if (t.BM == 128 && t.BN == 128 && use_wgrad_dma(p, splits)) {       // LDS-DMA form, scales folded per sample
-        if (scm == 0) hipLaunchKernelGGL((conv_wgrad_dma_kernel<0>), grid, dim3(512), 0, stream, a);
-        else hipLaunchKernelGGL((conv_wgrad_dma_kernel<1>), grid, dim3(512), 0, stream, a);
-        IGAN_LAUNCH_CHECK("conv2d_wgrad (LDS-DMA) launch");
-        if (splits > 1) {
-            const int total = (int)wsize;
-            const int rg = std::min(ceil_div(total, 256), 2048);
-            hipLaunchKernelGGL(plain_reduce_kernel, dim3(rg), dim3(256), 0, stream, (const float*)p->workspace, p->dw, total, splits, p->alpha);
-            IGAN_LAUNCH_CHECK("conv2d_wgrad reduce launch");
-        }
-        return IGAN_OK;
-    }
     // 8 waves pay on the short pixel axes (32x32 and below: +1.5 %), 4 waves on the 128x128 layers (+3-4 %): measured, tools/conv_bench.py
     const bool long_axis = (long long)p->OH * p->OW >= 128LL * 128LL;
     if (t.BM == 128 && t.BN == 128 && eight_waves("IGAN_WGRAD_8WAVE") && !long_axis) launch_wgrad<128, 128, 2, 4>(stream, a, grid, vec, scm);

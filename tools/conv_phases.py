@@ -17,8 +17,8 @@ from inclusivegan_amd import _abi, hip_ops  # noqa: E402
 
 
 def main():
-    loop_stamps = '--loop' in sys.argv          # library built with -DIGAN_LOOP_STAMPS: per-wave phase cycles inside the main loop
-    batches = [int(a) for a in sys.argv[1:] if a != '--loop'] or [2, 4, 6, 12]
+    loop_stamps = '--loop' in sys.argv or '--prologue' in sys.argv         # library built with -DIGAN_LOOP_STAMPS / -DIGAN_PROLOGUE_STAMPS: per-wave stamps after the per-workgroup ones
+    batches = [int(a) for a in sys.argv[1:] if not a.startswith('--')] or [2, 4, 6, 12]
     dev = torch.device('cuda', 0)
     lib = _abi.get_plugin()
     g = hip_ops.ConvGeom(3, 3, 1, 1, 1, 1)
@@ -62,6 +62,11 @@ def main():
             w = np.median(ph, axis=0)
             for wv in range(8):
                 print('      wave %d: %6.0f %6.0f %6.0f %6.0f' % (wv, w[wv, 0], w[wv, 1], w[wv, 2], w[wv, 3]))
+        if '--prologue' in sys.argv:      # library built with -DIGAN_PROLOGUE_STAMPS: per-wave 100 MHz stamps inside the prologue
+            pw = raw[tiles * 4:].reshape(tiles, 8, 4).astype(np.float64) * 0.01
+            start = t[:, 0][:, None]
+            print('   per wave, us after the workgroup\'s first stamp (median over workgroups): tables start %s | loads issued %s | own loads landed %s | barrier passed %s' % tuple(
+                np.array2string(np.median(pw[:, :, k] - start, axis=0), precision=1, separator=' ') for k in range(4)))
         first_round = np.sort(t[:, 0] - t0)[:512]
         print('   start of the first %d workgroups spans %.1f us' % (len(first_round), first_round.max()))
 
