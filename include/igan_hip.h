@@ -123,6 +123,17 @@ int igan_bias_act_noise_bwd(igan_stream_t stream, const float* dy, const float* 
                             float* dx, float* db, float* dstrength, float* workspace,
                             int rows, int C, int act, float alpha, float gain);
 
+/* The same backward when the epilogue was fused into a modulated convolution (igan_conv2d with act / noise / out_scale:
+ * y = act(d[n,c] * z + noise * strength + b) * gain, z never stored): additionally
+ *     dd[n][c] = sum_{pixels of n} dx * z,      z = (pre - b[c] - noise * strength) / d[n][c],
+ * the demodulation gradient of modulated_conv2d_layer (networks_stylegan2.py:105-107,126), with the pre-activation value
+ * recovered from y (act 1 linear or 3 lrelu only).  y, dy, dx: [N, HW, C]; dscale = d [N, C]; noise [N or 1, HW] with
+ * noise_bcast; workspace of igan_bias_act_noise_dd_workspace_floats(N, HW, C) floats.  One pass + one small reduce. */
+size_t igan_bias_act_noise_dd_workspace_floats(int N, int HW, int C);
+int igan_bias_act_noise_bwd_dd(igan_stream_t stream, const float* dy, const float* y, const float* noise, const float* strength,
+                               const float* b, const float* dscale, float* dx, float* db, float* dstrength, float* dd,
+                               float* workspace, int noise_bcast, int N, int HW, int C, int act, float alpha, float gain);
+
 /* ------------------------------------------------------------------------
  * conv2d (implicit GEMM on f32 MFMA, exact fp32 accumulate).
  * One entry point covers what the reference gets from tf.nn.conv2d (SAME stride 1,
@@ -173,6 +184,10 @@ typedef struct igan_conv2d_params {
                              * convolution (networks_stylegan2.py:66-68); bias may be NULL */
     int act;                /* 0 = no epilogue; 1 linear, 2 relu, 3 lrelu (as igan_bias_act_noise_*) */
     float act_alpha, act_gain;
+    const float* noise;     /* fused epilogue of a synthesis layer (networks_stylegan2.py:351-357): with act != 0,
+                             * y = act(y + noise[n, oy, ox] * noise_strength[0] + bias[co]) * act_gain; NULL = no noise */
+    const float* noise_strength; /* device scalar */
+    int noise_bcast;        /* 1: noise is [1, OH, OW], shared by the batch (the layer's stored noise); 0: [N, OH, OW] */
 } igan_conv2d_params;
 
 int igan_conv2d_plan(const igan_conv2d_params* p, int* splits, int* sliced_tiles, size_t* workspace_floats);

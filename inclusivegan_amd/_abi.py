@@ -58,6 +58,7 @@ class Conv2DParams(ctypes.Structure):
         ('pad_y', ctypes.c_int), ('pad_x', ctypes.c_int),
         ('w_transposed', ctypes.c_int), ('splits', ctypes.c_int), ('sliced_tiles', ctypes.c_int), ('alpha', ctypes.c_float),
         ('bias', ctypes.c_void_p), ('act', ctypes.c_int), ('act_alpha', ctypes.c_float), ('act_gain', ctypes.c_float),
+        ('noise', ctypes.c_void_p), ('noise_strength', ctypes.c_void_p), ('noise_bcast', ctypes.c_int),
     ]
 
     def __init__(self, *args, **kwargs):
@@ -131,6 +132,8 @@ SIGNATURES = {
     'igan_bias_grad': (_I, [_P, _P, _P, _P, _I, _I, _I]),
     'igan_bias_act_noise_workspace_floats': (_SZ, [_I, _I]),
     'igan_bias_act_noise_fwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F]),
+    'igan_bias_act_noise_dd_workspace_floats': (ctypes.c_size_t, [_I, _I, _I]),
+    'igan_bias_act_noise_bwd_dd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F]),
     'igan_bias_act_noise_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F]),
     'igan_conv2d_plan': (_I, [ctypes.POINTER(Conv2DParams), ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_SZ)]),
     'igan_conv2d': (_I, [_P, ctypes.POINTER(Conv2DParams)]),

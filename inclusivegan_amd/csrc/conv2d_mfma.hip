@@ -78,10 +78,19 @@ struct ConvArgs {
     int walk;               // walking address computation usable (16 B paths, Cin % 32 == 0)
     int stagger;            // start delay (64-cycle quanta) of the workgroup in the upper LDS slot (0 = none)
     unsigned long long* diag;   // diagnostic build-in: 4 time stamps (100 MHz ticks) per workgroup, or nullptr
-    const float* bias;      // fused epilogue (act != 0): y = act(y + bias[co]) * act_gain
+    const float* bias;      // fused epilogue (act != 0): y = act(y + noise[n, pixel] * strength + bias[co]) * act_gain
     int act;                // 0 none, 1 linear, 2 relu, 3 lrelu
     float act_alpha, act_gain;
+    const float* noise;     // [N or 1, OH, OW] or nullptr; strength = *noise_strength (device scalar)
+    const float* noise_strength;
+    int noise_bcast;        // noise has one sample, shared by the batch
 };
+
+// noise[n, pixel] * strength of output pixel `pix` (linear index over [N, OH, OW]); 0 without noise or for padding rows
+__device__ __forceinline__ float noise_term(const ConvArgs& a, int pix) {
+    if (a.noise == nullptr || pix < 0) return 0.0f;
+    return a.noise[a.noise_bcast ? pix % (a.OH * a.OW) : pix] * a.noise_strength[0];
+}
 
 __device__ __forceinline__ float epi_act(int act, float v, float alpha) {
     if (act == 2) return v > 0.f ? v : 0.f;
@@ -234,6 +243,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 8 : ((WM * WN == 8)
     __shared__ __attribute__((aligned(16))) float Bs[2 * B_ELEMS];
     __shared__ int row_pix[BM];  // linear output pixel (n*OH+oy)*OW+ox, or -1
     __shared__ int row_n[BM];
+    __shared__ float row_nz[BM];  // noise * strength of the row's pixel (fused epilogue)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -303,6 +313,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 8 : ((WM * WN == 8)
         }
         row_pix[tid] = pix;
         row_n[tid] = nn;
+        row_nz[tid] = noise_term(a, pix);
     }
     // loader rows (registers)
     const int kvec = tid & 7;
@@ -579,7 +590,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 8 : ((WM * WN == 8)
                 v[tn] = acc[tm][tn][r] * alpha;
                 if (scale && one_sample) v[tn] *= mul[tn];       // same product order as the per-row form and the fix-up kernel
                 if (row_scale && cos[tn] < a.Cout) v[tn] *= a.out_scale[row_n[row] * a.Cout + cos[tn]];
-                if (a.act) v[tn] = epi_act(a.act, v[tn] + bia[tn], a.act_alpha) * a.act_gain;
+                if (a.act) v[tn] = epi_act(a.act, v[tn] + row_nz[row] + bia[tn], a.act_alpha) * a.act_gain;
             }
             if constexpr (!WT && TN == 2) {
                 if (a.vecY) {   // the lane's two tiles are adjacent channels: one 8 B store
@@ -635,12 +646,13 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_dma_kernel(ConvArgs a) {
     constexpr int A_STAGE = BM * BK, B_STAGE = BK * BN;          // floats per stage (16 KiB each)
     constexpr int SMAX = 2048;                                   // scale rows of the tile's samples: (samples per tile) * Cin <= SMAX, checked by the host
     // one LDS object: [A0 A1 B0 B1 | scale row | row_pix row_n]
-    __shared__ __attribute__((aligned(1024))) float smem[2 * A_STAGE + 2 * B_STAGE + SMAX + 2 * BM];
+    __shared__ __attribute__((aligned(1024))) float smem[2 * A_STAGE + 2 * B_STAGE + SMAX + 3 * BM];
     float* As = smem;
     float* Bs = smem + 2 * A_STAGE;
     float* s_tab = smem + 2 * A_STAGE + 2 * B_STAGE;
     int* row_pix = reinterpret_cast<int*>(s_tab + SMAX);
     int* row_n = row_pix + BM;
+    float* row_nz = reinterpret_cast<float*>(row_n + BM);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -863,6 +875,7 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_dma_kernel(ConvArgs a) {
         }
         row_pix[tid] = pix;
         row_n[tid] = nn;
+        row_nz[tid] = noise_term(a, pix);
     }
     if constexpr (SC) {   // scale rows of the samples this tile touches (consecutive; their number is bounded by the host)
         const int n_hi = div_small(min(m0 + BM, Mcls) - 1, QH * QW, inv_hw);
@@ -956,7 +969,7 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_dma_kernel(ConvArgs a) {
             float v = acc[tm][0][r] * alpha;
             if (scale && one_sample) v *= mul;
             if (row_scale) v *= a.out_scale[row_n[row] * a.Cout + co];
-            if (a.act) v = epi_act(a.act, v + bia, a.act_alpha) * a.act_gain;
+            if (a.act) v = epi_act(a.act, v + row_nz[row] + bia, a.act_alpha) * a.act_gain;
             out[(size_t)pix * a.Cout + co] = v;
         }
     }
@@ -969,6 +982,7 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_dma_kernel(ConvArgs a) {
 __global__ __launch_bounds__(256) void conv_fixup_kernel(ConvArgs a, int BM, int BN, int RP) {
     __shared__ int row_pix[128];
     __shared__ int row_n[128];
+    __shared__ float row_nz[128];
     const int tid = threadIdx.x;
     const int up = 1 << a.up_shift;
     const int tile = a.full_tiles + blockIdx.x;
@@ -991,6 +1005,7 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(ConvArgs a, int BM, int
         }
         row_pix[tid] = pix;
         row_n[tid] = nn;
+        row_nz[tid] = noise_term(a, pix);
     }
     __syncthreads();
     const float* wst = a.y + (size_t)blockIdx.x * a.splits * (BM * BN);
@@ -1021,7 +1036,7 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(ConvArgs a, int BM, int
             if (co < a.Cout) {
                 float v = v4[e] * a.alpha;
                 if (a.out_scale) v *= a.out_scale[nn * a.Cout + co];
-                if (a.act) v = epi_act(a.act, v + (a.bias ? a.bias[co] : 0.f), a.act_alpha) * a.act_gain;
+                if (a.act) v = epi_act(a.act, v + row_nz[rl] + (a.bias ? a.bias[co] : 0.f), a.act_alpha) * a.act_gain;
                 a.out[(size_t)pix * a.Cout + co] = v;
             }
         }
@@ -1337,6 +1352,7 @@ int fwd_geometry_check(const igan_conv2d_params* p) {
     IGAN_REQUIRE((long long)p->KH * p->KW * p->Cin * p->Cout * 4 <= 0x7FFFFFF0LL, "conv2d: filter too large (2 GiB per operand)");
     IGAN_REQUIRE(p->act >= 0 && p->act <= 3, "conv2d: fused epilogue act must be 0 (none), 1 linear, 2 relu or 3 lrelu");
     IGAN_REQUIRE(p->act == 0 || p->act_gain > 0.0f, "conv2d: fused epilogue gain must be positive");
+    IGAN_REQUIRE(p->noise == nullptr || (p->act != 0 && p->noise_strength != nullptr), "conv2d: noise needs the fused epilogue (act != 0) and a strength scalar");
     return IGAN_OK;
 }
 
@@ -1547,11 +1563,13 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
     IGAN_REQUIRE(p != nullptr, "conv2d: null params");
     if (int rc = fwd_geometry_check(p)) return rc;
     if (is_small_dense(p)) {
+        IGAN_REQUIRE(p->noise == nullptr, "conv2d: the fused noise epilogue is not offered on the small dense path");
         dense_small(stream, p->x, p->w, p->y, p->N, p->Cin, p->Cout, p->w_transposed != 0, p->alpha);
         IGAN_LAUNCH_CHECK("conv2d dense launch");
         return IGAN_OK;
     }
     if (const int kind = thin_conv_kind(p)) {
+        IGAN_REQUIRE(p->noise == nullptr, "conv2d: the fused noise epilogue is not offered on the thin-channel path");
         thin_conv(stream, p, kind);
         IGAN_LAUNCH_CHECK("conv2d thin-channel launch");
         return IGAN_OK;
@@ -1604,6 +1622,7 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
         a.walk = (walk && a.vecA && a.vecB && (a.in_scale == nullptr || a.vecS) && (p->Cin % BK == 0)) ? 1 : 0;
     }
     a.bias = p->bias; a.act = p->act; a.act_alpha = p->act_alpha; a.act_gain = p->act_gain;
+    a.noise = p->act ? p->noise : nullptr; a.noise_strength = p->noise_strength; a.noise_bcast = p->noise_bcast;
 
     dim3 grid(a.full_tiles + (l.T - a.full_tiles) * splits);
     const bool wt = p->w_transposed != 0;

@@ -145,7 +145,7 @@ extern "C" int igan_nn1_update(igan_stream_t stream_, const float* query, const 
     IGAN_REQUIRE(query && qnorm && cand && cnorm && best_d2 && best_idx && dots, "nn1_update: null buffer");
     IGAN_REQUIRE(nq >= 1 && nc >= 1 && dim >= 1, "nn1_update: sizes must be positive");
     IGAN_REQUIRE(idx_base >= 0 && (long long)idx_base + nc <= INT32_MAX, "nn1_update: candidate index overflows int32");
-    igan_conv2d_params p;
+    igan_conv2d_params p{};          // every optional field (epilogue, noise) zero
     p.x = query; p.w = cand; p.y = dots;
     p.in_scale = nullptr; p.out_scale = nullptr;
     p.workspace = nullptr; p.workspace_floats = 0;

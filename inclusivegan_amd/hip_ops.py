@@ -436,7 +436,7 @@ def conv_flops(n, h, w, cin, oh, ow, cout, geom):
     return 2.0 * n * pairs * cin * cout
 
 
-def conv2d_raw(x, w, geom, out_hw, cout, w_transposed=False, in_scale=None, out_scale=None, bias=None, act=None):
+def conv2d_raw(x, w, geom, out_hw, cout, w_transposed=False, in_scale=None, out_scale=None, bias=None, act=None, noise=None, strength=None):
     """x: logical [N,Cin,H,W] (channels_last).  w: HWIO [KH,KW,Cin,Cout] (or the forward layer's
     [KH,KW,Cout,Cin] when w_transposed).  Returns logical [N,Cout,OH,OW] channels_last.
     act = (act_idx, alpha, gain) fuses y = act(y + bias) * gain into the kernel's epilogue (bias may be None)."""
@@ -466,6 +466,12 @@ def conv2d_raw(x, w, geom, out_hw, cout, w_transposed=False, in_scale=None, out_
         w_transposed=1 if w_transposed else 0, splits=1, alpha=float(geom.alpha),
         bias=(bias.data_ptr() if bias is not None else None), act=(int(act[0]) if act is not None else 0),
         act_alpha=(float(act[1]) if act is not None else 0.0), act_gain=(float(act[2]) if act is not None else 1.0))
+    if noise is not None:       # epilogue noise: [N or 1, 1, OH, OW] contiguous + device scalar strength (needs act)
+        noise = noise.contiguous()
+        _require_cuda_f32(noise, strength)
+        if act is None or strength is None or noise.numel() not in (oh * ow, n * oh * ow):
+            raise ValueError('conv2d: noise needs the fused epilogue, a strength scalar and [N or 1, 1, OH, OW] values')
+        p.noise = noise.data_ptr(); p.noise_strength = strength.data_ptr(); p.noise_bcast = 1 if (noise.numel() == oh * ow and n > 1) else 0
     key = (n, h, wd, cin, oh, ow, cout, geom, act is not None, bool(w_transposed), in_scale is not None, out_scale is not None)
     plan = _plan_cache.get(key)
     if plan is None:
@@ -848,6 +854,72 @@ class ModConvGradFn(torch.autograd.Function):
                 gdy2 = y * (g_dd / d)[:, :, None, None]
                 g_dy = gdy2 if g_dy is None else g_dy + gdy2
         return g_dy, g_x, g_w, g_s, g_d, None, None, None, None
+
+
+def bias_act_noise_bwd_dd_raw(dy, y, noise, strength, b, d, act_idx, alpha, gain):
+    """include/igan_hip.h igan_bias_act_noise_bwd_dd: (dx, db, dstrength, dd) of the epilogue fused into a modulated convolution."""
+    lib = _abi.get_plugin()
+    _require_cuda_f32(dy, y, noise, strength, b, d)
+    y = nhwc(y)
+    dy = nhwc(dy)
+    n, c, h, w = y.shape
+    dx = torch.empty_like(y)
+    ws = torch.empty((int(lib.igan_bias_act_noise_dd_workspace_floats(n, h * w, c)),), device=y.device, dtype=torch.float32)
+    db = torch.empty((c,), device=y.device, dtype=torch.float32)
+    ds = torch.empty((), device=y.device, dtype=torch.float32) if noise is not None else None
+    dd = torch.empty((n, c), device=y.device, dtype=torch.float32)
+    bcast = 1 if (noise is not None and noise.numel() == h * w and n > 1) else 0
+    _abi.check(lib.igan_bias_act_noise_bwd_dd(_stream(), _ptr(dy), _ptr(y), _ptr(noise), _ptr(strength), _ptr(b), _ptr(d.contiguous()), _ptr(dx), _ptr(db),
+                                              _ptr(ds), _ptr(dd), _ptr(ws), bcast, n, h * w, c, act_idx, float(alpha), float(gain)))
+    return dx, db, ds, dd
+
+
+class ModConvBanFn(torch.autograd.Function):
+    """y = act(d * conv(x * s, w) + noise * strength + b) * gain: a whole synthesis layer that has no FIR between the convolution and
+    its epilogue (`layer()` with up=False, networks_stylegan2.py:349-357) as one kernel forward -- noise, bias and activation run in
+    the convolution's epilogue, the pre-activation tensor is never written -- and, backward, one pass that turns dy into the
+    gradient w.r.t. the convolution output together with db, dstrength AND the demodulation gradient dd (the pre-activation value
+    is recovered from y: linear / lrelu only), followed by the data / style / weight gradient kernels of ModConv2dFn.
+    First order only: under hip_ops.second_order() the layer is built from ModConv2dFn + BiasActNoiseFn instead."""
+
+    @staticmethod
+    def forward(ctx, x, w, s, d, b, noise, strength, geom, out_hw, act_idx, alpha, gain):
+        _mark_inputs(ctx, x, w, s, d, b, noise, strength, geom, out_hw, act_idx, alpha, gain)
+        y = conv2d_raw(x, w, geom, out_hw, w.shape[3], in_scale=s, out_scale=d, bias=b, act=(act_idx, alpha, gain), noise=noise, strength=strength)
+        ctx.save_for_backward(x, w, s, d, b, noise, strength, y)
+        ctx.geom, ctx.out_hw, ctx.cfg = geom, out_hw, (act_idx, alpha, gain)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if torch.is_grad_enabled():
+            raise NotImplementedError('fused synthesis layer: second-order gradients go through ModConv2dFn + BiasActNoiseFn (hip_ops.second_order())')
+        x, w, s, d, b, noise, strength, y = ctx.saved_tensors
+        act_idx, alpha, gain = ctx.cfg
+        geom = ctx.geom
+        need_x, need_w, need_s, need_d, need_b = [_needed(ctx, i) for i in range(5)]
+        need_st = noise is not None and _needed(ctx, 6)
+        dxp, db, dst, dd = bias_act_noise_bwd_dd_raw(dy, y, noise, strength, b, d, act_idx, alpha, gain)
+        dx = dw = ds = None
+        in_hw = (x.shape[2], x.shape[3])
+        if need_x or need_s:
+            dxs = conv2d_raw(dxp, w, dgrad_geom(geom), in_hw, w.shape[2], w_transposed=True, in_scale=d)
+            ds, dx = scale_dot_raw(x, dxs, s, want_scaled=need_x)
+            if not need_s:
+                ds = None
+        if need_w:
+            dw = conv2d_wgrad_raw(x, dxp, geom, in_scale=s, out_scale=d)
+        return dx, dw, ds, (dd if need_d else None), (db if need_b else None), None, (dst if need_st else None), None, None, None, None, None
+
+
+def modconv_ban_fusable(x, w, d, b, noise, act_idx):
+    """The fused layer applies on the first-order path, with demodulation, a piecewise-linear invertible activation, MFMA-sized
+    channel counts and 16 B paths; everything else takes the two-Function form."""
+    return (_MODCONV_BAN and _second_order_depth == 0 and not _is_meta(x) and x.is_cuda and d is not None and b is not None
+            and act_idx in (1, 3) and x.shape[1] % 32 == 0 and w.shape[3] % 32 == 0 and x.shape[1] >= 32 and w.shape[3] >= 32)
+
+
+_MODCONV_BAN = os.environ.get('IGAN_MODCONV_BAN', '1') != '0'      # A/B switch
 
 
 def modconv_composite(x, w, s, d, geom, out_hw):

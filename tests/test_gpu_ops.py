@@ -737,3 +737,41 @@ def test_autosummary_device_accumulator(cuda_device):
     out = AS.flush()
     assert abs(out['Test/x'] - want_s / want_c) < 1e-12
     assert float(AS._acc['Test/x'].abs().sum()) == 0.0
+
+
+# ----------------------------------------------------------------------------- fused synthesis layer
+@pytest.mark.parametrize('case', [(3, 128, 128, 32, 32, True), (2, 512, 512, 8, 8, True), (4, 64, 96, 16, 16, False), (2, 512, 512, 4, 4, True), (1, 32, 32, 32, 32, True)])
+def test_fused_synthesis_layer_matches_two_step_form(case, cuda_device):
+    """ModConvBanFn (modulated conv with noise + bias + lrelu in its epilogue; backward with the demodulation gradient recovered
+    from the activation output) against ModConv2dFn followed by BiasActNoiseFn -- both pinned to the oracle elsewhere -- for the
+    value and every gradient, on MFMA tiles, sliced small layers (4x4, 8x8: several samples per tile) and shared / per-sample noise."""
+    from inclusivegan_amd import hip_ops
+    N, cin, cout, H, W, per_sample = case
+    g = torch.Generator().manual_seed(cin + H)
+    dev = cuda_device
+    x = (torch.randn(N, cin, H, W, generator=g)).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = (torch.randn(3, 3, cin, cout, generator=g) / np.sqrt(9 * cin)).to(dev).requires_grad_(True)
+    s = (torch.rand(N, cin, generator=g) + 0.5).to(dev).requires_grad_(True)
+    d = (torch.rand(N, cout, generator=g) + 0.5).to(dev).requires_grad_(True)
+    b = (torch.randn(cout, generator=g) * 0.1).to(dev).requires_grad_(True)
+    noise = torch.randn(N if per_sample else 1, 1, H, W, generator=g).to(dev)
+    strength = torch.tensor(0.3, device=dev).requires_grad_(True)
+    dy = torch.randn(N, cout, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    geom = hip_ops.ConvGeom(3, 3, 1, 1, 1, 1, 0.7)
+    gain = float(np.sqrt(2))
+    leaves = [x, w, s, d, b, strength]
+    assert hip_ops.modconv_ban_fusable(x, w, d, b, noise, 3)
+    y1 = hip_ops.ModConvBanFn.apply(x, w, s, d, b, noise, strength, geom, (H, W), 3, 0.2, gain)
+    g1 = torch.autograd.grad(y1, leaves, dy)
+    y0 = hip_ops.ModConv2dFn.apply(x, w, s, d, geom, (H, W))
+    y0 = hip_ops.bias_act_noise(y0, b, noise, strength, 3, 0.2, gain)
+    g0 = torch.autograd.grad(y0, leaves, dy)
+    assert rel_err(y1, y0) < 2e-6
+    for name, a, r in zip(('x', 'w', 's', 'd', 'b', 'strength'), g1, g0):
+        assert rel_err(a, r) < (2e-5 if name == 'd' else 5e-6), name
+    # linear activation (ToRGB-like epilogue) and no gradient wanted for d / strength
+    y2 = hip_ops.ModConvBanFn.apply(x, w, s, d.detach(), b, noise, strength.detach(), geom, (H, W), 1, 0.0, 1.0)
+    (gx2,) = torch.autograd.grad(y2, [x], dy)
+    y3 = hip_ops.bias_act_noise(hip_ops.ModConv2dFn.apply(x, w, s, d.detach(), geom, (H, W)), b, noise, strength.detach(), 1, 0.0, 1.0)
+    (gx3,) = torch.autograd.grad(y3, [x], dy)
+    assert rel_err(y2, y3) < 2e-6 and rel_err(gx2, gx3) < 5e-6
