@@ -316,11 +316,20 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    # Test hooks for boxes with a single GPU (tests/test_gpu_dist.py): IGAN_BENCH_ONE_GPU=1 puts every rank on device 0 and
+    # IGAN_BENCH_BACKEND=gloo swaps RCCL (which needs one device per rank) for gloo -- the launch path, the rank slicing, the
+    # barriers and the max-over-ranks timing are the ones of a real multi-GPU run.
+    if os.environ.get('IGAN_BENCH_ONE_GPU') == '1':
+        local_rank = 0
+    backend = os.environ.get('IGAN_BENCH_BACKEND', 'nccl')
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.distributed.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        if backend == 'nccl':
+            torch.distributed.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        else:
+            torch.distributed.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, '--gpus %d but WORLD_SIZE is %d' % (args.gpus, world)
 
     from inclusivegan_amd import _abi

@@ -89,3 +89,22 @@ def test_two_rank_training_loop_keeps_replicas_identical(cuda_device, tmp_path):
         assert torch.equal(r0[k], r1[k]), k
         assert bool(torch.isfinite(r0[k]).all())
     assert r0['fed'] == r1['fed'] and len(r0['fed']) == 2
+
+
+def test_bench_launches_its_own_ranks(cuda_device):
+    """`python bench.py --gpus 2` with no launcher around it (the way the driver calls it): the parent spawns the ranks through
+    torch.distributed.run before touching the GPU, the ranks run the real loop on their slices and rank 0 prints ONE JSON line with
+    the whole-job rate.  Both ranks share GPU 0 and talk over gloo here (test hooks in bench.py): everything but RCCL itself."""
+    import json
+    env = dict(os.environ, IGAN_BENCH_ONE_GPU='1', IGAN_BENCH_BACKEND='gloo')
+    env.pop('RANK', None); env.pop('WORLD_SIZE', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--no-roofline', '--no-cpu-baseline',
+                        '--resolution', '32', '--minibatch-gpu', '3', '--data-size', '48', '--num-samples-factor', '2'],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 3 and d['warmup'] == 1 and d['scaling'] == 'weak'
+    assert d['config']['global_batch'] == 6 and d['config']['images_per_step'] == 12 and d['config']['parallelism'] == 'dp2'
+    assert d['value'] > 0 and abs(d['value'] - 12 / (d['ms_per_step'] * 1e-3)) < 1e-2 * d['value']
