@@ -191,6 +191,11 @@ def get_plugin():
             raise ImportError(
                 'inclusivegan_amd: %s is missing. Build it with `python -c "import __graft_entry__ as g; g.build()"` '
                 'or `make -C inclusivegan_amd/csrc`. There is no CPU fallback.' % LIB_PATH)
+        # The library's HIP runtime must be the one PyTorch drives (streams and device pointers are handed across): both name
+        # it libamdhip64.so.7, so whichever copy is loaded first serves both -- and it has to be the one PyTorch ships, because
+        # PyTorch loads its own copy by path.  Loading this library first used to leave two runtimes in the process
+        # (every launch then failed with hipErrorNoDevice).
+        import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
         for name, (restype, argtypes) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is absent

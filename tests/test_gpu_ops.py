@@ -5,6 +5,8 @@ max-abs error  max|hip - oracle| / max|oracle|:
     streaming kernels (upfirdn2d, fused_bias_act, mbstd, Adam, EMA): <= 2e-6 .. 1e-5
     MFMA convolutions (K up to ~4600 fp32 FMAs per output):           <= 3e-5
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -775,3 +777,23 @@ def test_fused_synthesis_layer_matches_two_step_form(case, cuda_device):
     y3 = hip_ops.bias_act_noise(hip_ops.ModConv2dFn.apply(x, w, s, d.detach(), geom, (H, W)), b, noise, strength.detach(), 1, 0.0, 1.0)
     (gx3,) = torch.autograd.grad(y3, [x], dy)
     assert rel_err(y2, y3) < 2e-6 and rel_err(gx2, gx3) < 5e-6
+
+
+def test_plugin_first_then_torch_share_one_runtime(cuda_device):
+    """A process that loads libigan_hip.so before it ever imports torch (what `build()` followed by `smoke()` does) must still
+    launch on PyTorch's streams: the binding pulls PyTorch's HIP runtime in first."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ('import sys; sys.path.insert(0, %r)\n'
+            'from inclusivegan_amd import _abi\n'
+            '_abi.get_plugin()\n'
+            'import torch\n'
+            'from inclusivegan_amd import hip_ops\n'
+            'x = torch.randn(4, 64, device="cuda"); w = torch.randn(64, 32, device="cuda")\n'
+            'y = hip_ops.matmul(x, w)\n'
+            'torch.cuda.synchronize()\n'
+            'print("ok", float((y - x @ w).abs().max()))\n') % root
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.startswith('ok'), r.stderr[-2000:]
+    assert float(r.stdout.split()[1]) < 1e-4
