@@ -220,3 +220,52 @@ def test_nn1_near_ties_decided_in_fp64(cuda_device):
     bd, bi = hip_ops.nn1_state(nq, dev)
     hip_ops.nn1_update_raw(qd, qn, cd2, hip_ops.row_sqnorm_raw(cd2), bd, bi, 0)
     assert bool(torch.isfinite(bd).all()) and not bool(((bi == 3) | (bi == 5)).any())
+
+
+@pytest.mark.parametrize('case', [('G 128 Conv1', 6, 128, 128, 128, True), ('G 32 Conv1 (4 calls)', 24, 512, 32, 512, True), ('G 8 Conv1', 24, 512, 8, 512, False)],
+                         ids=lambda c: c[0])
+def test_fused_synthesis_layer_against_fp64_samples_full_size(case, cuda_device):
+    """The one-kernel synthesis layer (modulated 3x3 conv + noise + bias + lrelu, hip_ops.ModConvBanFn) at the bench sizes against
+    fp64 values computed from the definition (networks_stylegan2.py:99-127,349-357) for sampled elements: the forward output, and
+    -- for a few (sample, channel) pairs -- the demodulation gradient dd[n,c] = sum_pixels dx[n,c,p] * z[n,c,p], which the backward
+    kernel obtains by inverting the activation instead of keeping z."""
+    from inclusivegan_amd import hip_ops
+    from oracle import conv_sample as CS
+    name, N, C, H, Cout, per_sample = case
+    g = torch.Generator(device='cpu').manual_seed(len(name) * 71 + N)
+    dev = cuda_device
+    cl = lambda t: t.to(dev).contiguous(memory_format=torch.channels_last)
+    x_c = torch.randn(N, C, H, H, generator=g)
+    w_c = torch.randn(3, 3, C, Cout, generator=g) / (9 * C) ** 0.5
+    s_c = torch.rand(N, C, generator=g) + 0.5
+    d_c = torch.rand(N, Cout, generator=g) + 0.5
+    b_c = torch.randn(Cout, generator=g) * 0.2
+    nz_c = torch.randn(N if per_sample else 1, 1, H, H, generator=g)
+    dy_c = torch.randn(N, Cout, H, H, generator=g)
+    alpha, strength, gain, slope = 0.83, 0.35, float(np.sqrt(2)), 0.2
+    x = cl(x_c).requires_grad_(True)
+    d = d_c.to(dev).requires_grad_(True)
+    st = torch.tensor(strength, device=dev)
+    geom = hip_ops.ConvGeom(3, 3, 1, 1, 1, 1, alpha)
+    y = hip_ops.ModConvBanFn.apply(x, w_c.to(dev), s_c.to(dev), d, b_c.to(dev), nz_c.to(dev), st, geom, (H, H), 3, slope, gain)
+    (gd,) = torch.autograd.grad(y, [d], cl(dy_c))
+    rng = np.random.RandomState(len(name))
+    m = 256
+    i = np.stack([rng.randint(n, size=m) for n in (N, Cout, H, H)], 1)
+    xn, wn, sn, dn = x_c.numpy(), w_c.numpy(), s_c.numpy(), d_c.numpy()
+    conv = CS.forward_samples(xn, wn, i, 1, 1, 1, sn, dn, alpha)                                   # alpha * d * conv(x * s, w), fp64
+    nz = nz_c.numpy().astype(np.float64)
+    pre = conv + nz[i[:, 0] if per_sample else 0, 0, i[:, 2], i[:, 3]] * strength + b_c.numpy().astype(np.float64)[i[:, 1]]
+    want = np.where(pre > 0, pre, pre * slope) * gain
+    got = y.detach().cpu().numpy()[tuple(i.T)].astype(np.float64)
+    assert np.abs(got - want).max() / np.abs(want).max() < 3e-5
+    # dd for three (n, c) pairs: every pixel of that sample and channel in fp64
+    for n, c in ((0, 1), (N - 1, Cout - 1), (N // 2, 7)):
+        hw = np.stack(np.meshgrid(np.arange(H), np.arange(H), indexing='ij'), -1).reshape(-1, 2)
+        idx = np.concatenate([np.full((H * H, 1), n), np.full((H * H, 1), c), hw], 1)
+        z = CS.forward_samples(xn, wn, idx, 1, 1, 1, sn, None, alpha)                               # un-demodulated output
+        pre = z * float(dn[n, c]) + nz[n if per_sample else 0, 0].reshape(-1) * strength + float(b_c[c])
+        dpre = dy_c.numpy()[n, c].reshape(-1).astype(np.float64) * np.where(pre > 0, 1.0, slope) * gain
+        want_dd = float((dpre * z).sum())
+        scale = float(np.abs(dpre * z).sum())
+        assert abs(float(gd[n, c]) - want_dd) < 2e-5 * scale, (name, n, c, float(gd[n, c]), want_dd)
