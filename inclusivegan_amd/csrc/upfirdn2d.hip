@@ -30,6 +30,7 @@ struct UpfirdnArgs {
     int majorDim, inH, inW, minorDim;
     int kernelH, kernelW;
     int outH, outW;
+    int xcd_remap;          // XCD-aware block order in the FIR fast path (A/B switch IGAN_FIR_XCD)
 };
 
 __host__ __device__ __forceinline__ int floor_div(int a, int b) {
@@ -86,7 +87,15 @@ __global__ __launch_bounds__(256) void upfirdn2d_fir4_kernel(UpfirdnArgs a, FirT
     const int strips = (a.outH + TY - 1) / TY;
     const int xgroups = (a.outW + TX - 1) / TX;
     const long long total = (long long)a.majorDim * strips * xgroups * cvecs;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    // XCD-aware block order (as in conv2d_mfma.hip): workgroups are dealt round-robin to the 8 XCDs, so with the plain order the
+    // blocks that share halo rows (neighbouring strips) sit on eight different L2s and every halo row is fetched from HBM twice;
+    // here XCD x works through one contiguous range of logical blocks.  Placement only: no result depends on it.
+    int bid = blockIdx.x;
+    if (a.xcd_remap) {
+        const int n = gridDim.x, q = n >> 3, r = n & 7, x = bid & 7;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+    }
+    const long long idx = (long long)bid * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     long long t = idx;
     const int cv = (int)(t % cvecs); t /= cvecs;
@@ -175,6 +184,8 @@ extern "C" int igan_upfirdn2d(igan_stream_t stream_, const igan_upfirdn2d_params
     a.majorDim = p->majorDim; a.inH = p->inH; a.inW = p->inW; a.minorDim = p->minorDim;
     a.kernelH = p->kernelH; a.kernelW = p->kernelW;
     a.outH = outH; a.outW = outW;
+    static const bool fir_xcd = !(getenv("IGAN_FIR_XCD") && atoi(getenv("IGAN_FIR_XCD")) == 0);     // A/B switch
+    a.xcd_remap = fir_xcd ? 1 : 0;
 
     const bool aligned = (((uintptr_t)p->x | (uintptr_t)p->y) & 15) == 0;
     const bool fast = p->upx == 1 && p->upy == 1 && p->downx == 1 && p->downy == 1 &&
