@@ -221,6 +221,96 @@ __global__ __launch_bounds__(256) void thin_in_kernel(ThinArgs a, int cg, int cb
     }
 }
 
+// ---- thin_in, 3x3 (VGG conv1_1: 3 -> 64): sliding window along x ----------------------------------
+// A lane owns 4 output channels and walks a run of RUN output pixels of one row; its 3 x 3 x CIN input window lives in registers
+// and moves one column per pixel (9 loads per pixel instead of 27, the three column buffers rotate through an unroll by three
+// instead of being copied), the 27 weight vectors stay in registers.  The cg lanes of a pixel group read the same addresses
+// (one broadcast request); their float4 outputs are one contiguous row segment.
+template <int CIN>
+__global__ __launch_bounds__(256) void thin_in3x3_kernel(ThinArgs a, int cg, int run, int runs_per_row) {
+    const int lane = threadIdx.x & 63;
+    const int lc = lane % cg, sub = lane / cg, ppw = 64 / cg;
+    const int gwave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * 256) >> 6;
+    const int co = 4 * lc;
+    const long long total_runs = (long long)a.N * a.OH * runs_per_row;
+    float4 wr[9][CIN];
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int ci = 0; ci < CIN; ci++) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (co < a.Cout) {
+                const int ky = t / 3, kx = t - ky * 3;
+                if (a.wt) {
+                    const float* b = a.w + ((size_t)((2 - ky) * 3 + (2 - kx)) * a.Cout + co) * CIN + ci;
+                    v = make_float4(b[0], b[CIN], b[2 * CIN], b[3 * CIN]);
+                } else {
+                    v = *reinterpret_cast<const float4*>(a.w + ((size_t)t * CIN + ci) * a.Cout + co);
+                }
+            }
+            wr[t][ci] = v;
+        }
+    for (long long rr = (long long)gwave * ppw + sub; rr < total_runs; rr += (long long)nwaves * ppw) {
+        const int xr = (int)(rr % runs_per_row);
+        const long long row = rr / runs_per_row;
+        const int oy = (int)(row % a.OH);
+        const int n = (int)(row / a.OH);
+        const int x0 = xr * run, x1 = min(x0 + run, a.OW);
+        const float* rowp[3];
+        bool rowok[3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++) {
+            const int iy = oy + ky - a.pad_y;
+            rowok[ky] = (unsigned)iy < (unsigned)a.H;
+            rowp[ky] = a.x + ((size_t)(n * a.H + (rowok[ky] ? iy : 0)) * a.W) * CIN;
+        }
+        float c0[3][CIN], c1[3][CIN], c2[3][CIN];
+        auto load_col = [&](float (&c)[3][CIN], int ix) {
+            const bool ok = (unsigned)ix < (unsigned)a.W;
+#pragma unroll
+            for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                for (int ci = 0; ci < CIN; ci++) c[ky][ci] = (ok && rowok[ky]) ? rowp[ky][(size_t)ix * CIN + ci] : 0.f;
+        };
+        auto emit = [&](const float (&k0)[3][CIN], const float (&k1)[3][CIN], const float (&k2)[3][CIN], int ox) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                for (int ci = 0; ci < CIN; ci++) {
+                    const float v0 = k0[ky][ci], v1 = k1[ky][ci], v2 = k2[ky][ci];
+                    const float4 w0 = wr[ky * 3 + 0][ci], w1 = wr[ky * 3 + 1][ci], w2 = wr[ky * 3 + 2][ci];
+                    acc.x = fmaf(v0, w0.x, acc.x); acc.y = fmaf(v0, w0.y, acc.y); acc.z = fmaf(v0, w0.z, acc.z); acc.w = fmaf(v0, w0.w, acc.w);
+                    acc.x = fmaf(v1, w1.x, acc.x); acc.y = fmaf(v1, w1.y, acc.y); acc.z = fmaf(v1, w1.z, acc.z); acc.w = fmaf(v1, w1.w, acc.w);
+                    acc.x = fmaf(v2, w2.x, acc.x); acc.y = fmaf(v2, w2.y, acc.y); acc.z = fmaf(v2, w2.z, acc.z); acc.w = fmaf(v2, w2.w, acc.w);
+                }
+            if (co < a.Cout) {
+                float4 v = make_float4(acc.x * a.alpha, acc.y * a.alpha, acc.z * a.alpha, acc.w * a.alpha);
+                if (a.out_scale) {
+                    const float4 sc = *reinterpret_cast<const float4*>(a.out_scale + (size_t)n * a.Cout + co);
+                    v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
+                }
+                *reinterpret_cast<float4*>(a.y + ((size_t)(n * a.OH + oy) * a.OW + ox) * a.Cout + co) = v;
+            }
+        };
+        load_col(c0, x0 - a.pad_x);
+        load_col(c1, x0 + 1 - a.pad_x);
+        for (int ox = x0; ox < x1; ox += 3) {          // three pixels per trip: the column buffers rotate, nothing is copied
+            load_col(c2, ox + 2 - a.pad_x);
+            emit(c0, c1, c2, ox);
+            if (ox + 1 < x1) {
+                load_col(c0, ox + 3 - a.pad_x);
+                emit(c1, c2, c0, ox + 1);
+            }
+            if (ox + 2 < x1) {
+                load_col(c1, ox + 4 - a.pad_x);
+                emit(c2, c0, c1, ox + 2);
+            }
+        }
+    }
+}
+
 // ---- thin_wgrad (1x1, stride 1): partial[block][c][t] = scale[n][c] * sum_{pixels of the block} wide[pix][c] * thin[pix][t]
 struct ThinWgArgs {
     const float* wide;      // [N, HW, C]
@@ -354,8 +444,14 @@ void thin_conv(hipStream_t stream, const igan_conv2d_params* p, int kind) {
         else if (taps == 1) hipLaunchKernelGGL((thin_out_kernel<1, 1>), dim3(std::max(grid, 1)), dim3(256), 0, stream, a, gw);
         else hipLaunchKernelGGL((thin_out_kernel<9, 1>), dim3(std::max(grid, 1)), dim3(256), 0, stream, a, gw);
     } else {
+        static const bool slide = !(getenv("IGAN_THIN_SLIDE") && atoi(getenv("IGAN_THIN_SLIDE")) == 0);      // A/B switch
         if (taps == 1) hipLaunchKernelGGL((thin_in_kernel<1>), dim3(std::max(grid, 1)), dim3(256), 0, stream, a, gw, cblocks);
-        else hipLaunchKernelGGL((thin_in_kernel<9>), dim3(std::max(grid, 1)), dim3(256), 0, stream, a, gw, cblocks);
+        else if (slide && p->Cin == 3 && cblocks == 1 && p->OW >= 16) {      // 3x3 from 3 channels: sliding window along x
+            const int run = 32, runs_per_row = ceil_div(p->OW, run);
+            const long long runs = (long long)p->N * p->OH * runs_per_row;
+            const int g = (int)std::min<long long>(ceil_div_ll(runs, 4LL * ppw), 256 * 8);
+            hipLaunchKernelGGL((thin_in3x3_kernel<3>), dim3(std::max(g, 1)), dim3(256), 0, stream, a, gw, run, runs_per_row);
+        } else hipLaunchKernelGGL((thin_in_kernel<9>), dim3(std::max(grid, 1)), dim3(256), 0, stream, a, gw, cblocks);
     }
 }
 
