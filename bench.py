@@ -393,7 +393,9 @@ def main():
                    **({'op_times': state.setdefault('op_times', {})} if args.op_times else {})),
     )
     log('starting training loop')
-    TL.training_loop(**kwargs)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):      # the loop's tick lines and layer tables go to stderr: stdout carries the ONE JSON line
+        TL.training_loop(**kwargs)
     log('timed region done')
 
     elapsed = torch.tensor([state['t_end'] - state['t_start']], device=device, dtype=torch.float64)
