@@ -75,6 +75,12 @@ typedef struct igan_upfirdn2d_params {
 } igan_upfirdn2d_params;
 
 int igan_upfirdn2d(igan_stream_t stream, const igan_upfirdn2d_params* p);
+/* The same with the synthesis layer's epilogue fused into the store (layers whose FIR sits between the up-convolution and the
+ * bias, networks_stylegan2.py:349-357 with up=True):  y = act(upfirdn(x) + noise[m, oy, ox] * strength[0] + bias[c]) * gain,
+ * act in {1 linear, 2 relu, 3 lrelu} as igan_bias_act_noise_*; noise [majorDim or 1 (noise_bcast), outH, outW] or NULL with
+ * strength.  Offered on the FIR fast path only (up = down = 1, taps <= 4x4, minorDim % 4 == 0); IGAN_ERR_UNSUPPORTED otherwise. */
+int igan_upfirdn2d_ban(igan_stream_t stream, const igan_upfirdn2d_params* p, const float* noise, const float* strength,
+                       int noise_bcast, const float* bias, int act, float alpha, float gain);
 
 /* ------------------------------------------------------------------------
  * fused_bias_act: y = act(x + b[(i / stepB) % sizeB]) * gain  (grad == 0) and its

@@ -127,6 +127,7 @@ SIGNATURES = {
     'igan_struct_size': (_SZ, [_I]),
     'igan_last_error': (ctypes.c_char_p, []),
     'igan_upfirdn2d': (_I, [_P, ctypes.POINTER(UpFirDn2DParams)]),
+    'igan_upfirdn2d_ban': (_I, [_P, _P, _P, _P, _I, _P, _I, _F, _F]),
     'igan_fused_bias_act': (_I, [_P, ctypes.POINTER(FusedBiasActParams)]),
     'igan_bias_grad_workspace_floats': (_SZ, [_I, _I, _I]),
     'igan_bias_grad': (_I, [_P, _P, _P, _P, _I, _I, _I]),

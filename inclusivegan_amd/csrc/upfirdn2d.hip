@@ -31,6 +31,12 @@ struct UpfirdnArgs {
     int kernelH, kernelW;
     int outH, outW;
     int xcd_remap;          // XCD-aware block order in the FIR fast path (A/B switch IGAN_FIR_XCD)
+    // optional epilogue of the FIR fast path (igan_upfirdn2d_ban): y = act(fir + noise[m, oy, ox] * strength + bias[c]) * gain
+    const float* noise;
+    const float* strength;
+    const float* bias;
+    int noise_bcast, act;
+    float act_alpha, act_gain;
 };
 
 __host__ __device__ __forceinline__ int floor_div(int a, int b) {
@@ -79,7 +85,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_generic_kernel(UpfirdnArgs a, F
 
 // Fast path: up = down = 1, taps zero-extended to 4x4, minorDim % 4 == 0.
 //   y[m,oy,ox,c] = sum_{ky,kx<4} x[m, oy+ky-pady0, ox+kx-padx0, c] * kf[ky][kx]
-template <int TY, int TX>
+template <int TY, int TX, bool EPI = false>
 __global__ __launch_bounds__(256) void upfirdn2d_fir4_kernel(UpfirdnArgs a, FirTaps taps) {
     // a lane owns TY output rows x TX adjacent output columns of one channel quad: (TY+3) x (TX+3) input loads feed
     // TY*TX outputs (5.5 loads per output at 8x1, 3.4 at 8x2: the kernel is L1-request bound, not HBM bound)
@@ -143,20 +149,62 @@ __global__ __launch_bounds__(256) void upfirdn2d_fir4_kernel(UpfirdnArgs a, FirT
     }
 
     float4* ybase = reinterpret_cast<float4*>(a.y) + (long long)m * a.outH * a.outW * cvecs + cv;
+    float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+    float st = 0.f;
+    if constexpr (EPI) {
+        if (a.bias) bb = *reinterpret_cast<const float4*>(a.bias + 4 * cv);
+        if (a.noise) st = a.strength[0];
+    }
 #pragma unroll
     for (int i = 0; i < TY; i++) {
         const int oy = oy0 + i;
 #pragma unroll
         for (int j = 0; j < TX; j++)
-            if (oy < a.outH && ox0 + j < a.outW) ybase[((long long)oy * a.outW + ox0 + j) * cvecs] = acc[i][j];
+            if (oy < a.outH && ox0 + j < a.outW) {
+                float4 v = acc[i][j];
+                if constexpr (EPI) {    // the layer epilogue that follows the FIR (networks_stylegan2.py:351-357)
+                    const float nz = a.noise ? a.noise[((long long)(a.noise_bcast ? 0 : m) * a.outH + oy) * a.outW + ox0 + j] * st : 0.f;
+                    const float e[4] = {v.x + nz + bb.x, v.y + nz + bb.y, v.z + nz + bb.z, v.w + nz + bb.w};
+                    float o[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        float t = e[q];
+                        if (a.act == 2) t = t > 0.f ? t : 0.f;
+                        if (a.act == 3) t = t > 0.f ? t : t * a.act_alpha;
+                        o[q] = t * a.act_gain;
+                    }
+                    v = make_float4(o[0], o[1], o[2], o[3]);
+                }
+                ybase[((long long)oy * a.outW + ox0 + j) * cvecs] = v;
+            }
     }
 }
 
 }  // namespace
 
+namespace {
+struct FirEpilogue { const float* noise; const float* strength; const float* bias; int noise_bcast, act; float alpha, gain; };
+int upfirdn_launch(hipStream_t stream, const igan_upfirdn2d_params* p, const FirEpilogue* epi);
+}  // namespace
+
 extern "C" int igan_upfirdn2d(igan_stream_t stream_, const igan_upfirdn2d_params* p) {
+    return upfirdn_launch((hipStream_t)stream_, p, nullptr);
+}
+
+extern "C" int igan_upfirdn2d_ban(igan_stream_t stream_, const igan_upfirdn2d_params* p, const float* noise, const float* strength,
+                                  int noise_bcast, const float* bias, int act, float alpha, float gain) {
     using namespace igan;
-    hipStream_t stream = (hipStream_t)stream_;
+    IGAN_REQUIRE(act >= 1 && act <= 3, "upfirdn2d_ban: act must be 1 (linear), 2 (relu) or 3 (lrelu)");
+    IGAN_REQUIRE(gain > 0.0f, "upfirdn2d_ban: gain must be positive");
+    IGAN_REQUIRE((noise == nullptr) == (strength == nullptr), "upfirdn2d_ban: noise and strength go together");
+    IGAN_REQUIRE(((uintptr_t)bias & 15) == 0, "upfirdn2d_ban: bias must be 16-byte aligned");
+    FirEpilogue e{noise, strength, bias, noise_bcast, act, alpha, gain};
+    return upfirdn_launch((hipStream_t)stream_, p, &e);
+}
+
+namespace {
+int upfirdn_launch(hipStream_t stream, const igan_upfirdn2d_params* p, const FirEpilogue* epi) {
+    using namespace igan;
     IGAN_REQUIRE(p != nullptr, "upfirdn2d: null params");
     IGAN_REQUIRE(p->x && p->k && p->y, "upfirdn2d: null buffer");
     // upfirdn_2d.cu:228-229
@@ -186,6 +234,9 @@ extern "C" int igan_upfirdn2d(igan_stream_t stream_, const igan_upfirdn2d_params
     a.outH = outH; a.outW = outW;
     static const bool fir_xcd = !(getenv("IGAN_FIR_XCD") && atoi(getenv("IGAN_FIR_XCD")) == 0);     // A/B switch
     a.xcd_remap = fir_xcd ? 1 : 0;
+    a.noise = epi ? epi->noise : nullptr; a.strength = epi ? epi->strength : nullptr; a.bias = epi ? epi->bias : nullptr;
+    a.noise_bcast = epi ? epi->noise_bcast : 0; a.act = epi ? epi->act : 0;
+    a.act_alpha = epi ? epi->alpha : 0.f; a.act_gain = epi ? epi->gain : 1.f;
 
     const bool aligned = (((uintptr_t)p->x | (uintptr_t)p->y) & 15) == 0;
     const bool fast = p->upx == 1 && p->upy == 1 && p->downx == 1 && p->downy == 1 &&
@@ -201,15 +252,19 @@ extern "C" int igan_upfirdn2d(igan_stream_t stream_, const igan_upfirdn2d_params
         static const int tx = getenv("IGAN_FIR_TX") ? atoi(getenv("IGAN_FIR_TX")) : 2;   // A/B switch
         if (outH >= 8 && outW >= 16 && tx >= 2) {        // 8x2 outputs per lane (8x4 and 4x4 were slower: registers)
             const long long total = (long long)p->majorDim * ceil_div(outH, 8) * ceil_div(outW, 2) * cvecs;
-            hipLaunchKernelGGL((upfirdn2d_fir4_kernel<8, 2>), dim3((int)ceil_div_ll(total, 256)), dim3(256), 0, stream, a, taps);
+            if (epi) hipLaunchKernelGGL((upfirdn2d_fir4_kernel<8, 2, true>), dim3((int)ceil_div_ll(total, 256)), dim3(256), 0, stream, a, taps);
+            else hipLaunchKernelGGL((upfirdn2d_fir4_kernel<8, 2>), dim3((int)ceil_div_ll(total, 256)), dim3(256), 0, stream, a, taps);
         } else if (outH >= 8) {
             const long long total = (long long)p->majorDim * ceil_div(outH, 8) * outW * cvecs;
-            hipLaunchKernelGGL((upfirdn2d_fir4_kernel<8, 1>), dim3((int)ceil_div_ll(total, 256)), dim3(256), 0, stream, a, taps);
+            if (epi) hipLaunchKernelGGL((upfirdn2d_fir4_kernel<8, 1, true>), dim3((int)ceil_div_ll(total, 256)), dim3(256), 0, stream, a, taps);
+            else hipLaunchKernelGGL((upfirdn2d_fir4_kernel<8, 1>), dim3((int)ceil_div_ll(total, 256)), dim3(256), 0, stream, a, taps);
         } else {
             const long long total = (long long)p->majorDim * ceil_div(outH, 2) * outW * cvecs;
-            hipLaunchKernelGGL((upfirdn2d_fir4_kernel<2, 1>), dim3((int)ceil_div_ll(total, 256)), dim3(256), 0, stream, a, taps);
+            if (epi) hipLaunchKernelGGL((upfirdn2d_fir4_kernel<2, 1, true>), dim3((int)ceil_div_ll(total, 256)), dim3(256), 0, stream, a, taps);
+            else hipLaunchKernelGGL((upfirdn2d_fir4_kernel<2, 1>), dim3((int)ceil_div_ll(total, 256)), dim3(256), 0, stream, a, taps);
         }
     } else {
+        if (epi) return fail(IGAN_ERR_UNSUPPORTED, "upfirdn2d_ban: the epilogue rides on the FIR fast path only (up = down = 1, taps <= 4x4, minorDim %% 4 == 0, 16-byte aligned)");
         for (int ky = 0; ky < p->kernelH; ky++)
             for (int kx = 0; kx < p->kernelW; kx++)
                 taps.k[ky * p->kernelW + kx] = p->k[(p->kernelH - 1 - ky) * p->kernelW + (p->kernelW - 1 - kx)];
@@ -219,3 +274,4 @@ extern "C" int igan_upfirdn2d(igan_stream_t stream_, const igan_upfirdn2d_params
     IGAN_LAUNCH_CHECK("upfirdn2d launch");
     return IGAN_OK;
 }
+}  // namespace

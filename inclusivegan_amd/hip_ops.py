@@ -92,8 +92,10 @@ def empty_nchw(n, c, h, w, like):
 # ----------------------------------------------------------------------------
 # upfirdn2d
 
-def upfirdn2d_raw(x, k, upx, upy, downx, downy, padx0, padx1, pady0, pady1):
-    """x: [majorDim, inH, inW, minorDim] dense.  k: host float32 [kH, kW]."""
+def upfirdn2d_raw(x, k, upx, upy, downx, downy, padx0, padx1, pady0, pady1, epilogue=None):
+    """x: [majorDim, inH, inW, minorDim] dense.  k: host float32 [kH, kW].
+    epilogue = (noise [majorDim or 1, outH, outW] or None, strength, bias [minorDim] or None, act_idx, alpha, gain): the layer epilogue
+    fused into the FIR's store (igan_upfirdn2d_ban; FIR fast path only)."""
     k = np.ascontiguousarray(k, dtype=np.float32)
     if k.ndim != 2:
         raise ValueError('kernel must have rank 2')
@@ -117,8 +119,67 @@ def upfirdn2d_raw(x, k, upx, upy, downx, downy, padx0, padx1, pady0, pady1):
         padx0=padx0, padx1=padx1, pady0=pady0, pady1=pady1,
         majorDim=major, inH=in_h, inW=in_w, minorDim=minor,
         kernelH=kh, kernelW=kw, outH=out_h, outW=out_w)
+    if epilogue is not None:
+        noise, strength, bias, act_idx, alpha, gain = epilogue
+        _require_cuda_f32(noise, strength, bias)
+        if noise is not None:
+            noise = noise.contiguous()
+            if noise.numel() not in (out_h * out_w, major * out_h * out_w):
+                raise ValueError('upfirdn2d epilogue: noise must hold [majorDim or 1, outH, outW] values')
+        bcast = 1 if (noise is not None and noise.numel() == out_h * out_w and major > 1) else 0
+        _abi.check(lib.igan_upfirdn2d_ban(_stream(), ctypes.byref(p), _ptr(noise), _ptr(strength if noise is not None else None), bcast,
+                                          _ptr(bias.contiguous() if bias is not None else None), int(act_idx), float(alpha), float(gain)))
+        return y
     _abi.check(lib.igan_upfirdn2d(_stream(), ctypes.byref(p)))
     return y
+
+
+def fir_ban_fusable(x, k, act_idx):
+    """FIR (pad only, <= 4x4 taps) + noise + bias + activation in one pass: first-order path, channel-minor data with C % 4 == 0."""
+    k = np.asarray(k)
+    return (_FIR_BAN and _second_order_depth == 0 and not _is_meta(x) and x.is_cuda and x.dim() == 4 and x.shape[1] % 4 == 0
+            and act_idx in (1, 2, 3) and k.ndim == 2 and k.shape[0] <= 4 and k.shape[1] <= 4)
+
+
+_FIR_BAN = os.environ.get('IGAN_FIR_BAN', '1') != '0'      # A/B switch
+
+
+class FirBanFn(torch.autograd.Function):
+    """y = act(fir(x; k, pad) + noise * strength + b) * gain on logical-NCHW channels_last tensors: the FIR that follows an
+    up-convolution together with the layer's epilogue (networks_stylegan2.py:349-357 with up=True) as one pass -- the filtered,
+    pre-activation tensor is never written.  Backward: the one-pass epilogue gradient (dx_pre, db, dstrength), then the FIR's own
+    gradient (the same op with the flipped filter, upfirdn_2d.py:123-128).  First order only (see fir_ban_fusable)."""
+
+    @staticmethod
+    def forward(ctx, x, k, pad0, pad1, b, noise, strength, act_idx, alpha, gain):
+        _mark_inputs(ctx, x, k, pad0, pad1, b, noise, strength, act_idx, alpha, gain)
+        k = np.asarray(k, dtype=np.float32)
+        xh = nhwc(x).permute(0, 2, 3, 1)                                  # [N, H, W, C] dense view
+        y = upfirdn2d_raw(xh, k, 1, 1, 1, 1, pad0, pad1, pad0, pad1, epilogue=(noise, strength, b, act_idx, alpha, gain))
+        in_h, in_w = xh.shape[1], xh.shape[2]
+        out_h, out_w = y.shape[1], y.shape[2]
+        kh, kw = k.shape
+        ctx.gargs = (np.ascontiguousarray(k[::-1, ::-1]), 1, 1, 1, 1, kw - pad0 - 1, in_w - out_w + pad0, kh - pad0 - 1, in_h - out_h + pad0)
+        y = y.permute(0, 3, 1, 2)                                         # logical NCHW, channels_last strides
+        ctx.save_for_backward(y, noise)
+        ctx.cfg = (act_idx, alpha, gain)
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if torch.is_grad_enabled():
+            raise NotImplementedError('fused FIR + epilogue: second-order gradients go through UpFirDn2dFn + BiasActNoiseFn (hip_ops.second_order())')
+        y, noise = ctx.saved_tensors
+        act_idx, alpha, gain = ctx.cfg
+        need_b = ctx.has_b and _needed(ctx, 4)
+        need_s = noise is not None and _needed(ctx, 6)
+        nz = noise.expand(_noise_view(y)).contiguous() if noise is not None else None
+        dxp, db, ds = bias_act_noise_bwd_raw(dy, y, nz, act_idx, alpha, gain, need_b)
+        dx = None
+        if _needed(ctx, 0):
+            dx = upfirdn2d_raw(nhwc(dxp).permute(0, 2, 3, 1), *ctx.gargs).permute(0, 3, 1, 2)
+        return dx, None, None, None, (db if need_b else None), None, (ds if need_s else None), None, None, None
 
 
 class UpFirDn2dFn(torch.autograd.Function):

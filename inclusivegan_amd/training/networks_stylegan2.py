@@ -169,7 +169,7 @@ def _precompute_styles(specs, dlatents, init_mul):
 # Modulated convolution layer (:89-127).
 
 def modulated_conv2d_layer(x, y, fmaps, kernel, up=False, down=False, demodulate=True, resample_kernel=None, gain=1, use_wscale=True, lrmul=1, fused_modconv=True, weight_var='weight', mod_weight_var='mod_weight', mod_bias_var='mod_bias', init_mul=1.0, epilogue=None):
-    """`epilogue=dict(act=, noise=)` (stride-1 layers only) asks for the whole synthesis layer -- convolution, noise * noise_strength,
+    """`epilogue=dict(act=, noise=)` (stride-1 and up-sampling layers) asks for the whole synthesis layer -- convolution, noise * noise_strength,
     bias, activation (:349-357), variables created in the reference's order -- from one kernel where that form applies
     (hip_ops.ModConvBanFn), from the convolution + the fused epilogue pass otherwise."""
     assert not (up and down)
@@ -206,6 +206,19 @@ def modulated_conv2d_layer(x, y, fmaps, kernel, up=False, down=False, demodulate
         from ..dnnlib.tflib.ops.upfirdn_2d import _setup_kernel, _simple_upfirdn_2d
         k = _setup_kernel(resample_kernel if resample_kernel is not None else [1, 1]) * 4.0
         p = (k.shape[0] - 2) - (kernel - 1)
+        if epilogue is not None:
+            # the FIR and the layer epilogue (noise, bias, activation) as one pass over the up-sampled tensor
+            from ..dnnlib.tflib.ops.fused_bias_act import activation_funcs
+            spec = activation_funcs[epilogue['act']]
+            noise = epilogue['noise']
+            noise_strength = get_variable('noise_strength', shape=[], initializer=('zeros',))
+            b = get_variable('bias', shape=[fmaps], initializer=('zeros',))
+            if hip_ops.fir_ban_fusable(x, k, spec.hip_idx):
+                return hip_ops.FirBanFn.apply(x, k, (p+1)//2+2-1, p//2+1, b, noise, noise_strength, spec.hip_idx, spec.def_alpha or 0.0, spec.def_gain)
+            x = _simple_upfirdn_2d(x, k, pad0=(p+1)//2+2-1, pad1=p//2+1, data_format='NCHW')
+            if spec.hip_idx in (1, 2, 3):
+                return hip_ops.bias_act_noise(x, b, noise, noise_strength, spec.hip_idx, spec.def_alpha or 0.0, spec.def_gain)
+            return fused_bias_act(x + noise * noise_strength, b=b, act=epilogue['act'])
         x = _simple_upfirdn_2d(x, k, pad0=(p+1)//2+2-1, pad1=p//2+1, data_format='NCHW')
     elif down:
         from ..dnnlib.tflib.ops.upfirdn_2d import _setup_kernel, _simple_upfirdn_2d
@@ -445,17 +458,11 @@ def G_synthesis_stylegan2(
     # Single convolution layer with all the bells and whistles (:349-357).
     def layer(x, layer_idx, fmaps, kernel, up=False):
         noise = fresh_noise[layer_idx] if randomize_noise else noise_inputs[layer_idx]
-        if not up:
-            # no FIR between the convolution and its epilogue: noise, bias and activation run inside the convolution kernel
-            # (same variables in the same order: weight, [mod_weight, mod_bias], noise_strength, bias)
-            return modulated_conv2d_layer(x, dlatents_in[layer_idx], fmaps=fmaps, kernel=kernel, resample_kernel=resample_kernel, fused_modconv=fused_modconv,
-                                          init_mul=init_mul, epilogue=dict(act=act, noise=noise))
-        x = modulated_conv2d_layer(x, dlatents_in[layer_idx], fmaps=fmaps, kernel=kernel, up=up, resample_kernel=resample_kernel, fused_modconv=fused_modconv, init_mul=init_mul)
-        if randomize_noise:
-            assert tuple(noise.shape[2:]) == tuple(int(d) for d in x.shape[2:])
-        noise_strength = get_variable('noise_strength', shape=[], initializer=('zeros',))
-        # x += noise * noise_strength; apply_bias_act(x, act)  (:356-357) as one fused pass
-        return apply_bias_act(x, act=act, noise=noise, noise_strength=noise_strength)
+        # noise, bias and activation ride on the layer's last pass over the activations: the convolution's own epilogue, or -- for
+        # up-sampling layers -- the FIR that follows the transposed convolution (same variables in the same order: weight,
+        # [mod_weight, mod_bias], noise_strength, bias)
+        return modulated_conv2d_layer(x, dlatents_in[layer_idx], fmaps=fmaps, kernel=kernel, up=up, resample_kernel=resample_kernel, fused_modconv=fused_modconv,
+                                      init_mul=init_mul, epilogue=dict(act=act, noise=noise))
 
     # Building blocks for main layers (:360-377).
     def block(x, res): # res = 3..resolution_log2

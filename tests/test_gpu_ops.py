@@ -797,3 +797,31 @@ def test_plugin_first_then_torch_share_one_runtime(cuda_device):
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.startswith('ok'), r.stderr[-2000:]
     assert float(r.stdout.split()[1]) < 1e-4
+
+
+@pytest.mark.parametrize('case', [(3, 64, 33, 33, True, 3), (2, 128, 17, 9, False, 3), (2, 32, 9, 9, True, 1), (1, 8, 5, 7, True, 2)])
+def test_fir_with_fused_epilogue_matches_two_step_form(case, cuda_device):
+    """FirBanFn (the FIR after an up-convolution with noise + bias + activation in its store) against upfirdn_2d followed by
+    BiasActNoiseFn -- each pinned to the oracle by its own tests: same values bit for bit (same arithmetic in the same order),
+    same gradients."""
+    from inclusivegan_amd import hip_ops
+    from inclusivegan_amd.dnnlib.tflib.ops.upfirdn_2d import _setup_kernel, _simple_upfirdn_2d
+    N, C, H, W, per_sample, act = case
+    g = torch.Generator().manual_seed(C + H)
+    dev = cuda_device
+    k = _setup_kernel([1, 3, 3, 1]) * 4.0
+    pad0, pad1 = 1, 1                                                   # the post-up-conv filter: out = in - 1
+    x = torch.randn(N, C, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    b = (torch.randn(C, generator=g) * 0.2).to(dev).requires_grad_(True)
+    noise = torch.randn(N if per_sample else 1, 1, H - 1, W - 1, generator=g).to(dev)
+    strength = torch.tensor(0.4, device=dev).requires_grad_(True)
+    dy = torch.randn(N, C, H - 1, W - 1, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    gain = float(np.sqrt(2)) if act == 3 else 1.0
+    assert hip_ops.fir_ban_fusable(x, k, act)
+    y1 = hip_ops.FirBanFn.apply(x, k, pad0, pad1, b, noise, strength, act, 0.2, gain)
+    g1 = torch.autograd.grad(y1, [x, b, strength], dy)
+    y0 = hip_ops.bias_act_noise(_simple_upfirdn_2d(x, k, pad0=pad0, pad1=pad1, data_format='NCHW'), b, noise, strength, act, 0.2, gain)
+    g0 = torch.autograd.grad(y0, [x, b, strength], dy)
+    assert tuple(y1.shape) == (N, C, H - 1, W - 1) and torch.equal(y1, y0)
+    for a, r in zip(g1, g0):
+        assert torch.equal(a, r)
