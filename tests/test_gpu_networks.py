@@ -481,3 +481,37 @@ def test_generator_and_discriminator_at_128_full_config(cuda_device):
         s, _ = D.get_output_for(x, torch.zeros(2, 0, device=dev), is_training=True)
         so, _ = ON.D_stylegan2_feature(_oracle_params(D), x.double().cpu(), 128, fmap_base=8192, architecture='resnet')
     assert rel_err(s, so) < 1e-4
+
+
+@pytest.mark.parametrize('variant', ['exclusive+projection', 'mirror+attributes'])
+def test_training_loop_optional_paths(cuda_device, variant):
+    """The loop's optional branches run end to end on the device: exclusive k-NN assignment with a random projection in front
+    (training_loop.py:28-35,205-213,382-396), mirror augmentation (:47-49) with the attribute AND-mask selection (:416-424) on
+    CelebA-shaped labels."""
+    from inclusivegan_amd.dnnlib import EasyDict
+    from inclusivegan_amd.training import training_loop as TL
+    from inclusivegan_amd.training import imle
+    seen, batches = [], []
+    def on_it(info):
+        seen.append(info['cur_nimg'])
+        return len(seen) >= 2
+    extra = dict(exclusive_retrieved_code=True, init_proj_dim=24) if variant.startswith('exclusive') else dict(
+        mirror_augment=True, attr_interesting='Smiling', attr_names=list(imle.CELEBA_ATTRIBUTES))
+    label = dict(label_size=10, label_kind='onehot') if variant.startswith('exclusive') else dict(label_size=40, label_kind='attributes')
+    out = TL.training_loop(
+        G_args=EasyDict(func_name='training.networks_stylegan2.G_main', fmap_base=512, architecture='skip'),
+        D_args=EasyDict(func_name='training.networks_stylegan2.D_stylegan2_feature', fmap_base=512, architecture='resnet'),
+        G_opt_args=EasyDict(beta1=0.0, beta2=0.99, epsilon=1e-8), D_opt_args=EasyDict(beta1=0.0, beta2=0.99, epsilon=1e-8),
+        G_loss_args=EasyDict(func_name='training.loss.G_logistic_ns_rec_interp_arb_pathreg', NN_rec_lpips_weight=2.5),
+        D_loss_args=EasyDict(func_name='training.loss.D_logistic_r1', gamma=100),
+        dataset_args=EasyDict(resolution=32, num_channels=3, **label),
+        sched_args=EasyDict(minibatch_gpu_base=3, minibatch_size_base=3), tf_config={'rnd.np_random_seed': 1000},
+        total_kimg=1, data_size=48, num_samples_factor=4, init_staleness=10, knn_perturb_factor=0.05, candidate_batch_size=64,
+        hooks=dict(on_iteration=on_it, on_batch=batches.append), **extra)
+    assert seen == [6, 12] and len(batches) == 2
+    for net in (out['G'], out['D'], out['Gs']):
+        assert bool(torch.isfinite(net.flat_params).all())
+    if variant.startswith('mirror'):
+        col = imle.CELEBA_ATTRIBUTES.index('Smiling')
+        for b in batches:
+            assert b['labels_rec_1'].shape == (3, 40) and bool((b['labels_rec_1'][:, col] == 1).all()) and bool((b['labels_rec_2'][:, col] == 1).all())
