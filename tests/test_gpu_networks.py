@@ -515,3 +515,29 @@ def test_training_loop_optional_paths(cuda_device, variant):
         col = imle.CELEBA_ATTRIBUTES.index('Smiling')
         for b in batches:
             assert b['labels_rec_1'].shape == (3, 40) and bool((b['labels_rec_1'][:, col] == 1).all()) and bool((b['labels_rec_2'][:, col] == 1).all())
+
+
+def test_training_loop_config2_full_width(cuda_device):
+    """BASELINE config 2 as the loop runs it: Stacked-MNIST-shaped 32x32 data with 1000-d one-hot labels, config-e width
+    (fmap_base 8192), minibatch_gpu 6, IMLE refresh + all four step kinds through captured graphs."""
+    from inclusivegan_amd.dnnlib import EasyDict
+    from inclusivegan_amd.training import training_loop as TL
+    seen = []
+    def on_it(info):
+        seen.append(info['cur_nimg'])
+        return len(seen) >= 5
+    refresh = []
+    out = TL.training_loop(
+        G_args=EasyDict(func_name='training.networks_stylegan2.G_main', fmap_base=8192, architecture='skip'),
+        D_args=EasyDict(func_name='training.networks_stylegan2.D_stylegan2_feature', fmap_base=8192, architecture='resnet'),
+        G_opt_args=EasyDict(beta1=0.0, beta2=0.99, epsilon=1e-8), D_opt_args=EasyDict(beta1=0.0, beta2=0.99, epsilon=1e-8),
+        G_loss_args=EasyDict(func_name='training.loss.G_logistic_ns_rec_interp_arb_pathreg', NN_rec_lpips_weight=2.5),
+        D_loss_args=EasyDict(func_name='training.loss.D_logistic_r1', gamma=100),
+        dataset_args=EasyDict(resolution=32, num_channels=3, label_size=1000, label_kind='onehot'),
+        sched_args=EasyDict(minibatch_gpu_base=6, minibatch_size_base=6), tf_config={'rnd.np_random_seed': 1000},
+        total_kimg=1, data_size=96, num_samples_factor=10, init_staleness=10, knn_perturb_factor=0.05, candidate_batch_size=128,
+        hooks=dict(on_iteration=on_it, on_refresh=refresh.append))
+    assert seen == [12, 24, 36, 48, 60] and len(refresh) == 1
+    assert out['G'].flat_params.numel() > 20_000_000
+    for net in (out['G'], out['D'], out['Gs']):
+        assert bool(torch.isfinite(net.flat_params).all())
