@@ -29,80 +29,88 @@ def convert_images_to_uint8(images, drange=[-1, 1], nchw_to_nhwc=False, shrink=1
     return images.clamp(0, 255).to(torch.uint8)       # saturate_cast truncates after clamping
 
 
+class _Result:
+    """One reported number: `<metric name><suffix> <fmt % value>` in the result line."""
+    __slots__ = ('value', 'suffix', 'fmt')
+
+    def __init__(self, value, suffix, fmt):
+        self.value, self.suffix, self.fmt = value, suffix, fmt
+
+
 class MetricBase:
+    """Harness of one metric (metric_base.py:22-130): `run()` evaluates it on a snapshot or a live Gs, `_evaluate()` (subclass)
+    calls `_report_result()` once per number, `get_result_str()` renders the reference's line."""
+
     def __init__(self, name):
         self.name = name
         self._dataset_obj = None
-        self._reset()
+        self._configure()
 
-    def close(self):
-        self._reset()
-
-    def _reset(self, network_pkl=None, run_dir=None, data_dir=None, dataset_args=None, mirror_augment=None):
+    # ---- per-run state -------------------------------------------------------------------------------------------------
+    def _configure(self, source='', data_dir=None, dataset_args=None, mirror_augment=False):
         if self._dataset_obj is not None:
             self._dataset_obj.close()
-        self._network_pkl = network_pkl
-        self._data_dir = data_dir
-        self._dataset_args = dataset_args
-        self._dataset_obj = None
+            self._dataset_obj = None
+        self._network_pkl, self._data_dir, self._dataset_args = source, data_dir, dataset_args
         self._mirror_augment = bool(mirror_augment)
-        self._eval_time = 0
-        self._results = []
+        self._eval_time, self._results = 0, []
 
+    def close(self):
+        self._configure()
+
+    # ---- evaluation ----------------------------------------------------------------------------------------------------
     def run(self, network_pkl, run_dir=None, data_dir=None, dataset_args=None, mirror_augment=None, num_gpus=1, tf_config=None,
             log_results=True, Gs_kwargs=dict(is_validation=True), device=None):
         """`network_pkl`: a snapshot file (the last object of the pickled tuple is Gs, metric_base.py:66) or a live Gs Network."""
         from ..training import misc
-        self._reset(network_pkl=network_pkl if isinstance(network_pkl, str) else 'live-network', run_dir=run_dir, data_dir=data_dir,
-                    dataset_args=dataset_args, mirror_augment=mirror_augment)
-        time_begin = time.time()
-        Gs = misc.as_networks(misc.load_pkl(network_pkl), device=device)[-1] if isinstance(network_pkl, str) else network_pkl
+        from_file = isinstance(network_pkl, str)
+        self._configure(network_pkl if from_file else 'live-network', data_dir, dataset_args, mirror_augment)
+        started = time.time()
+        Gs = misc.as_networks(misc.load_pkl(network_pkl), device=device)[-1] if from_file else network_pkl
         with torch.no_grad():
             self._evaluate(Gs, Gs_kwargs=Gs_kwargs, num_gpus=num_gpus)
-        self._eval_time = time.time() - time_begin
-        if log_results:
-            line = self.get_result_str().strip()
-            if run_dir is not None:
-                with open(os.path.join(run_dir, 'metric-%s.txt' % self.name), 'a') as f:
-                    f.write(line + '\n')
-            print(line)
+        self._eval_time = time.time() - started
+        if not log_results:
+            return
+        line = self.get_result_str().strip()
+        if run_dir is not None:
+            with open(os.path.join(run_dir, 'metric-%s.txt' % self.name), 'a') as f:
+                f.write(line + '\n')
+        print(line)
 
+    def _evaluate(self, Gs, Gs_kwargs, num_gpus):
+        raise NotImplementedError('subclasses compute the metric here and call _report_result()')
+
+    def _report_result(self, value, suffix='', fmt='%-10.4f'):
+        self._results.append(_Result(value, suffix, fmt))
+
+    # ---- reporting (line format of metric_base.py:95-104: 30-column name, elapsed time, then the numbers) ------------------
     def get_result_str(self):
-        network_name = os.path.splitext(os.path.basename(self._network_pkl))[0]
-        if len(network_name) > 29:
-            network_name = '...' + network_name[-26:]
-        result_str = '%-30s' % network_name
-        result_str += ' time %-12s' % dnnlib.util.format_time(self._eval_time)
-        for res in self._results:
-            result_str += ' ' + self.name + res.suffix + ' '
-            result_str += res.fmt % res.value
-        return result_str
+        stem = os.path.splitext(os.path.basename(self._network_pkl))[0]
+        shown = stem if len(stem) <= 29 else '...' + stem[-26:]
+        fields = ['%-30s' % shown, 'time %-12s' % dnnlib.util.format_time(self._eval_time)]
+        fields += ['%s%s %s' % (self.name, r.suffix, r.fmt % r.value) for r in self._results]
+        return ' '.join(fields)
 
     def update_autosummaries(self):
         from ..dnnlib.tflib.autosummary import autosummary
-        for res in self._results:
-            autosummary('Metrics/' + self.name + res.suffix, res.value)
+        for r in self._results:
+            autosummary('Metrics/%s%s' % (self.name, r.suffix), r.value)
 
-    def _evaluate(self, Gs, Gs_kwargs, num_gpus):
-        raise NotImplementedError   # to be overridden by subclasses
-
-    def _report_result(self, value, suffix='', fmt='%-10.4f'):
-        self._results += [dnnlib.EasyDict(value=value, suffix=suffix, fmt=fmt)]
-
+    # ---- data ----------------------------------------------------------------------------------------------------------
     def _get_dataset_obj(self):
-        from ..training import dataset
         if self._dataset_obj is None:
+            from ..training import dataset
             self._dataset_obj = dataset.load_dataset(data_dir=self._data_dir, **self._dataset_args)
         return self._dataset_obj
 
     def _iterate_reals(self, minibatch_size):
+        """Endless stream of real uint8 minibatches, mirrored at random when the run asked for it (metric_base.py:124-130)."""
         from ..training import misc
-        dataset_obj = self._get_dataset_obj()
+        source = self._get_dataset_obj()
         while True:
-            images, _labels = dataset_obj.get_minibatch_np(minibatch_size)
-            if self._mirror_augment:
-                images = misc.apply_mirror_augment(images)
-            yield images
+            batch = source.get_minibatch_np(minibatch_size)[0]
+            yield misc.apply_mirror_augment(batch) if self._mirror_augment else batch
 
     def _generate(self, Gs, minibatch_size, Gs_kwargs, as_uint8=True):
         """One minibatch of fakes from Gs: latents ~ N(0, I) on the device, random labels (metric_base.py:139-146 / the
@@ -113,31 +121,34 @@ class MetricBase:
         return convert_images_to_uint8(images) if as_uint8 else images
 
 
-class MetricGroup:
-    def __init__(self, metric_kwarg_list):
-        self.metrics = [dnnlib.util.call_func_by_name(**_retarget(kwargs)) for kwargs in metric_kwarg_list]
-
-    def run(self, *args, **kwargs):
-        for metric in self.metrics:
-            metric.run(*args, **kwargs)
-
-    def get_result_str(self):
-        return ' '.join(metric.get_result_str() for metric in self.metrics)
-
-    def update_autosummaries(self):
-        for metric in self.metrics:
-            metric.update_autosummaries()
-
-
 def _retarget(kwargs):
+    """The reference names its metrics `metrics.<module>.<Class>`; the same classes live under this package."""
     kwargs = dict(kwargs)
-    fn = kwargs.get('func_name', '')
-    if fn.startswith('metrics.'):
-        kwargs['func_name'] = 'inclusivegan_amd.' + fn
+    if kwargs.get('func_name', '').startswith('metrics.'):
+        kwargs['func_name'] = 'inclusivegan_amd.' + kwargs['func_name']
     return kwargs
 
 
+class MetricGroup:
+    """Several metrics driven as one (metric_base.py:142-159)."""
+
+    def __init__(self, metric_kwarg_list):
+        self.metrics = [dnnlib.util.call_func_by_name(**_retarget(kw)) for kw in metric_kwarg_list]
+
+    def run(self, *args, **kwargs):
+        for m in self.metrics:
+            m.run(*args, **kwargs)
+
+    def get_result_str(self):
+        return ' '.join(m.get_result_str() for m in self.metrics)
+
+    def update_autosummaries(self):
+        for m in self.metrics:
+            m.update_autosummaries()
+
+
 class DummyMetric(MetricBase):
+    """Reports a constant: exercises the harness (metric_base.py:163-165)."""
+
     def _evaluate(self, Gs, Gs_kwargs, num_gpus):
-        _ = Gs, Gs_kwargs, num_gpus
         self._report_result(0.0)
