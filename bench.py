@@ -312,6 +312,7 @@ def main():
     args = parse_args()
     if args.gpus > 1 and 'RANK' not in os.environ and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(args))
+    import inclusivegan_amd  # noqa: F401 -- first: sets the HIP runtime flags the captured graphs need, before anything touches the GPU
     import torch
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))

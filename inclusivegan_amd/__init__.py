@@ -10,4 +10,14 @@ reference's dotted-name plugin mechanism (dnnlib/util.py:251-256) can point at i
 Native code lives in csrc/ (hand-written HIP for CDNA4) behind the C ABI declared in
 include/igan_hip.h and bound in _abi.py.
 """
+import os as _os
+
+# ROCm's "graph packet capture" (AQL packets of a hipGraph pre-built at instantiation; on by default in the HIP runtime this
+# PyTorch ships) replays the training ops' graphs WRONGLY on MI355X: a reduction deep in the second-order backward reads its
+# input before the producing kernel of the same replay has written it (found by tests/test_gpu_loop_parity.py; evidence in
+# profiles/r03_graph_packet_capture.txt).  The runtime reads its flags at the first HIP call, so the switch has to be in the
+# environment before anything touches the GPU; dnnlib/tflib/graphs.py additionally validates every captured op against
+# its eager execution and refuses to replay a graph that disagrees.
+_os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
+
 __version__ = '0.1.0'

@@ -16,6 +16,8 @@ import os
 
 import torch
 
+from . import tfutil
+
 
 def graphs_enabled(default=True):
     v = os.environ.get('IGAN_HIP_GRAPHS')
@@ -24,8 +26,18 @@ def graphs_enabled(default=True):
     return v not in ('0', 'false', 'False', '')
 
 
+def validation_enabled():
+    """IGAN_GRAPH_VALIDATE=0 skips the replay-vs-eager check after capture (training_loop.py)."""
+    return os.environ.get('IGAN_GRAPH_VALIDATE', '1') != '0'
+
+
+def _one_stream():
+    return os.environ.get('IGAN_GRAPH_ONE_STREAM', '1') != '0'      # A/B switch (0 = warm up on the default stream, capture on torch's own side stream)
+
+
 class GraphedStep:
     _pool = None
+    _stream = None
     force_eager = False     # profiling switch: run every step eagerly (per-launch event timing)
     generation = 0          # bump to make every step re-capture its graph at its next call (e.g. after switching on hip_ops.stamp_log)
     after_capture = None    # optional callable run INSIDE the capture, after fn() (e.g. StampLog.fold); receives the step
@@ -41,10 +53,82 @@ class GraphedStep:
         self.captured_generation = 0
         self.replays = 0        # replays of the CURRENT graph (first capture counts: a capture does not execute, the replay after it does)
 
+    def _run_fn(self):
+        # a TapRandom source groups the draws by op: tell it which op's Python is about to run (eager call or capture)
+        src = tfutil.random_source()
+        if hasattr(src, 'begin'):
+            src.begin(self.name)
+            try:
+                return self.fn()
+            finally:
+                src.begin(None)
+        return self.fn()
+
+    @classmethod
+    def side_stream(cls):
+        """ONE stream for the eager warm-up calls and every capture.  Autograd remembers the stream a parameter's
+        gradient-accumulation node was created on and sums the contributions of a parameter with several consumers (every
+        modulated weight: convolution + demodulation) on THAT stream; nodes created by a warm-up call on the default
+        stream and still alive at capture time would pull that summation out of the captured stream."""
+        if cls._stream is None:
+            cls._stream = torch.cuda.Stream()
+        return cls._stream
+
+    def check_replay(self, state, results, context=()):
+        """One replay and one eager execution of the op, from the same values of `state` (tensors the op reads AND updates in
+        place) and the same device-generator state, must agree bit for bit in `results(out)` (a list of tensors; `out` is the
+        op's return value) and in `state`.  `context`: other captured steps, replayed right before the tested replay -- the
+        way the training loop runs them back to back (the runtime fault this check exists for only shows when another
+        graph of the shared pool has just run).  Leaves `state` and the generator as it found them.  Returns the list of
+        (index, max abs difference) of the disagreeing tensors -- empty when the graph is faithful."""
+        assert self.graph is not None, 'check_replay() needs a captured graph'
+        saved = [t.detach().clone() for t in state]
+        rng = torch.cuda.get_rng_state()
+
+        def reset():
+            with torch.no_grad():
+                for t, v in zip(state, saved):
+                    t.copy_(v)
+            torch.cuda.set_rng_state(rng)
+
+        def snapshot(out):
+            return [t.detach().clone() for t in list(results(out)) + list(state)]
+
+        for other in context:
+            if other.graph is not None:
+                other.graph.replay()
+        reset()
+        self.graph.replay()
+        a = snapshot(self.out)
+        reset()
+        src = tfutil.random_source()
+        tapped = src.by_op.get(self.name) if hasattr(src, 'by_op') else None     # a TapRandom must keep pointing at the GRAPH's draws
+        b = snapshot(self._run_fn())
+        if tapped is not None:
+            src.by_op[self.name] = tapped
+        reset()
+        torch.cuda.synchronize()
+        bad = []
+        for i, (x, y) in enumerate(zip(a, b)):
+            same = (x == y) | (torch.isnan(x) & torch.isnan(y)) if x.dtype.is_floating_point else (x == y)
+            if x.shape != y.shape or not bool(same.all()):
+                bad.append((i, float((x.double() - y.double()).abs().nan_to_num(nan=float('inf')).max()) if x.shape == y.shape else float('inf')))
+        return bad
+
     def __call__(self):
-        if not self.enabled or GraphedStep.force_eager or self.calls < self.eager_calls:
+        if not self.enabled or GraphedStep.force_eager:
             self.calls += 1
-            return self.fn()
+            return self._run_fn()
+        if self.calls < self.eager_calls:
+            self.calls += 1
+            if not _one_stream():
+                return self._run_fn()
+            s = GraphedStep.side_stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                out = self._run_fn()
+            torch.cuda.current_stream().wait_stream(s)
+            return out
         if self.graph is not None and self.captured_generation != GraphedStep.generation:
             torch.cuda.synchronize()
             self.graph = None
@@ -55,8 +139,9 @@ class GraphedStep:
             # With a process group up, RCCL's watchdog thread polls events while we capture: in the default
             # "global" mode that foreign call would invalidate the capture; only this thread's calls matter here.
             dist_up = torch.distributed.is_available() and torch.distributed.is_initialized()
-            with torch.cuda.graph(g, pool=GraphedStep._pool, capture_error_mode='thread_local' if dist_up else 'global'):
-                self.out = self.fn()
+            with torch.cuda.graph(g, pool=GraphedStep._pool, stream=GraphedStep.side_stream() if _one_stream() else None,
+                                  capture_error_mode='thread_local' if dist_up else 'global'):
+                self.out = self._run_fn()
                 if GraphedStep.after_capture is not None:
                     GraphedStep.after_capture(self)
             self.captured_generation = GraphedStep.generation

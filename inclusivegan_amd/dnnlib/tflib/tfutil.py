@@ -178,6 +178,45 @@ class RecordingRandom(_DefaultRandom):
         return ts
 
 
+class TapRandom(_DefaultRandom):
+    """Default source that keeps the DEVICE tensors of every draw, grouped by the training op that made them, so that the
+    draws of a captured hipGraph can be read back after each replay (a replay refills the same tensors; holding the
+    references keeps the graph's memory pool from handing their storage to a later allocation).  `begin(name)` is called
+    by GraphedStep before every Python execution of an op (eager run or capture); `snapshot(name)` copies the current
+    contents to the host as a tape [(kind, ndarray), ...] in call order."""
+
+    def __init__(self):
+        self.by_op = {}
+        self.current = None
+
+    def begin(self, name):
+        """name=None: no op is running (draws made now, e.g. by the IMLE refresh, are not kept)."""
+        if name is None:
+            self.current = None
+        else:
+            self.current = self.by_op[name] = []
+
+    def _keep(self, kind, t):
+        if self.current is not None:
+            self.current.append((kind, t))
+        return t
+
+    def normal(self, shape, device):
+        return self._keep('normal', super().normal(shape, device))
+
+    def uniform(self, shape, device, minval=0.0, maxval=1.0):
+        return self._keep('uniform', super().uniform(shape, device, minval, maxval))
+
+    def randint(self, low, high, device):
+        return self._keep('randint', super().randint(low, high, device))
+
+    def normal_many(self, shapes, device):
+        return [self._keep('normal', t) for t in super().normal_many(shapes, device)]
+
+    def snapshot(self, name):
+        return [(kind, t.detach().cpu().numpy().copy()) for kind, t in self.by_op.get(name, [])]
+
+
 _random = _DefaultRandom()
 
 def random_source():

@@ -21,6 +21,7 @@ latents, the reconstruction pairs of the IMLE term, and (G, D, Gs) pickles in th
 `resume_pkl` continues from such a pickle -- or from one the reference wrote.  Metric scheduling and tfevents stay out
 (SURVEY.md section 2.1).  A `hooks` dict lets a driver (bench.py, tests) observe iterations and stop early.
 """
+import functools
 import os
 import time
 
@@ -228,6 +229,20 @@ def imle_refresh(G, training_set_rec, latent_candidates, label_candidates, data_
 #----------------------------------------------------------------------------
 # Main training script.
 
+def _with_random_source(fn):
+    """hooks['random_source'] (a tflib.tfutil source, e.g. TapRandom) supplies every device-side random draw of the run --
+    the parity tests read the draws of the captured graphs back through it."""
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        src = (kwargs.get('hooks') or {}).get('random_source')
+        if src is None:
+            return fn(*args, **kwargs)
+        with tfutil.use_random(src):
+            return fn(*args, **kwargs)
+    return wrapper
+
+
+@_with_random_source
 def training_loop(
     G_args                  = {},
     D_args                  = {},
@@ -269,7 +284,9 @@ def training_loop(
     # --- extensions (not in the reference) ---
     attr_names              = None,     # list of attribute names (reference reads celeba/Anno/list_attr_celeba.txt, :174-180)
     lpips_func_name         = 'inclusivegan_amd.metrics.lpips.vgg16_zhang_perceptual',
-    hooks                   = None,     # {'on_iteration': f(state) -> bool stop, 'on_refresh': f(seconds), 'on_batch': f(host batch dict)}
+    hooks                   = None,     # {'on_iteration': f(state) -> bool stop, 'on_refresh': f(seconds), 'on_batch': f(host batch dict),
+                                        #  'on_start': f(state) before the first iteration, 'on_op': f(step name, output, feed) after each training op,
+                                        #  'random_source': tfutil source for all device draws}
     hip_graphs              = True,     # capture the four training ops into hipGraphs (env IGAN_HIP_GRAPHS=0 disables)
     run_dir                 = None,     # where snapshots go (arb-reals.png, arb-fakes-*.png, rec-*.png, network-snapshot-*.pkl, :171-172,506-519); None = none
     reference_src           = None,     # path of a reference checkout's training/networks_stylegan2.py: snapshots then open in the reference too
@@ -452,6 +469,26 @@ def training_loop(
         for step in ((G_grad_step, G_reg_step, D_grad_step, D_reg_step) if lazy_regularization else (G_grad_step, D_grad_step)):
             step()      # eager
             step()      # capture + first replay
+        # Every captured op must reproduce its own eager execution bit for bit (same inputs, same state, same generator
+        # state) before the run is allowed to depend on it; a graph that does not is not replayed -- its op runs eagerly.
+        graphs_ok = True
+        if graphs.validation_enabled():
+            state = [G.vars['dlatent_avg']] + ([G.pl_mean_var] if hasattr(G, 'pl_mean_var') else [])
+            all_steps = (G_grad_step, G_reg_step, D_grad_step, D_reg_step)
+            for step, net in zip(all_steps, (G, G, D, D)):
+                if step.graph is None:
+                    continue
+                bad = step.check_replay(state, lambda out, net=net: [out, net.flat_grads], context=[s for s in all_steps if s is not step] if os.environ.get('IGAN_GRAPH_VALIDATE_CONTEXT', '1') != '0' else [])
+                flag = torch.tensor([1.0 if bad else 0.0], device=device)
+                if world > 1:       # every rank takes the same decision (the ops contain collectives)
+                    torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+                if bool(flag.item()):
+                    graphs_ok = False
+                    print('WARNING: hipGraph of training op %r does not reproduce its eager execution (tensor index, max |diff|: %s); '
+                          'running this op eagerly' % (step.name, bad), flush=True)
+                    step.enabled = False
+        if 'on_graphs' in hooks:
+            hooks['on_graphs'](dict(captured=True, validated=graphs.validation_enabled(), faithful=graphs_ok))
         with torch.no_grad():
             for n, v in saved.items():
                 G.vars[n].copy_(v)
@@ -469,26 +506,30 @@ def training_loop(
         feed['labels'].copy_(labels)
 
     def G_train_op():
-        G_grad_step()
+        out = G_grad_step()
         G_opt.mark_registered(G)
         G_opt.apply_updates()
+        return 'G', out
 
     def G_reg_op():
-        G_reg_step()
+        out = G_reg_step()
         G_reg_opt.mark_registered(G)
         G_reg_opt.apply_updates(allow_no_op=True)
+        return 'G_reg', out
 
     def D_train_op():
         next_reals()
-        D_grad_step()
+        out = D_grad_step()
         D_opt.mark_registered(D)
         D_opt.apply_updates()
+        return 'D', out
 
     def D_reg_op():
         next_reals()
-        D_reg_step()
+        out = D_reg_step()
         D_reg_opt.mark_registered(D)
         D_reg_opt.apply_updates(allow_no_op=True)
+        return 'D_reg', out
 
     if rank == 0:
         print('Training for %d kimg...\n' % total_kimg)
@@ -514,6 +555,8 @@ def training_loop(
     sampler = imle.ImleSampler(training_set_rec, latent_candidates, data_size, num_samples_factor, init_staleness, knn_perturb_factor,
                                dist_thres_percentile=dist_thres_percentile, attr_interesting=attr_interesting, attr_names=attr_names,
                                search=search)
+    if 'on_start' in hooks:
+        hooks['on_start'](dict(G=G, D=D, Gs=Gs, lpips=lpips, feed=feed, training_set=training_set, G_opt=G_opt, D_opt=D_opt))
     stop = False
     while cur_nimg < total_kimg * 1000 and not stop:
         # Choose training parameters (:336-340).
@@ -555,12 +598,16 @@ def training_loop(
 
             # Run training ops (:474-479).
             timed = hooks.get('op_times')          # optional: dict name -> list of (start, end) HIP events
+            on_op = hooks.get('on_op')
             def run(name, op):
                 if timed is None:
-                    return op()
-                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-                e0.record(); op(); e1.record()
-                timed.setdefault(name, []).append((e0, e1))
+                    res = op()
+                else:
+                    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                    e0.record(); res = op(); e1.record()
+                    timed.setdefault(name, []).append((e0, e1))
+                if on_op is not None and res is not None:
+                    on_op(res[0], res[1], feed)
             run('G_train', G_train_op)
             if run_G_reg:
                 run('G_reg', G_reg_op)

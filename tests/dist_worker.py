@@ -99,13 +99,21 @@ def mode_loop(rank, world, outdir):
                os.path.join(outdir, 'rank%d.pt' % rank))
 
 
+def mode_record(rank, world, outdir):
+    """Five iterations of the real loop with every op recorded (draws, fed slices, loss outputs, final state):
+    tests/test_gpu_loop_parity.py replays both ranks' logs into the oracle's two towers."""
+    from tests.test_gpu_loop_parity import record_loop, loop_kwargs
+    log = record_loop(5, loop_kwargs(512, 3, world=world, data_size=48), keep_state=(rank == 0))
+    torch.save(log, os.path.join(outdir, 'rank%d.pt' % rank))
+
+
 def main():
     mode, rank, world, port, outdir = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = port
     torch.cuda.set_device(0)
     torch.distributed.init_process_group('gloo', rank=rank, world_size=world)
-    {'exchange': mode_exchange, 'loop': mode_loop}[mode](rank, world, outdir)
+    {'exchange': mode_exchange, 'loop': mode_loop, 'record': mode_record}[mode](rank, world, outdir)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import rel_err
+from tests.util import rel_err, gloss_tape_in_reference_order as _gloss_tape_in_reference_order
 
 pytestmark = pytest.mark.gpu
 
@@ -90,22 +90,6 @@ def _grad_errs(net, oparams):
     if sc_o:
         errs['<all scalar parameters>'] = float((torch.cat(sc_h) - torch.cat(sc_o)).norm() / (torch.cat(sc_o).norm() + 1e-30))
     return errs
-
-
-def _gloss_tape_in_reference_order(entries, B, calls=4):
-    """The HIP G loss draws [interp factors, random latents] and then runs ONE generator pass for the four
-    reference calls (G_main num_calls=4: latents2 for all 4B samples, a (coin, cutoff) pair per call, one
-    noise tensor of 4B samples per layer).  The oracle makes the reference's four sequential calls
-    (loss.py:25,26,39,48), so the recorded draws are re-sliced into that order:
-    call 1, call 2, interp factors, call 3, random latents, call 4."""
-    t, zr, l2 = entries[0], entries[1], entries[2][1]
-    ur = entries[3:3 + 2 * calls]
-    noises = entries[3 + 2 * calls:]
-    per_call = []
-    for k in range(calls):
-        sl = slice(k * B, (k + 1) * B)
-        per_call.append([('normal', l2[sl]), ur[2 * k], ur[2 * k + 1]] + [('normal', n[1][sl]) for n in noises])
-    return per_call[0] + per_call[1] + [t] + per_call[2] + [zr] + per_call[3]
 
 
 @pytest.mark.parametrize('fmap', [FMAP, 8192], ids=['width1024', 'config_e_width8192'])
