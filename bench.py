@@ -41,11 +41,13 @@ def parse_args():
     p.add_argument('--warmup', type=int, default=4)
     p.add_argument('--resolution', type=int, default=128)
     p.add_argument('--minibatch-gpu', type=int, default=6)
-    p.add_argument('--data-size', type=int, default=1152)
+    p.add_argument('--data-size', type=int, default=30000, help='images in the data set = reals of one IMLE refresh (BASELINE config 4: 30 000); rounded down to a multiple of 2 * minibatch_gpu * gpus')
     p.add_argument('--num-samples-factor', type=int, default=10)
     p.add_argument('--lpips-weight', type=float, default=2.5)
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true')
+    p.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='process-group backend for --gpus > 1 (nccl = RCCL; gloo for the one-GPU tests)')
+    p.add_argument('--one-gpu', action='store_true', help='test hook: every rank on device 0 (needs --backend gloo: RCCL refuses two ranks on one device)')
     p.add_argument('--op-times', action='store_true', help='also report the mean device time of each training op (HIP events)')
     p.add_argument('--conv-shapes', default=None, metavar='FILE', help='write the per-shape table of the conv family inside the replayed graphs (device stamps) to FILE')
     return p.parse_args()
@@ -220,7 +222,7 @@ def cpu_baseline(resolution, batch, lpips_weight):
         iters += 1
     dt = time.time() - t0
     return dict(value=round(2 * batch * iters / dt, 4), unit='img/s', cores=cores, kind='port',
-                sample='%d iteration(s) (G step + D step, forward+backward, no lazy-reg steps) at minibatch_gpu=%d, %dx%d, PyTorch-CPU fp32 oracle, %.1f s'
+                sample='per-image rate of %d iteration(s) (G step + D step, forward+backward) at minibatch_gpu=%d WITHOUT the lazy-regularisation steps -- not the GPU line\'s workload mix -- %dx%d, PyTorch-CPU fp32 oracle, %.1f s'
                        % (iters, batch, resolution, resolution, dt))
 
 
@@ -317,12 +319,11 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    # Test hooks for boxes with a single GPU (tests/test_gpu_dist.py): IGAN_BENCH_ONE_GPU=1 puts every rank on device 0 and
-    # IGAN_BENCH_BACKEND=gloo swaps RCCL (which needs one device per rank) for gloo -- the launch path, the rank slicing, the
+    # --one-gpu / --backend gloo: for boxes with a single GPU (tests/test_gpu_dist.py) -- the launch path, the rank slicing, the
     # barriers and the max-over-ranks timing are the ones of a real multi-GPU run.
-    if os.environ.get('IGAN_BENCH_ONE_GPU') == '1':
+    if args.one_gpu:
         local_rank = 0
-    backend = os.environ.get('IGAN_BENCH_BACKEND', 'nccl')
+    backend = args.backend
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if world > 1:
@@ -339,7 +340,9 @@ def main():
     from inclusivegan_amd.training import training_loop as TL
 
     B = args.minibatch_gpu
-    state = dict(t_start=None, t_end=None, refresh=[], iters=0)
+    # the loop needs data_size % (2 * minibatch_size) == 0 (training_loop.py:338-340 walks the set in whole double minibatches)
+    data_size = args.data_size // (2 * B * world) * (2 * B * world)
+    state = dict(t_start=None, t_end=None, refresh=[], iters=0, graphs=None)
     profile_iters = 0 if args.no_roofline else 16     # stamped iterations (graphs re-captured with device time stamps) after the timed region
 
     def barrier_sync():
@@ -361,12 +364,13 @@ def main():
             # roofline leg: the same iterations with the graphs re-captured around device-side time stamps
             from inclusivegan_amd import hip_ops
             from inclusivegan_amd.dnnlib.tflib.graphs import GraphedStep
-            if rank == 0:
-                state['stamp'] = hip_ops.StampLog(device)
-                state['stamp_steps'] = {}
-                hip_ops.stamp_log = state['stamp']
-                GraphedStep.after_capture = lambda step: state['stamp_steps'].__setitem__(step, state['stamp'].fold())
-                GraphedStep.generation += 1
+            # every rank re-captures in lockstep (the graphs contain the gradient exchange under RCCL); the stamps of the other
+            # ranks are taken and dropped, so all ranks replay the same graphs
+            state['stamp'] = hip_ops.StampLog(device)
+            state['stamp_steps'] = {}
+            hip_ops.stamp_log = state['stamp']
+            GraphedStep.after_capture = lambda step: state['stamp_steps'].__setitem__(step, state['stamp'].fold())
+            GraphedStep.generation += 1
         if state['iters'] == args.warmup + args.steps + profile_iters:
             torch.cuda.synchronize()
             return True
@@ -388,9 +392,9 @@ def main():
         dataset_args=EasyDict(resolution=args.resolution, num_channels=3, label_size=40, label_kind='attributes'),
         sched_args=EasyDict(G_lrate_base=0.002, D_lrate_base=0.002, minibatch_gpu_base=B, minibatch_size_base=B * world),
         tf_config={'rnd.np_random_seed': 1000},
-        total_kimg=10 ** 6, data_size=args.data_size, num_epochs=10000,
+        total_kimg=10 ** 6, data_size=data_size, num_epochs=10000,
         init_staleness=10, num_samples_factor=args.num_samples_factor, knn_perturb_factor=0.05, candidate_batch_size=256,
-        hooks=dict(on_iteration=on_iteration, on_refresh=on_refresh,
+        hooks=dict(on_iteration=on_iteration, on_refresh=on_refresh, on_graphs=lambda g: state.__setitem__('graphs', g),
                    **({'op_times': state.setdefault('op_times', {})} if args.op_times else {})),
     )
     log('starting training loop')
@@ -412,9 +416,16 @@ def main():
         'config': {'workload': 'CelebA-shaped %dx%d StyleGAN2+IMLE, config-e-Gskip-Dresnet (fmap_base 8192), minibatch_gpu %d, '
                                'NN_rec_lpips_weight %g, lazy reg G/4 D/16, random-init weights' % (args.resolution, args.resolution, B, args.lpips_weight),
                    'global_batch': B * world, 'images_per_step': 2 * B * world, 'parallelism': 'dp%d' % world,
-                   'data_size': args.data_size, 'num_samples_factor': args.num_samples_factor},
+                   'data_size': data_size, 'num_samples_factor': args.num_samples_factor, 'init_staleness': 10},
         'imle_refresh_s': round(state['refresh'][0], 3) if state['refresh'] else None,
+        # the four training ops run as replayed hipGraphs, each validated bit for bit against its eager execution after capture
+        'hip_graphs': state['graphs'] if state['graphs'] is not None else {'captured': False},
     }
+    if state['refresh']:
+        # `value` is the steady state between refreshes (the refresh is reported separately); one refresh serves
+        # data_size * init_staleness images (training_loop.py:354), so over the first period the throughput is
+        period = data_size * 10
+        out['amortised_img_s'] = round(period / (period / out['value'] + state['refresh'][0]), 3)
     if args.op_times:
         torch.cuda.synchronize()
         out['op_ms'] = {k: round(sum(a.elapsed_time(b) for a, b in v[2:]) / max(len(v) - 2, 1), 3) for k, v in state['op_times'].items()}

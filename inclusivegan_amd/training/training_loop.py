@@ -145,12 +145,12 @@ def exclusive_assignment(knn_idx, knn_dist):
 
 
 def imle_refresh(G, training_set_rec, latent_candidates, label_candidates, data_size, minibatch_size, candidate_batch_size,
-                 drange_net, device, rank=0, world=1, query_chunk=4096, infer_minibatch=None, projector=None, exclusive_k=0):
+                 drange_net, device, rank=0, world=1, query_chunk=8192, infer_minibatch=None, projector=None, exclusive_k=0, cand_pack=4096):
     """IMLE assignment (:357-406, non-exclusive): every real image (dataset order, [-1,1] range, flattened CHW;
     times `projector` [C*H*W, proj_dim] when random projection is on, :377-380) gets the index of its nearest generated
     candidate and the Euclidean distance.  Candidates are generated batch by batch with G (training weights, validation
-    mode, random noise -- `G.run(..., is_validation=True)`, :361) and folded into a running per-real minimum; rank r
-    handles candidate batches r, r+world, ... and the minima are combined across ranks.  The reals are pulled from
+    mode, random noise -- `G.run(..., is_validation=True)`, :361) and folded, a pack of `cand_pack` at a time, into a running
+    per-real minimum; rank r handles packs r, r+world, ... and the minima are combined across ranks.  The reals are pulled from
     `training_set_rec` exactly as the reference's query loop does (2 * minibatch_size per call, data_size in all, :374-403).
     Returns (nearest_indices int64 [data_size], dists float64 [data_size]) as NumPy."""
     num_cand = latent_candidates.shape[0]
@@ -171,26 +171,36 @@ def imle_refresh(G, training_set_rec, latent_candidates, label_candidates, data_
         i += r.shape[0]
     rnorm = hip_ops.row_sqnorm_raw(reals)
     best_d2, best_idx = hip_ops.nn1_state(data_size, device)
-    nbatches = (num_cand + candidate_batch_size - 1) // candidate_batch_size
     resident = [] if exclusive_k > 1 else None      # exclusive assignment: this rank's candidates stay on the device (59 GB for CelebA-128)
+    # Candidates are generated `candidate_batch_size` at a time like the reference (:359-366) but searched in PACKS of several
+    # batches: the distance GEMM of one 256-candidate batch against a 4096-query chunk is 64 tiles -- a quarter of the
+    # device -- and ran at 31 TFLOP/s; a [query_chunk x dim] x [dim x pack] product fills it (profiles/r03_refresh_*.txt).
+    # The assignment is the exact minimum over all candidates, so it does not depend on how they are grouped.
+    pack = max(candidate_batch_size, (int(cand_pack) // candidate_batch_size) * candidate_batch_size)
+    npacks = (num_cand + pack - 1) // pack
+    # Inference batch: the reference feeds sched.minibatch_size at a time (G.run(..., minibatch_size=), :361); the images do not
+    # depend on how the candidates are batched, so use a batch that fills the MFMA tiles (bounded so that the largest
+    # intermediate, [n, C, 2R+1, 2R+1], stays under 2 GiB: the kernels address with 32-bit byte offsets).
+    per_img = 4 * max(training_set_rec.shape[0], 128) * (training_set_rec.shape[1] * 2 + 1) ** 2 // 4
+    infer_batch = infer_minibatch or int(max(minibatch_size, min(candidate_batch_size, 64, (1 << 30) // max(per_img, 1))))
+    pack_buf = None
     with torch.no_grad():
-        for b in range(rank, nbatches, world):
-            c0 = b * candidate_batch_size
-            z = torch.from_numpy(latent_candidates[c0:c0 + candidate_batch_size]).to(device)
-            lab = torch.from_numpy(np.ascontiguousarray(label_candidates[c0:c0 + candidate_batch_size], dtype=np.float32)).to(device)
-            imgs = []
-            # Inference batch: the reference feeds sched.minibatch_size at a time (G.run(..., minibatch_size=), :361);
-            # the images do not depend on how the candidates are batched, so use a batch that fills the MFMA
-            # tiles (bounded so that the largest intermediate, [n, C, 2R+1, 2R+1], stays under 2 GiB).
-            per_img = 4 * max(training_set_rec.shape[0], 128) * (training_set_rec.shape[1] * 2 + 1) ** 2 // 4
-            infer_batch = infer_minibatch or int(max(minibatch_size, min(candidate_batch_size, 64, (1 << 30) // max(per_img, 1))))
-            for j in range(0, z.shape[0], infer_batch):
-                imgs.append(G.get_output_for(z[j:j + infer_batch], lab[j:j + infer_batch], is_validation=True))
-            cand = torch.cat(imgs, dim=0).contiguous().reshape(z.shape[0], -1)   # logical NCHW flatten (:363)
+        for pk in range(rank, npacks, world):
+            c0 = pk * pack
+            n = min(pack, num_cand - c0)
+            if pack_buf is None or resident is not None:
+                pack_buf = torch.empty((min(pack, num_cand), pdim), device=device, dtype=torch.float32)
+            cand = pack_buf[:n]
+            z = torch.from_numpy(latent_candidates[c0:c0 + n]).to(device)
+            lab = torch.from_numpy(np.ascontiguousarray(label_candidates[c0:c0 + n], dtype=np.float32)).to(device)
+            for j in range(0, n, infer_batch):
+                img = G.get_output_for(z[j:j + infer_batch], lab[j:j + infer_batch], is_validation=True)
+                flat = img.contiguous().reshape(img.shape[0], -1)                     # logical NCHW flatten (:363)
+                if projector is not None:
+                    flat = hip_ops.matmul(flat, projector)                            # :365
+                cand[j:j + flat.shape[0]].copy_(flat)
             if not bool(torch.isfinite(cand).all()):
-                raise FloatingPointError('IMLE refresh: the generator produced non-finite candidate images (batch %d)' % b)
-            if projector is not None:
-                cand = hip_ops.matmul(cand, projector)                           # :365
+                raise FloatingPointError('IMLE refresh: the generator produced non-finite candidate images (candidates %d..%d)' % (c0, c0 + n))
             if resident is not None:
                 resident.append((c0, cand))
                 continue

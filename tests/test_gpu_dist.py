@@ -94,11 +94,11 @@ def test_two_rank_training_loop_keeps_replicas_identical(cuda_device, tmp_path):
 def test_bench_launches_its_own_ranks(cuda_device):
     """`python bench.py --gpus 2` with no launcher around it (the way the driver calls it): the parent spawns the ranks through
     torch.distributed.run before touching the GPU, the ranks run the real loop on their slices and rank 0 prints ONE JSON line with
-    the whole-job rate.  Both ranks share GPU 0 and talk over gloo here (test hooks in bench.py): everything but RCCL itself."""
+    the whole-job rate.  Both ranks share GPU 0 and talk over gloo here (--one-gpu --backend gloo): everything but RCCL itself."""
     import json
-    env = dict(os.environ, IGAN_BENCH_ONE_GPU='1', IGAN_BENCH_BACKEND='gloo')
+    env = dict(os.environ)
     env.pop('RANK', None); env.pop('WORLD_SIZE', None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--no-roofline', '--no-cpu-baseline',
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--one-gpu', '--backend', 'gloo', '--steps', '3', '--warmup', '1', '--no-roofline', '--no-cpu-baseline',
                         '--resolution', '32', '--minibatch-gpu', '3', '--data-size', '48', '--num-samples-factor', '2'],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
