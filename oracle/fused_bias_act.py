@@ -3,8 +3,10 @@
 fused_bias_act restated from dnnlib/tflib/ops/fused_bias_act.py:20-30,72-96 (forward, any
 activation) and the per-element derivative table of dnnlib/tflib/ops/fused_bias_act.cu:42-116
 (`fused_bias_act_kernel_ref`: what the CUDA op returns for grad = 0/1/2 given x, b, ref).
-Parity unpinned at the reference level (no tests there); pinned here by autograd of the forward
-agreeing with the grad=1 / grad=2 table (tests/test_oracle_ops.py).
+PINNED (round 3) for the table and the forward: tests/golden/ref_ops_golden.npz holds the reference's own activation_funcs
+fields and the outputs of its _fused_bias_act_ref executed with a NumPy stand-in for TF (tests/test_ref_ops_golden.py).  The
+.cu derivative table cannot be executed here: it stays pinned only by autograd of the forward agreeing with the
+grad=1 / grad=2 restatement (tests/test_oracle_ops.py).
 """
 import numpy as np
 import torch

@@ -11,8 +11,11 @@ and HWIO / [in,out] layouts (e.g. 'G_synthesis/64x64/Conv0_up/mod_weight'); rand
 an explicit `rand` object with .normal(shape) / .uniform(shape) / .randint(low, high) in the
 reference's call order (noise :352, style-mix latents :212, coin :218, cutoff :219).
 
-Parity unpinned at the reference level (TF code cannot run here, no reference tests); pinned by the
-fused == non-fused modconv identity and fp64 gradcheck (tests/test_oracle_networks.py).
+PINNED (round 3) to the reference's own code: tests/golden/ref_ops_golden.npz holds the outputs of training/networks_stylegan2.py
+EXECUTED with a NumPy stand-in for the TF primitives (tests/golden/make_ref_ops_golden.py, np_tf.py) -- every layer function, G_main in
+training / validation / fixed-noise mode, D, architectures orig / skip / resnet -- and tests/test_ref_ops_golden.py requires this file
+to reproduce them to 1e-10.  Unpinned remainder: the TF primitives' own semantics (np_tf.py lists them) and the backward pass
+(tf.gradients), which is checked by fp64 gradcheck and the fused == non-fused identity (tests/test_oracle_networks.py).
 """
 import numpy as np
 import torch
@@ -45,16 +48,16 @@ def get_weight(sc, shape, gain=1, use_wscale=True, lrmul=1, weight_var='weight')
     return w * float(runtime_coef)
 
 
-def dense_layer(sc, x, fmaps, gain=1, lrmul=1, weight_var='weight'):
+def dense_layer(sc, x, fmaps, gain=1, use_wscale=True, lrmul=1, weight_var='weight'):
     if x.dim() > 2:
         x = x.reshape(x.shape[0], -1)
-    w = get_weight(sc, [x.shape[1], fmaps], gain=gain, lrmul=lrmul, weight_var=weight_var)
+    w = get_weight(sc, [x.shape[1], fmaps], gain=gain, use_wscale=use_wscale, lrmul=lrmul, weight_var=weight_var)
     return x @ w
 
 
-def conv2d_layer(sc, x, fmaps, kernel, up=False, down=False, resample_kernel=None, gain=1, lrmul=1, weight_var='weight'):
+def conv2d_layer(sc, x, fmaps, kernel, up=False, down=False, resample_kernel=None, gain=1, use_wscale=True, lrmul=1, weight_var='weight'):
     assert not (up and down)
-    w = get_weight(sc, [kernel, kernel, x.shape[1], fmaps], gain=gain, lrmul=lrmul, weight_var=weight_var)
+    w = get_weight(sc, [kernel, kernel, x.shape[1], fmaps], gain=gain, use_wscale=use_wscale, lrmul=lrmul, weight_var=weight_var)
     if up:
         return U.upsample_conv_2d(x, w, k=resample_kernel)
     if down:
@@ -179,7 +182,7 @@ def G_synthesis_stylegan2(sc, dlatents_in, rand, resolution=1024, num_channels=3
 def G_main(params, latents_in, rand, resolution, num_channels=3, fmap_base=16 << 10, architecture='skip',
            is_training=False, is_validation=False, return_dlatents=False, truncation_psi=0.6, truncation_cutoff=None,
            truncation_psi_val=None, truncation_cutoff_val=None, dlatent_avg_beta=0.995, style_mixing_prob=0.9,
-           fused_modconv=True, state=None):
+           fused_modconv=True, state=None, dlatent_size=512, mapping_fmaps=512, randomize_noise=True):
     """`state` (dict) receives the updated non-trainable 'dlatent_avg' (tf.assign :205)."""
     sc = Scope(params)
     if is_validation:
@@ -194,7 +197,8 @@ def G_main(params, latents_in, rand, resolution, num_channels=3, fmap_base=16 <<
         style_mixing_prob = None
     num_layers = int(np.log2(resolution)) * 2 - 2
     msc = sc.sub('G_mapping')
-    dlatents = G_mapping(msc, latents_in, dlatent_broadcast=num_layers)
+    mkw = dict(dlatent_size=dlatent_size, mapping_fmaps=mapping_fmaps)
+    dlatents = G_mapping(msc, latents_in, dlatent_broadcast=num_layers, **mkw)
     if dlatent_avg_beta is not None:
         batch_avg = dlatents[:, 0].mean(dim=0).detach()
         new_avg = batch_avg + (sc.get('dlatent_avg') - batch_avg) * dlatent_avg_beta     # lerp(batch_avg, avg, beta)
@@ -202,7 +206,7 @@ def G_main(params, latents_in, rand, resolution, num_channels=3, fmap_base=16 <<
             state['dlatent_avg'] = new_avg
     if style_mixing_prob is not None:
         latents2 = rand.normal(list(latents_in.shape)).to(latents_in.dtype)              # :212
-        dlatents2 = G_mapping(msc, latents2, dlatent_broadcast=num_layers)
+        dlatents2 = G_mapping(msc, latents2, dlatent_broadcast=num_layers, **mkw)
         layer_idx = torch.arange(num_layers)[None, :, None]
         u = float(rand.uniform([]))                                                      # :218
         r = int(rand.randint(1, num_layers))                                             # :219 (evaluated by tf.cond only if taken;
@@ -218,7 +222,7 @@ def G_main(params, latents_in, rand, resolution, num_channels=3, fmap_base=16 <<
         avg = sc.get('dlatent_avg')
         dlatents = avg + (dlatents - avg) * torch.as_tensor(layer_psi, dtype=dlatents.dtype)   # lerp(avg, dlatents, psi)
     images = G_synthesis_stylegan2(sc.sub('G_synthesis'), dlatents, rand, resolution=resolution, num_channels=num_channels,
-                                   fmap_base=fmap_base, architecture=architecture, fused_modconv=fused_modconv)
+                                   fmap_base=fmap_base, architecture=architecture, fused_modconv=fused_modconv, randomize_noise=randomize_noise)
     if return_dlatents:
         return images, dlatents
     return images

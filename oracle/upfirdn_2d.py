@@ -15,7 +15,11 @@ CPU restatement (NumPy / PyTorch-CPU, any float dtype) of the reference's resamp
 Pinning: the reference holds no test or golden vector for this path, and
 TensorFlow is not installable here, so the restatement is pinned by (i) the two independent
 formulations above agreeing, (ii) analytic known answers (tests/test_oracle_ops.py), (iii) fp64
-gradcheck of the gradient parameters.  PARITY UNPINNED at the reference level.
+gradcheck of the gradient parameters, and -- since round 3 -- (iv) PINNED to the reference's own statements: tests/golden/
+ref_ops_golden.npz holds the results of EXECUTING dnnlib/tflib/ops/upfirdn_2d.py (all of the functions above, plus the
+gradient definition of _upfirdn_2d_cuda to second order) with a NumPy stand-in for the TF primitives (tests/golden/np_tf.py);
+tests/test_ref_ops_golden.py requires this file to reproduce them to 1e-11.  Unpinned remainder: the semantics of tf.nn.conv2d /
+conv2d_transpose / tf.pad themselves (restated in np_tf.py from TensorFlow's documentation).
 """
 import numpy as np
 import torch
