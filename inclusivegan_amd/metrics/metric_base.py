@@ -54,6 +54,7 @@ class MetricBase:
         self._network_pkl, self._data_dir, self._dataset_args = source, data_dir, dataset_args
         self._mirror_augment = bool(mirror_augment)
         self._eval_time, self._results = 0, []
+        self._label_rng = None      # private stream for the generator's label draws (see _get_random_labels)
 
     def close(self):
         self._configure()
@@ -112,11 +113,23 @@ class MetricBase:
             batch = source.get_minibatch_np(minibatch_size)[0]
             yield misc.apply_mirror_augment(batch) if self._mirror_augment else batch
 
+    def _get_random_labels(self, minibatch_size, Gs):
+        """Label rows drawn from the data set (metric_base.py:139-140 `_get_random_labels_tf`; used by every metric's generator
+        graph, e.g. frechet_inception_distance.py:54): a conditional G is evaluated on labels it was trained on, not on zeros."""
+        want = int(Gs.input_shapes[1][1]) if len(Gs.input_shapes[1]) > 1 else 0
+        if want == 0:
+            return torch.zeros([minibatch_size, 0], device=Gs.device)
+        if self._label_rng is None:
+            self._label_rng = np.random.RandomState(0x1ab)
+        labels = np.asarray(self._get_dataset_obj().get_random_labels_np(minibatch_size, rng=self._label_rng), dtype=np.float32)
+        assert labels.shape == (minibatch_size, want), (labels.shape, want)
+        return torch.from_numpy(labels).to(Gs.device)
+
     def _generate(self, Gs, minibatch_size, Gs_kwargs, as_uint8=True):
-        """One minibatch of fakes from Gs: latents ~ N(0, I) on the device, random labels (metric_base.py:139-146 / the
-        per-GPU graphs of the metric files), optionally converted like tflib.convert_images_to_uint8."""
+        """One minibatch of fakes from Gs: latents ~ N(0, I) on the device, label rows drawn from the data set (metric_base.py:139-146 /
+        the per-GPU graphs of the metric files), optionally converted like tflib.convert_images_to_uint8."""
         latents = tfutil.random_normal([minibatch_size] + Gs.input_shapes[0][1:], Gs.device)
-        labels = torch.zeros([minibatch_size] + Gs.input_shapes[1][1:], device=Gs.device)
+        labels = self._get_random_labels(minibatch_size, Gs)
         images = Gs.get_output_for(latents, labels, **Gs_kwargs)
         return convert_images_to_uint8(images) if as_uint8 else images
 

@@ -84,9 +84,16 @@ def run(attr_file=None, **args):
     from .training import training_loop as TL
     from .training import imle
     kw = build_kwargs(**args)
+    run_desc = kw['run_desc']
     for k in ('run_func_name', 'num_gpus', 'run_desc'):
         kw.pop(k)
     kw = copy.deepcopy(kw)
+    # the run directory dnnlib.submit_run would create: <result_dir>/<next 5-digit id>-<run_desc> (dnnlib/submission/submit.py:_create_run_dir_local)
+    result_dir = args.get('result_dir')
+    if result_dir is not None and int(os.environ.get('RANK', '0')) == 0:
+        os.makedirs(result_dir, exist_ok=True)
+        ids = [int(d.split('-')[0]) for d in os.listdir(result_dir) if d.split('-')[0].isdigit() and os.path.isdir(os.path.join(result_dir, d))]
+        kw['run_dir'] = os.path.join(result_dir, '%05d-%s' % (max(ids) + 1 if ids else 0, run_desc))
     # synthetic data source (no tfrecords reader in this round): shape follows the dataset name
     ds = kw['dataset_args']
     if 'mnist' in ds['tfrecord_dir']:

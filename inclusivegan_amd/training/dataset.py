@@ -85,9 +85,12 @@ class SyntheticDataset:
         tidx = (self._dev_arange[:per] + (start + self.rank * per)) % self.data_size
         return self._dev_images[tidx], self._dev_labels[tidx]
 
-    def get_random_labels_np(self, minibatch_size):  # => labels
-        if self.label_size > 0:      # the GLOBAL NumPy stream, like dataset.py:163-166 (the host loop's draws depend on it)
-            return self._labels[np.random.randint(self._labels.shape[0], size=[minibatch_size])]
+    def get_random_labels_np(self, minibatch_size, rng=None):  # => labels
+        """`rng` None: the GLOBAL NumPy stream, like dataset.py:163-166 (the host loop's draws depend on it).  The metrics pass
+        their own generator: the reference draws THEIR labels with TensorFlow ops (dataset.py:159-161), which leaves the NumPy
+        stream the training loop reads untouched."""
+        if self.label_size > 0:
+            return self._labels[(rng or np.random).randint(self._labels.shape[0], size=[minibatch_size])]
         return np.zeros([minibatch_size, 0], np.float32)
 
     def get_random_labels_tf(self, minibatch_size):  # => labels

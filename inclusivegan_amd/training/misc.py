@@ -3,7 +3,7 @@ adjust_dynamic_range (:36-41) and the NumPy slerp / normalize pair (:190-203) th
 matched IMLE latents (training_loop.py:447), plus the snapshot helpers the loop's setup touches: pickle wrappers
 (:25-31), image grids (:43-74) and `setup_snapshot_image_grid` (:95-143), which advances the training set's iterator and
 fixes how many `grid_latents` are drawn from the host random stream before the IMLE candidates (training_loop.py:171,203).
-Resume bookkeeping from log files (:147-187) is run-directory maintenance and not built."""
+and the resume bookkeeping that reads a snapshot's kimg / elapsed time back from its run directory's log.txt (:147-187)."""
 import numpy as np
 
 
@@ -123,13 +123,22 @@ def resume_kimg_time(network_pkl):
     path, file = os.path.split(network_pkl)
     kimg = str(int(os.path.splitext(file)[0][-6:]))
     s = 0.0
+    if not os.path.isfile('%s/log.txt' % path):       # a snapshot copied away from its run directory: resume at its kimg, clock at zero
+        return float(kimg), s
     with open('%s/log.txt' % path, 'r') as f:
         for line in f:
             if all(w in line for w in ('tick', 'kimg', 'minibatch', 'time', 'sec/tick', 'sec/kimg', 'maintenance', 'gpumem')) and kimg in line:
                 idx = line.find(kimg)
                 kimg = float(line[idx:idx + len(kimg) + 2])
                 idx = line.find('time')
-                s = time_to_seconds(line[idx + 5:idx + 5 + 12])
+                try:
+                    s = time_to_seconds(line[idx + 5:idx + 5 + 12])
+                except ValueError:
+                    # the reference's parser cannot read a single-digit leading field ('7s', '3m 05s': it would crash on resuming a
+                    # run younger than ten minutes... which takes this engine seconds to produce); read such strings field by field
+                    import re
+                    found = dict((u, int(v)) for v, u in re.findall(r'(\d+)([dhms])', line[idx + 5:idx + 5 + 12]))
+                    s = float(((found.get('d', 0) * 24 + found.get('h', 0)) * 60 + found.get('m', 0)) * 60 + found.get('s', 0))
                 break
     return float(kimg), s
 

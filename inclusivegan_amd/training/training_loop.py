@@ -18,8 +18,9 @@ per-real minima (fp64 distance, index) are combined with two all-reduce(min).
 
 With `run_dir` set, rank 0 writes the reference's snapshots at its cadence (:165-166,506-519): image grids of Gs on fixed
 latents, the reconstruction pairs of the IMLE term, and (G, D, Gs) pickles in the reference's own layout (training/misc.py);
-`resume_pkl` continues from such a pickle -- or from one the reference wrote.  Metric scheduling and tfevents stay out
-(SURVEY.md section 2.1).  A `hooks` dict lets a driver (bench.py, tests) observe iterations and stop early.
+`resume_pkl` continues from such a pickle -- or from one the reference wrote; the tick lines are teed into run_dir/log.txt (the
+file resume reads its kimg / time from, misc.py:147-162), `metric_arg_list` is evaluated on every network snapshot (:519) and a
+final snapshot is written (:527-530).  tfevents stay out.  A `hooks` dict lets a driver (bench.py, tests) observe iterations and stop early.
 """
 import functools
 import os
@@ -370,6 +371,8 @@ def training_loop(
     if rank == 0:
         G.print_layers(); D.print_layers()
     sched = training_schedule(cur_nimg=0, training_set=training_set, **sched_args)
+    from ..metrics import metric_base
+    metrics = metric_base.MetricGroup(metric_arg_list)       # :198
 
     # Setup optimizers (:242-255).
     cur_lrate = [sched.G_lrate]
@@ -548,6 +551,8 @@ def training_loop(
     tick_start_nimg = cur_nimg
     tick_start_time = time.time()
     start_time = tick_start_time
+    maintenance_time = 0.0
+    final_grids = None
     running_mb_counter = 0
     latent_candidates = np.random.randn(data_size * num_samples_factor, *G.input_shapes[0][1:]).astype(np.float32)  # :325
 
@@ -633,7 +638,7 @@ def training_loop(
                     stop = True
                     break
 
-        # Per-tick progress line (:485-505); snapshots / metrics are out of scope.
+        # Per-tick maintenance (:485-525): progress line (teed into run_dir/log.txt), snapshots, metrics on network snapshots.
         done = (cur_nimg >= total_kimg * 1000) or stop
         if cur_tick < 0 or cur_nimg >= tick_start_nimg + sched.tick_kimg * 1000 or done:
             cur_tick += 1
@@ -641,15 +646,18 @@ def training_loop(
             now = time.time()
             tick_kimg = max((cur_nimg - tick_start_nimg) / 1000.0, 1e-9)
             tick_time = now - tick_start_time
+            total_time = now - start_time + resume_time
             sums = autosummary_mod.flush()
             if rank == 0:
-                print('tick %-5d kimg %-8.1f lod %-5.2f minibatch %-4d time %-12s sec/tick %-7.1f sec/kimg %-7.2f gpumem %.1f' % (
-                    cur_tick, cur_nimg / 1000.0, sched.lod, sched.minibatch_size, dnnlib.util.format_time(now - start_time),
-                    tick_time, tick_time / tick_kimg, torch.cuda.max_memory_allocated() / 2**30))
-                for k, v in sums.items():
-                    print('    %-32s %g' % (k, v))
+                lines = ['tick %-5d kimg %-8.1f lod %-5.2f minibatch %-4d time %-12s sec/tick %-7.1f sec/kimg %-7.2f maintenance %-6.1f gpumem %.1f' % (
+                    cur_tick, cur_nimg / 1000.0, sched.lod, sched.minibatch_size, dnnlib.util.format_time(total_time),
+                    tick_time, tick_time / tick_kimg, maintenance_time, torch.cuda.max_memory_allocated() / 2**30)]       # the reference's line, field for field (:495-504)
+                lines += ['    %-32s %g' % (k, v) for k, v in sums.items()]
+                print('\n'.join(lines))
+                if run_dir is not None:
+                    with open(os.path.join(run_dir, 'log.txt'), 'a') as f:
+                        f.write('\n'.join(lines) + '\n')
             tick_start_nimg = cur_nimg
-            tick_start_time = now
 
             # Save snapshots (:506-519); rank 0 only, and only when a run directory was asked for.
             if run_dir is not None and rank == 0:
@@ -665,8 +673,23 @@ def training_loop(
                             tick_reals_old = np.array(t_reals)
                         fakes_nn = Gs.run(t_latents, t_labels, is_validation=True, minibatch_size=sched.minibatch_gpu)
                         misc.save_image_grid(fakes_nn, snap('rec-fakes-%06d.png' % (cur_nimg // 1000)), drange=drange_net, grid_size=rec_grid)
+                        final_grids = (grid_fakes, fakes_nn, rec_grid)
                 if network_snapshot_ticks is not None and (cur_tick % max(network_snapshot_ticks, 1) == 0 or done):
-                    misc.save_pkl((G, D, Gs), snap('network-snapshot-%06d.pkl' % (cur_nimg // 1000)), reference_layout=True, build_module_src=module_src)
+                    pkl = snap('network-snapshot-%06d.pkl' % (cur_nimg // 1000))
+                    misc.save_pkl((G, D, Gs), pkl, reference_layout=True, build_module_src=module_src)
+                    metrics.run(pkl, run_dir=run_dir, data_dir=data_dir, dataset_args=ds_args, mirror_augment=mirror_augment,
+                                num_gpus=min([2, num_gpus]), tf_config=tf_config, device=device)                   # :519
+            metrics.update_autosummaries()                                                                        # :522
+            torch.cuda.synchronize()
+            tick_start_time = time.time()
+            maintenance_time = tick_start_time - now
+
+    # Save final snapshot (:527-530).
+    if run_dir is not None and rank == 0:
+        if final_grids is not None:
+            misc.save_image_grid(final_grids[0], os.path.join(run_dir, 'arb-fakes-final.png'), drange=drange_net, grid_size=grid_size)
+            misc.save_image_grid(final_grids[1], os.path.join(run_dir, 'rec-fakes-final.png'), drange=drange_net, grid_size=final_grids[2])
+        misc.save_pkl((G, D, Gs), os.path.join(run_dir, 'network-final.pkl'), reference_layout=True, build_module_src=module_src)
 
     training_set.close()
     training_set_rec.close()

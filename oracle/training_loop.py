@@ -129,3 +129,16 @@ def imle_host_loop(training_set, training_set_rec, latent_shape, generate, make_
             cur_nimg += mb * 2                                                                # :481
     log.update(final_cursor=cursor, final_staleness=init_staleness)
     return log
+
+
+def process_reals(x, labels, lod, mirror_augment, drange_data, drange_net, coin=None):
+    """training_loop.py:40-60 in NumPy: cast to float32 (:42), dynamic range (:43-44), random mirror (:45-49: a per-image uniform
+    draw `coin` < 0.5 keeps the image, otherwise it is reversed along W -- tf.where(coin < 0.5, x, reverse(x, [3]))), then the
+    level-of-detail fade (:50-57) and upscale (:58-59), which are the identity at lod = 0 -- the only value configs e/f produce."""
+    x = np.asarray(x).astype(np.float32)
+    x = adjust_dynamic_range(x, list(drange_data), list(drange_net))
+    if mirror_augment:
+        coin = np.asarray(coin, np.float32).reshape(-1, 1, 1, 1)
+        x = np.where(coin < 0.5, x, x[:, :, :, ::-1])
+    assert lod == 0
+    return x, labels

@@ -10,6 +10,8 @@ Fixtures:
                            (dnnlib.submit_run monkey-patched to capture instead of launching)
   dci_golden.npz           seeded (data, queries) + the reference DCI library's (idx, dist) with the
                            training-time parameters (training_loop.py:197,368,398)
+  grid_golden.npz          training/misc.py: create_image_grid, convert_to_pil_image, setup_snapshot_image_grid (every size /
+                           layout) on a small stand-in data set, apply_mirror_augment, time_to_seconds (python make_golden.py grids)
 """
 import json
 import os
@@ -94,9 +96,68 @@ def make_dci():
     np.savez(os.path.join(HERE, 'dci_golden.npz'), data=data, queries=queries, idx=idx[:, 0], dist=dist[:, 0])
 
 
+class GridSet:
+    """Stand-in for the training set object setup_snapshot_image_grid walks (shape, dtype, label_size, label_dtype,
+    get_minibatch_np): image i carries i in every pixel (mod 251) and the label one_hot(LABEL_SEQ[i])."""
+    LABEL_SEQ = [0, 2, 1, 1, 0, 2, 2, 0, 1, 0, 1, 2, 2, 1, 0, 0, 0, 1, 2, 2, 1, 1, 0, 2]
+
+    def __init__(self, shape, label_size=3):
+        self.shape, self.dtype, self.label_size, self.label_dtype, self.cur = list(shape), 'uint8', label_size, 'float32', 0
+
+    def get_minibatch_np(self, n):
+        idx = (self.cur + np.arange(n)) % 240
+        self.cur += n
+        imgs = np.broadcast_to((idx % 251).astype(np.uint8)[:, None, None, None], [n] + self.shape).copy()
+        labels = np.zeros((n, self.label_size), np.float32)
+        labels[np.arange(n), [self.LABEL_SEQ[i % len(self.LABEL_SEQ)] % self.label_size for i in idx]] = 1
+        return imgs, labels
+
+
+def make_grids():
+    sys.path.insert(0, REF)
+    from training import misc
+    rng = np.random.RandomState(321)
+    out = {}
+    for j, (shape, gs) in enumerate([((7, 3, 5, 4), None), ((7, 3, 5, 4), (4, 2)), ((5, 6, 6), None), ((1, 1, 4, 4), None), ((12, 3, 2, 3), (3, 5))]):
+        imgs = rng.rand(*shape).astype(np.float32)
+        out['grid_%d_in' % j] = imgs
+        out['grid_%d_size' % j] = np.array(gs if gs is not None else (-1, -1))
+        out['grid_%d_out' % j] = misc.create_image_grid(imgs, gs)
+    for j, (img, drange) in enumerate([(rng.rand(3, 6, 5) * 2 - 1, [-1, 1]), (rng.rand(1, 6, 5) * 255, [0, 255]), (rng.rand(6, 5), [0, 1])]):
+        out['pil_%d_in' % j], out['pil_%d_drange' % j] = img, np.array(drange)
+        out['pil_%d_out' % j] = np.array(misc.convert_to_pil_image(img, drange))
+    k = 0
+    for shape in ([1, 540, 640], [3, 128, 128], [3, 32, 32]):
+        for size in ('1080p', '4k', '8k', 'other'):
+            for layout in ('random', 'row_per_class', 'col_per_class', 'class4x4'):
+                if shape[1] < 128 and (size != '1080p' or layout not in ('random', 'row_per_class')):
+                    continue        # 32x32 grids are 32 x 32 cells: two cases are enough
+                ts = GridSet(shape)
+                (gw, gh), reals, labels = misc.setup_snapshot_image_grid(ts, size=size, layout=layout)
+                out['snap_%d_cfg' % k] = np.array([shape[0], shape[1], shape[2], ['1080p', '4k', '8k', 'other'].index(size),
+                                                  ['random', 'row_per_class', 'col_per_class', 'class4x4'].index(layout)])
+                out['snap_%d_grid' % k] = np.array([gw, gh, ts.cur])
+                out['snap_%d_ids' % k] = reals[:, 0, 0, 0].copy()
+                out['snap_%d_labels' % k] = labels
+                k += 1
+    out['snap_cases'] = np.array(k)
+    np.random.seed(5)
+    mb = rng.randint(0, 256, size=(9, 3, 4, 6)).astype(np.uint8)
+    out['mirror_in'], out['mirror_out'] = mb, misc.apply_mirror_augment(mb)
+    strings = ['0s', '59s', '1m 00s', '12m 34s', '1h 00m 00s', '9h 59m 59s', '1d 00h 00m', '12d 23h 59m']
+    def tts(x):        # the reference's parser raises on single-digit seconds ('5s'): recorded as NaN (error behaviour is part of the surface)
+        try:
+            return misc.time_to_seconds(x)
+        except ValueError:
+            return np.nan
+    out['tts_in'], out['tts_out'] = np.array(strings + ['5s']), np.array([tts(x) for x in strings + ['5s']])
+    np.savez_compressed(os.path.join(HERE, 'grid_golden.npz'), **out)
+
+
 if __name__ == '__main__':
     os.chdir(REF)
-    make_misc()
-    make_run_training()
-    make_dci()
+    which = sys.argv[1:] or ['misc', 'run_training', 'dci', 'grids']
+    for name, fn in (('misc', make_misc), ('run_training', make_run_training), ('dci', make_dci), ('grids', make_grids)):
+        if name in which:
+            fn()
     print('golden fixtures written to', HERE)
