@@ -342,6 +342,7 @@ extern "C" int igan_bias_act_noise_bwd_dd(igan_stream_t stream_, const float* dy
     IGAN_REQUIRE((noise == nullptr) || (strength != nullptr && dstrength != nullptr), "bias_act_noise_bwd_dd: noise given without strength / dstrength");
     IGAN_REQUIRE(N >= 1 && HW >= 1 && (long long)N * HW <= INT32_MAX, "bias_act_noise_bwd_dd: bad sizes");
     if (int rc = ban_check("bias_act_noise_bwd_dd", N * HW, C, act, gain)) return rc;
+    IGAN_REQUIRE(noise == nullptr || C <= 1024, "bias_act_noise_bwd_dd: with noise C must be <= 1024 (the noise-strength partial is reduced by the first block column only)");
     IGAN_REQUIRE(act == 1 || act == 3, "bias_act_noise_bwd_dd: the pre-activation value is recovered from y: linear or lrelu only");
     IGAN_REQUIRE(act != 3 || alpha > 0.0f, "bias_act_noise_bwd_dd: lrelu slope must be positive");
     IGAN_REQUIRE((((uintptr_t)dy | (uintptr_t)y | (uintptr_t)dx | (uintptr_t)b) & 15) == 0, "bias_act_noise_bwd_dd: buffers must be 16-byte aligned");

@@ -131,42 +131,59 @@ class DCI(object):
         """k > 1 neighbours (the exclusive IMLE assignment asks for num_samples_factor of them, training_loop.py:386):
         (int64 idx [nq, k], fp64 Euclidean dist [nq, k]), ascending, ties to the lower index.  Screening on the fp32 MFMA
         products keeps the k + margin best candidates per query over all candidate batches; those are then measured exactly
-        (direct differences in fp64, compute_dist of dci_code/src/util.c:62-69) and re-ranked -- the same two-step rule as the
-        1-NN kernel, with the exact pass done by torch ops (a non-default path: the reference's default is k = 1)."""
+        (direct differences in fp64, compute_dist of dci_code/src/util.c:62-69) and re-ranked by torch ops (a non-default path: the
+        reference's default is k = 1).  The short list is PROVEN sufficient before it is trusted: every candidate that was
+        screened out has an approximate squared distance of at least the worst kept one, hence an exact one of at least that
+        minus the screening error bound tol * (|q|^2 + max |c|^2) (the 1-NN kernel's nn1_tol); if that does not exceed the exact
+        k-th distance found, the margin is quadrupled and the chunk is searched again (up to keeping every candidate)."""
         nq = int(q.shape[0])
         n = self.num_points
-        keep = min(n, k + margin)
         out_i = torch.empty((nq, k), device=self.device, dtype=torch.int64)
         out_d = torch.empty((nq, k), device=self.device, dtype=torch.float64)
+        tol = max(2.0 ** -22 * float(np.sqrt(self.dim)), 1e-6)
+        cmax = float(self._norms.max()) if n else 0.0
+        self.last_margins = []
         for q0 in range(0, nq, self.query_chunk):
             qs = q[q0:q0 + self.query_chunk]
             qn = hip_ops.row_sqnorm_raw(qs).double()
-            best_v = None
-            best_i = None
-            for c0 in range(0, n, self.cand_chunk):
-                cs = self._data[c0:c0 + self.cand_chunk]
-                dots = hip_ops.conv2d_raw(qs.reshape(qs.shape[0], self.dim, 1, 1), cs.reshape(1, 1, cs.shape[0], self.dim),
-                                          hip_ops.ConvGeom(1, 1, 1, 1, 0, 0), (1, 1), cs.shape[0], w_transposed=True).reshape(qs.shape[0], -1)
-                d2 = qn[:, None] + self._norms[c0:c0 + self.cand_chunk].double()[None, :] - 2.0 * dots.double()
-                d2 = torch.where(torch.isfinite(d2), d2, torch.full_like(d2, float('inf')))
-                ci = torch.arange(c0, c0 + cs.shape[0], device=self.device)[None, :].expand_as(d2)
-                if best_v is not None:
-                    d2 = torch.cat([best_v, d2], dim=1)
-                    ci = torch.cat([best_i, ci], dim=1)
-                v, j = torch.topk(d2, min(keep, d2.shape[1]), dim=1, largest=False)
-                best_v, best_i = v, torch.gather(ci, 1, j)
-            # exact fp64 distances of the survivors, re-ranked by (distance, index)
-            for r0 in range(0, qs.shape[0], rerank_chunk):
-                qq = qs[r0:r0 + rerank_chunk].double()
-                ii = best_i[r0:r0 + rerank_chunk]
-                diff = self._data[ii.reshape(-1)].double().reshape(ii.shape[0], ii.shape[1], self.dim) - qq[:, None, :]
-                e = (diff * diff).sum(dim=2)
-                e = torch.where(torch.isfinite(e), e, torch.full_like(e, float('inf')))
-                order = torch.argsort(ii, dim=1, stable=True)                       # lower index first among equal distances
-                e, ii = torch.gather(e, 1, order), torch.gather(ii, 1, order)
-                order = torch.argsort(e, dim=1, stable=True)
-                out_i[q0 + r0:q0 + r0 + qq.shape[0]] = torch.gather(ii, 1, order)[:, :k]
-                out_d[q0 + r0:q0 + r0 + qq.shape[0]] = torch.sqrt(torch.gather(e, 1, order)[:, :k])
+            m = margin
+            while True:
+                keep = min(n, k + m)
+                best_v = None
+                best_i = None
+                for c0 in range(0, n, self.cand_chunk):
+                    cs = self._data[c0:c0 + self.cand_chunk]
+                    dots = hip_ops.conv2d_raw(qs.reshape(qs.shape[0], self.dim, 1, 1), cs.reshape(1, 1, cs.shape[0], self.dim),
+                                              hip_ops.ConvGeom(1, 1, 1, 1, 0, 0), (1, 1), cs.shape[0], w_transposed=True).reshape(qs.shape[0], -1)
+                    d2 = qn[:, None] + self._norms[c0:c0 + self.cand_chunk].double()[None, :] - 2.0 * dots.double()
+                    d2 = torch.where(torch.isfinite(d2), d2, torch.full_like(d2, float('inf')))
+                    ci = torch.arange(c0, c0 + cs.shape[0], device=self.device)[None, :].expand_as(d2)
+                    if best_v is not None:
+                        d2 = torch.cat([best_v, d2], dim=1)
+                        ci = torch.cat([best_i, ci], dim=1)
+                    v, j = torch.topk(d2, min(keep, d2.shape[1]), dim=1, largest=False)
+                    best_v, best_i = v, torch.gather(ci, 1, j)
+                # exact fp64 distances of the survivors, re-ranked by (distance, index)
+                es, iis = [], []
+                for r0 in range(0, qs.shape[0], rerank_chunk):
+                    qq = qs[r0:r0 + rerank_chunk].double()
+                    ii = best_i[r0:r0 + rerank_chunk]
+                    diff = self._data[ii.reshape(-1)].double().reshape(ii.shape[0], ii.shape[1], self.dim) - qq[:, None, :]
+                    e = (diff * diff).sum(dim=2)
+                    e = torch.where(torch.isfinite(e), e, torch.full_like(e, float('inf')))
+                    order = torch.argsort(ii, dim=1, stable=True)                       # lower index first among equal distances
+                    e, ii = torch.gather(e, 1, order), torch.gather(ii, 1, order)
+                    order = torch.argsort(e, dim=1, stable=True)
+                    es.append(torch.gather(e, 1, order)[:, :k]); iis.append(torch.gather(ii, 1, order)[:, :k])
+                e_k, i_k = torch.cat(es), torch.cat(iis)
+                # sufficiency: no screened-out candidate can be closer than the k-th exact distance
+                floor = best_v[:, -1] - tol * (qn + cmax)
+                if keep >= n or bool((floor > e_k[:, -1]).all()):
+                    break
+                m *= 4
+            self.last_margins.append(m)
+            out_i[q0:q0 + qs.shape[0]] = i_k
+            out_d[q0:q0 + qs.shape[0]] = torch.sqrt(e_k)
         return out_i, out_d
 
     def clear(self):

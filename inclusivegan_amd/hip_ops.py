@@ -977,7 +977,7 @@ def modconv_ban_fusable(x, w, d, b, noise, act_idx):
     """The fused layer applies on the first-order path, with demodulation, a piecewise-linear invertible activation, MFMA-sized
     channel counts and 16 B paths; everything else takes the two-Function form."""
     return (_MODCONV_BAN and _second_order_depth == 0 and not _is_meta(x) and x.is_cuda and d is not None and b is not None
-            and act_idx in (1, 3) and x.shape[1] % 32 == 0 and w.shape[3] % 32 == 0 and x.shape[1] >= 32 and w.shape[3] >= 32)
+            and act_idx in (1, 3) and x.shape[1] % 32 == 0 and w.shape[3] % 32 == 0 and x.shape[1] >= 32 and 32 <= w.shape[3] <= 1024)    # <= 1024: the backward's noise-strength partial is one block column wide (igan_bias_act_noise_bwd_dd)
 
 
 _MODCONV_BAN = os.environ.get('IGAN_MODCONV_BAN', '1') != '0'      # A/B switch

@@ -222,6 +222,33 @@ def test_nn1_near_ties_decided_in_fp64(cuda_device):
     assert bool(torch.isfinite(bd).all()) and not bool(((bi == 3) | (bi == 5)).any())
 
 
+def test_knn_short_list_is_widened_when_many_candidates_nearly_coincide(cuda_device):
+    """k > 1 (the exclusive assignment): 40 candidates per query within 2^-12 relative of one another at dim 49 152 -- far more
+    than the k + 8 short list of the fp32 screening, and indistinguishable to it.  query_device_k must notice that the list
+    cannot be proven sufficient, widen it, and return the fp64 brute-force k nearest (distance, then index)."""
+    from inclusivegan_amd.dci_code.dci import DCI
+    dev = cuda_device
+    rng = np.random.RandomState(9)
+    dim, nq, n, k = 49152, 6, 400, 5
+    q = rng.uniform(-1, 1, size=(nq, dim)).astype(np.float32)
+    c = rng.uniform(-1, 1, size=(n, dim)).astype(np.float32)
+    for i in range(nq):
+        slots = rng.choice(n // nq, size=40, replace=False) * nq + i         # disjoint slot sets per query
+        for r, slot in enumerate(rng.permutation(slots)):
+            row = q[i].copy()
+            j = rng.randint(dim)
+            row[j] = np.float32(row[j] + 0.1 * (1.0 + r * 2.0 ** -12) * (1 if row[j] < 0 else -1))
+            c[slot] = row
+    d = np.sqrt(((q[:, None, :].astype(np.float64) - c[None, :, :].astype(np.float64)) ** 2).sum(-1))
+    want = np.lexsort((np.broadcast_to(np.arange(n), d.shape), d), axis=1)[:, :k]
+    db = DCI(dim, device=dev)
+    db.add(torch.from_numpy(c).to(dev))
+    idx, dist = db.query_device_k(torch.from_numpy(q).to(dev), k)
+    assert max(db.last_margins) > 8, 'the planted near-ties did not force a wider short list: the test no longer probes the check'
+    assert np.array_equal(idx.cpu().numpy(), want)
+    assert np.abs(dist.cpu().numpy() - np.take_along_axis(d, want, 1)).max() <= 1e-12 * d.max()
+
+
 @pytest.mark.parametrize('case', [('G 128 Conv1', 6, 128, 128, 128, True), ('G 32 Conv1 (4 calls)', 24, 512, 32, 512, True), ('G 8 Conv1', 24, 512, 8, 512, False)],
                          ids=lambda c: c[0])
 def test_fused_synthesis_layer_against_fp64_samples_full_size(case, cuda_device):
