@@ -297,6 +297,7 @@ def training_loop(
     lpips_func_name         = 'inclusivegan_amd.metrics.lpips.vgg16_zhang_perceptual',
     hooks                   = None,     # {'on_iteration': f(state) -> bool stop, 'on_refresh': f(seconds), 'on_batch': f(host batch dict),
                                         #  'on_start': f(state) before the first iteration, 'on_op': f(step name, output, feed) after each training op,
+                                        #  'on_assignment': f(nearest indices, distances) after every IMLE refresh,
                                         #  'random_source': tfutil source for all device draws}
     hip_graphs              = True,     # capture the four training ops into hipGraphs (env IGAN_HIP_GRAPHS=0 disables)
     run_dir                 = None,     # where snapshots go (arb-reals.png, arb-fakes-*.png, rec-*.png, network-snapshot-*.pkl, :171-172,506-519); None = none
@@ -558,12 +559,17 @@ def training_loop(
 
     def search(latents, label_candidates, minibatch_size):
         t0 = time.time()
+        # packs of candidates are dealt to the ranks: keep them small enough that every rank gets some (and at most 4096)
+        per_rank = -(-latents.shape[0] // world)
+        pack = max(candidate_batch_size, min(4096, -(-per_rank // candidate_batch_size) * candidate_batch_size))
         out = imle_refresh(G, training_set_rec, latents, label_candidates, data_size, minibatch_size, candidate_batch_size,
                            drange_net, device, rank=rank, world=world, projector=projector,
-                           exclusive_k=num_samples_factor if exclusive_retrieved_code else 0)      # :382-386
+                           exclusive_k=num_samples_factor if exclusive_retrieved_code else 0, cand_pack=pack)      # :382-386
         torch.cuda.synchronize()
         if 'on_refresh' in hooks:
             hooks['on_refresh'](time.time() - t0)
+        if 'on_assignment' in hooks:
+            hooks['on_assignment'](out[0], out[1])
         return out
 
     # Host side of the IMLE term (:325-464): refresh cadence, selection, carry-over, perturbation, shuffles -- training/imle.py

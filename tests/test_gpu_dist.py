@@ -108,3 +108,45 @@ def test_bench_launches_its_own_ranks(cuda_device):
     assert d['n_gpus'] == 2 and d['steps'] == 3 and d['warmup'] == 1 and d['scaling'] == 'weak'
     assert d['config']['global_batch'] == 6 and d['config']['images_per_step'] == 12 and d['config']['parallelism'] == 'dp2'
     assert d['value'] > 0 and abs(d['value'] - 12 / (d['ms_per_step'] * 1e-3)) < 1e-2 * d['value']
+
+
+def test_eight_rank_loop_at_config5_shape(cuda_device, tmp_path):
+    """BASELINE config 5 (8 GPUs, minibatch_gpu 3, attribute-masked selection) as far as one GPU allows: EIGHT ranks on GPU 0 over
+    gloo run two iterations of the real loop.  Replicas end bit-identical; the ranks' slices tile the global minibatch (reals picked by
+    the attribute mask, latents, labels); the refresh sharded over eight ranks + the two min-exchanges assign every real the same
+    candidate as ONE process searching all candidates (same seeds; noise strengths are zero at initialisation, so the candidate
+    images do not depend on the ranks' device generators)."""
+    import numpy as np
+    import torch
+    world = 8
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'dist_worker.py'), 'config5', str(r), str(world), str(port), str(tmp_path)],
+                              cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=1500) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    recs = [torch.load(os.path.join(str(tmp_path), 'rank%d.pt' % r), weights_only=False) for r in range(world)]
+    for r in recs[1:]:
+        for k in ('G', 'D', 'Gs'):
+            assert torch.equal(recs[0][k], r[k]), k
+        assert np.array_equal(recs[0]['assign'][0][0], r['assign'][0][0])
+    assert bool(torch.isfinite(recs[0]['G']).all()) and len(recs[0]['fed']) == 2
+    col = 31        # 'Smiling' in the CelebA attribute order
+    for it in range(2):
+        fed = recs[0]['fed'][it]
+        assert fed['latents_rec_1'].shape == (24, 512) and fed['labels_rec_1'].shape == (24, 40)
+        assert bool((fed['labels_rec_1'][:, col] == 1).all()) and bool((fed['labels_rec_2'][:, col] == 1).all())      # the AND-mask selection (:416-424)
+        lat = np.concatenate([recs[r]['slices'][it]['lat'] for r in range(world)])
+        lab = np.concatenate([recs[r]['slices'][it]['lab'] for r in range(world)])
+        assert np.array_equal(lat, fed['latents_rec_1'].astype(np.float32)) and np.array_equal(lab, fed['labels_rec_1'].astype(np.float32))
+    # one process, the whole minibatch of 24: the same host stream, hence the same candidates -- and the same assignment
+    single = tmp_path / 'single'
+    single.mkdir()
+    env = dict(os.environ, IGAN_TEST_MB_GPU='24')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'dist_worker.py'), 'config5', '0', '1', str(port), str(single)], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    one = torch.load(os.path.join(str(single), 'rank0.pt'), weights_only=False)
+    assert np.array_equal(one['assign'][0][0], recs[0]['assign'][0][0])
+    assert np.allclose(one['assign'][0][1], recs[0]['assign'][0][1], rtol=1e-6, atol=0)
+    assert np.array_equal(one['fed'][0]['latents_rec_1'], recs[0]['fed'][0]['latents_rec_1'])
