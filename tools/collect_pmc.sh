@@ -4,7 +4,7 @@
 #   order off and on (tools/pmc_conv.sh); upfirdn2d traffic at its three call sites; the conv family over the eager device work
 #   of one G step and one D step (per-instantiation average traffic: what bench.py reports as roofline.traffic).
 # Each pass is its own rocprofv3 run with --pmc + --kernel-trace only.  Everything lands in gpurun_out/prof_<tag>/pmc/.
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$PWD/gpurun_out/prof_$TAG/pmc
 R=$PWD
 mkdir -p $OUT
