@@ -1,6 +1,10 @@
-"""Does a G_reg replay depend on what ran eagerly before it?  Same state, same generator state, replays separated by eager runs of other ops."""
+"""Is a captured training op's REPLAY inside the real loop equal to its eager execution?  (The probe that exposed the HIP runtime's
+graph-packet-capture fault in round 3: profiles/r03_graph_packet_capture.txt.)  Runs training_loop() at 32x32 until the first
+replay of TARGET (default G_reg), then from the same state and generator state: replays it twice, runs it eagerly, replays it
+after eager runs / replays of the other ops, and prints the relative L2 distance of the gradient buckets.
+usage: [DEBUG_CLR_GRAPH_PACKET_CAPTURE=1] [IGAN_GRAPH_VALIDATE=0] [FMAP=1024] [TARGET=G_reg] python tools/graph_replay_probe.py"""
 import os, sys
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import tests.test_gpu_loop_parity as T
 from inclusivegan_amd.training import training_loop as TL

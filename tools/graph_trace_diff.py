@@ -1,6 +1,9 @@
-"""aten-level trace on BOTH threads (main + autograd engine thread) of the G_reg op: replay-in-loop vs eager on the same draws."""
+"""First tensor that differs between a captured op's REPLAY inside the real loop and its eager execution on the same draws: an
+op-level trace (every aten op on the main thread AND the autograd engine thread, every hip_ops Function) of both runs, compared
+record by record.  Used in round 3 to locate the unfaithful replay (profiles/r03_graph_packet_capture.txt).
+usage: [DEBUG_CLR_GRAPH_PACKET_CAPTURE=1] [IGAN_GRAPH_VALIDATE=0] [FMAP=1024] [TARGET=G_reg] python tools/graph_trace_diff.py"""
 import os, sys, threading
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from torch.utils._python_dispatch import TorchDispatchMode
 import tests.test_gpu_loop_parity as T
