@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 /* Bumped whenever a struct layout or a signature changes (2: fused conv epilogue fields, fp64 nearest-neighbour state). */
-#define IGAN_ABI_VERSION 3
+#define IGAN_ABI_VERSION 4
 
 typedef void* igan_stream_t; /* hipStream_t */
 
@@ -75,6 +75,11 @@ typedef struct igan_upfirdn2d_params {
 } igan_upfirdn2d_params;
 
 int igan_upfirdn2d(igan_stream_t stream, const igan_upfirdn2d_params* p);
+/* The half instantiation the reference registers next to float (REGISTER_KERNEL_BUILDER ... Eigen::half, upfirdn_2d.cu:323-324):
+ * `x` and `y` hold IEEE binary16 values behind the float-typed fields (cast the pointers); `k` stays a host float array and is
+ * rounded to half like the reference's `k: T` input; loads widen to float, the accumulation is float, the store rounds to half
+ * (upfirdn_2d.cu:101,114).  General kernel only (no configuration of the training path runs in half). */
+int igan_upfirdn2d_f16(igan_stream_t stream, const igan_upfirdn2d_params* p);
 /* The same with the synthesis layer's epilogue fused into the store (layers whose FIR sits between the up-convolution and the
  * bias, networks_stylegan2.py:349-357 with up=True):  y = act(upfirdn(x) + noise[m, oy, ox] * strength[0] + bias[c]) * gain,
  * act in {1 linear, 2 relu, 3 lrelu} as igan_bias_act_noise_*; noise [majorDim or 1 (noise_bcast), outH, outW] or NULL with
@@ -105,6 +110,9 @@ typedef struct igan_fused_bias_act_params {
 } igan_fused_bias_act_params;
 
 int igan_fused_bias_act(igan_stream_t stream, const igan_fused_bias_act_params* p);
+/* The half instantiation (fused_bias_act.cu:185-186): x / b / ref / y hold IEEE binary16 values behind the float-typed fields;
+ * every element is widened to float, evaluated with the same table, and rounded on store (fused_bias_act.cu:56-61,113). */
+int igan_fused_bias_act_f16(igan_stream_t stream, const igan_fused_bias_act_params* p);
 
 /* Bias gradient: db[c] = sum over all i with (i / stepB) % sizeB == c of dx[i].
  * Replaces the TF reduce_sum pair of fused_bias_act.py:137-146.

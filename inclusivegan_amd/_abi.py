@@ -112,7 +112,7 @@ class TapsParams(ctypes.Structure):
                 ('taps', ctypes.c_int), ('n', ctypes.c_int), ('scale', ctypes.c_float)]
 
 
-ABI_VERSION = 3      # include/igan_hip.h IGAN_ABI_VERSION
+ABI_VERSION = 4      # include/igan_hip.h IGAN_ABI_VERSION
 STRUCTS = (UpFirDn2DParams, FusedBiasActParams, Conv2DParams, Conv2DWgradParams, DenseParams, DenseWgradParams, TapsParams)   # igan_struct_size ids
 
 DENSE_MAX_GROUPS = 24
@@ -127,8 +127,10 @@ SIGNATURES = {
     'igan_struct_size': (_SZ, [_I]),
     'igan_last_error': (ctypes.c_char_p, []),
     'igan_upfirdn2d': (_I, [_P, ctypes.POINTER(UpFirDn2DParams)]),
+    'igan_upfirdn2d_f16': (_I, [_P, ctypes.POINTER(UpFirDn2DParams)]),
     'igan_upfirdn2d_ban': (_I, [_P, _P, _P, _P, _I, _P, _I, _F, _F]),
     'igan_fused_bias_act': (_I, [_P, ctypes.POINTER(FusedBiasActParams)]),
+    'igan_fused_bias_act_f16': (_I, [_P, ctypes.POINTER(FusedBiasActParams)]),
     'igan_bias_grad_workspace_floats': (_SZ, [_I, _I, _I]),
     'igan_bias_grad': (_I, [_P, _P, _P, _P, _I, _I, _I]),
     'igan_bias_act_noise_workspace_floats': (_SZ, [_I, _I]),

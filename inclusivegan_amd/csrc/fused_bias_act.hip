@@ -10,6 +10,7 @@
 // maps to four consecutive bias entries and the bias load is one (L1/L2-resident)
 // float4 as well.
 #include "igan_common.h"
+#include <hip/hip_fp16.h>
 
 namespace {
 
@@ -120,6 +121,31 @@ void fba_launch(hipStream_t stream, const FbaArgs& a, bool vec) {
     } else {
         const int grid = std::min(igan::ceil_div(a.sizeX, 256), 256 * 16);
         hipLaunchKernelGGL((fba_kernel<ACT, GRAD, false>), dim3(grid), dim3(256), 0, stream, a);
+    }
+}
+
+// The reference registers the op for float and half (fused_bias_act.cu:185-186); its kernel loads T, computes in float and
+// stores (T)y (:56-61,113).  Same here for T = half: x / b / ref / y hold IEEE halves, 8 of them per 16 B lane when aligned.
+template <int ACT, int GRAD>
+__global__ __launch_bounds__(256) void fba_f16_kernel(FbaArgs a) {
+    const __half* x = reinterpret_cast<const __half*>(a.x);
+    const __half* b = reinterpret_cast<const __half*>(a.b);
+    const __half* ref = reinterpret_cast<const __half*>(a.ref);
+    __half* y = reinterpret_cast<__half*>(a.y);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.sizeX; i += gridDim.x * blockDim.x) {
+        const float bias = b ? __half2float(b[(i / a.stepB) % a.sizeB]) : 0.0f;
+        const float r = (GRAD != 0) ? __half2float(ref[i]) : 0.0f;
+        y[i] = __float2half(fba_one<ACT, GRAD>(a, __half2float(x[i]), bias, r));
+    }
+}
+
+template <int ACT>
+void fba_f16_dispatch_grad(hipStream_t stream, const FbaArgs& a, int grad) {
+    const int grid = std::min(igan::ceil_div(a.sizeX, 256), 256 * 16);
+    switch (grad) {
+        case 0: hipLaunchKernelGGL((fba_f16_kernel<ACT, 0>), dim3(grid), dim3(256), 0, stream, a); break;
+        case 1: hipLaunchKernelGGL((fba_f16_kernel<ACT, 1>), dim3(grid), dim3(256), 0, stream, a); break;
+        default: hipLaunchKernelGGL((fba_f16_kernel<ACT, 2>), dim3(grid), dim3(256), 0, stream, a); break;
     }
 }
 
@@ -237,6 +263,39 @@ extern "C" int igan_fused_bias_act(igan_stream_t stream_, const igan_fused_bias_
         default: fba_dispatch_grad<1>(stream, a, p->grad, vec); break;  // fused_bias_act.cu:67 `default:` == linear
     }
     IGAN_LAUNCH_CHECK("fused_bias_act launch");
+    return IGAN_OK;
+}
+
+extern "C" int igan_fused_bias_act_f16(igan_stream_t stream_, const igan_fused_bias_act_params* p) {
+    using namespace igan;
+    hipStream_t stream = (hipStream_t)stream_;
+    IGAN_REQUIRE(p != nullptr, "fused_bias_act_f16: null params");
+    IGAN_REQUIRE(p->x && p->y, "fused_bias_act_f16: null buffer");
+    IGAN_REQUIRE(p->grad >= 0, "grad must be non-negative");
+    IGAN_REQUIRE(p->grad <= 2, "fused_bias_act: third-order gradients are not supported");
+    IGAN_REQUIRE(p->sizeX >= 0, "x is too large");
+    if (p->b) {
+        IGAN_REQUIRE(p->sizeB >= 1 && p->stepB >= 1, "b has wrong number of elements");
+        IGAN_REQUIRE(p->sizeX % (p->sizeB * p->stepB) == 0, "b has wrong number of elements");
+    }
+    IGAN_REQUIRE((p->ref != nullptr) == (p->grad != 0), "ref has wrong number of elements");
+    if (p->sizeX == 0) return IGAN_OK;
+    FbaArgs a;
+    a.x = p->x; a.b = p->b; a.ref = p->ref; a.y = p->y;       // halves behind the float-typed fields (see include/igan_hip.h)
+    a.alpha = p->alpha; a.gain = p->gain;
+    a.sizeX = p->sizeX; a.sizeB = p->b ? p->sizeB : 1; a.stepB = p->b ? p->stepB : 1;
+    switch (p->act) {
+        case 2: fba_f16_dispatch_grad<2>(stream, a, p->grad); break;
+        case 3: fba_f16_dispatch_grad<3>(stream, a, p->grad); break;
+        case 4: fba_f16_dispatch_grad<4>(stream, a, p->grad); break;
+        case 5: fba_f16_dispatch_grad<5>(stream, a, p->grad); break;
+        case 6: fba_f16_dispatch_grad<6>(stream, a, p->grad); break;
+        case 7: fba_f16_dispatch_grad<7>(stream, a, p->grad); break;
+        case 8: fba_f16_dispatch_grad<8>(stream, a, p->grad); break;
+        case 9: fba_f16_dispatch_grad<9>(stream, a, p->grad); break;
+        default: fba_f16_dispatch_grad<1>(stream, a, p->grad); break;
+    }
+    IGAN_LAUNCH_CHECK("fused_bias_act_f16 launch");
     return IGAN_OK;
 }
 

@@ -14,6 +14,7 @@
 // consecutive float4 = 1 KiB of one or more adjacent pixels, so global loads and
 // stores are fully coalesced.
 #include "igan_common.h"
+#include <hip/hip_fp16.h>
 #include <cstdlib>
 
 namespace {
@@ -45,9 +46,18 @@ __host__ __device__ __forceinline__ int floor_div(int a, int b) {
     return c;
 }
 
+__device__ __forceinline__ float io_load(const float* p) { return *p; }
+__device__ __forceinline__ float io_load(const __half* p) { return __half2float(*p); }
+__device__ __forceinline__ void io_store(float* p, float v) { *p = v; }
+__device__ __forceinline__ void io_store(__half* p, float v) { *p = __float2half(v); }
+
 // General path: one thread per output element, channel index fastest.
-// Same receptive-field arithmetic as upfirdn_2d.cu:76-90.
+// Same receptive-field arithmetic as upfirdn_2d.cu:76-90.  T = float or half (the reference registers both, upfirdn_2d.cu:323-324;
+// loads are widened to float, the accumulation is float, the store rounds to T: :101,114).
+template <typename T>
 __global__ __launch_bounds__(256) void upfirdn2d_generic_kernel(UpfirdnArgs a, FirTaps taps) {
+    const T* xin = reinterpret_cast<const T*>(a.x);
+    T* yout = reinterpret_cast<T*>(a.y);
     const long long total = (long long)a.majorDim * a.outH * a.outW * a.minorDim;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
@@ -72,14 +82,14 @@ __global__ __launch_bounds__(256) void upfirdn2d_generic_kernel(UpfirdnArgs a, F
         float v = 0.0f;
         for (int yy = 0; yy < h; yy++) {
             const int ky = kernelY - yy * a.upy;  // index into the unflipped filter
-            const float* xrow = a.x + (((long long)m * a.inH + inY + yy) * a.inW + inX) * a.minorDim + c;
+            const T* xrow = xin + (((long long)m * a.inH + inY + yy) * a.inW + inX) * a.minorDim + c;
             for (int xx = 0; xx < w; xx++) {
                 const int kx = kernelX - xx * a.upx;
                 const float kv = taps.k[(a.kernelH - 1 - ky) * a.kernelW + (a.kernelW - 1 - kx)];
-                v += xrow[(long long)xx * a.minorDim] * kv;
+                v += io_load(xrow + (long long)xx * a.minorDim) * kv;
             }
         }
-        a.y[idx] = v;
+        io_store(yout + idx, v);
     }
 }
 
@@ -184,11 +194,15 @@ __global__ __launch_bounds__(256) void upfirdn2d_fir4_kernel(UpfirdnArgs a, FirT
 
 namespace {
 struct FirEpilogue { const float* noise; const float* strength; const float* bias; int noise_bcast, act; float alpha, gain; };
-int upfirdn_launch(hipStream_t stream, const igan_upfirdn2d_params* p, const FirEpilogue* epi);
+int upfirdn_launch(hipStream_t stream, const igan_upfirdn2d_params* p, const FirEpilogue* epi, bool half_io = false);
 }  // namespace
 
 extern "C" int igan_upfirdn2d(igan_stream_t stream_, const igan_upfirdn2d_params* p) {
     return upfirdn_launch((hipStream_t)stream_, p, nullptr);
+}
+
+extern "C" int igan_upfirdn2d_f16(igan_stream_t stream_, const igan_upfirdn2d_params* p) {
+    return upfirdn_launch((hipStream_t)stream_, p, nullptr, true);
 }
 
 extern "C" int igan_upfirdn2d_ban(igan_stream_t stream_, const igan_upfirdn2d_params* p, const float* noise, const float* strength,
@@ -203,7 +217,7 @@ extern "C" int igan_upfirdn2d_ban(igan_stream_t stream_, const igan_upfirdn2d_pa
 }
 
 namespace {
-int upfirdn_launch(hipStream_t stream, const igan_upfirdn2d_params* p, const FirEpilogue* epi) {
+int upfirdn_launch(hipStream_t stream, const igan_upfirdn2d_params* p, const FirEpilogue* epi, bool half_io) {
     using namespace igan;
     IGAN_REQUIRE(p != nullptr, "upfirdn2d: null params");
     IGAN_REQUIRE(p->x && p->k && p->y, "upfirdn2d: null buffer");
@@ -239,7 +253,7 @@ int upfirdn_launch(hipStream_t stream, const igan_upfirdn2d_params* p, const Fir
     a.act_alpha = epi ? epi->alpha : 0.f; a.act_gain = epi ? epi->gain : 1.f;
 
     const bool aligned = (((uintptr_t)p->x | (uintptr_t)p->y) & 15) == 0;
-    const bool fast = p->upx == 1 && p->upy == 1 && p->downx == 1 && p->downy == 1 &&
+    const bool fast = !half_io && p->upx == 1 && p->upy == 1 && p->downx == 1 && p->downy == 1 &&
                       p->kernelH <= 4 && p->kernelW <= 4 && (p->minorDim % 4) == 0 && aligned;
     FirTaps taps;
     for (int i = 0; i < 64; i++) taps.k[i] = 0.0f;
@@ -269,7 +283,13 @@ int upfirdn_launch(hipStream_t stream, const igan_upfirdn2d_params* p, const Fir
             for (int kx = 0; kx < p->kernelW; kx++)
                 taps.k[ky * p->kernelW + kx] = p->k[(p->kernelH - 1 - ky) * p->kernelW + (p->kernelW - 1 - kx)];
         const int grid = (int)std::min<long long>(ceil_div_ll(out_elems, 256), 256 * 32);
-        hipLaunchKernelGGL(upfirdn2d_generic_kernel, dim3(grid), dim3(256), 0, stream, a, taps);
+        if (half_io) {
+            // the reference's half instantiation holds the taps in half too (k: T, upfirdn_2d.cu:312): round them the same way
+            for (int i = 0; i < 64; i++) taps.k[i] = (float)(_Float16)taps.k[i];
+            hipLaunchKernelGGL(upfirdn2d_generic_kernel<__half>, dim3(grid), dim3(256), 0, stream, a, taps);
+        } else {
+            hipLaunchKernelGGL(upfirdn2d_generic_kernel<float>, dim3(grid), dim3(256), 0, stream, a, taps);
+        }
     }
     IGAN_LAUNCH_CHECK("upfirdn2d launch");
     return IGAN_OK;

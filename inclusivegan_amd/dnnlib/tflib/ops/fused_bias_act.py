@@ -6,6 +6,7 @@ The activation table carries what the kernel dispatch needs: the kernel's activa
 `ref`, and whether the second derivative vanishes (fused_bias_act.py:20-30).
 """
 import numpy as np
+import torch
 
 from .... import hip_ops
 from ...util import EasyDict
@@ -46,7 +47,7 @@ def fused_bias_act(x, b=None, axis=1, act='linear', alpha=None, gain=None, impl=
         return x
     # piecewise-linear activations on channel-minor data: one-pass forward and one-pass backward
     # (dx and db together) -- csrc/bias_act_noise.hip
-    if axis == 1 and spec.hip_idx in (1, 2, 3) and gain > 0 and x.dim() in (2, 4) and x.shape[1] % 4 == 0:
+    if axis == 1 and spec.hip_idx in (1, 2, 3) and gain > 0 and x.dim() in (2, 4) and x.shape[1] % 4 == 0 and x.dtype == torch.float32:
         return hip_ops.bias_act_noise(x, b, None, None, spec.hip_idx, 0.0 if alpha is None else float(alpha), float(gain))
     return hip_ops.FusedBiasActFn.apply(x, b, axis, spec.hip_idx, 0.0 if alpha is None else float(alpha), float(gain),
                                         spec.ref, spec.zero_2nd_grad)

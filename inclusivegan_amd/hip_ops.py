@@ -51,6 +51,18 @@ def _require_cuda_f32(*ts):
             raise TypeError('inclusivegan_amd kernels are fp32 (got %s)' % t.dtype)
 
 
+def _require_cuda_io(*ts):
+    """Like _require_cuda_f32, for the two ops the reference registers for float AND half (UpFirDn2D, FusedBiasAct): all tensors
+    of one call share one of the two types."""
+    kinds = {t.dtype for t in ts if t is not None}
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('inclusivegan_amd kernels need tensors on a ROCm device (got %s); there is no CPU path' % t.device)
+    if len(kinds) != 1 or next(iter(kinds)) not in (torch.float32, torch.float16):
+        raise TypeError('upfirdn_2d / fused_bias_act take float32 or float16 tensors of one type (got %s)' % sorted(str(k) for k in kinds))
+    return next(iter(kinds)) == torch.float16
+
+
 def _is_meta(t):
     """Shape-only dry runs (Network template pass) use the meta device and never reach a kernel."""
     return t.device.type == 'meta'
@@ -110,9 +122,11 @@ def upfirdn2d_raw(x, k, upx, upy, downx, downy, padx0, padx1, pady0, pady1, epil
     if _is_meta(x):
         return torch.empty((major, out_h, out_w, minor), device='meta')
     lib = _abi.get_plugin()
-    _require_cuda_f32(x)
+    half = _require_cuda_io(x)
+    if half and epilogue is not None:
+        raise TypeError('upfirdn2d: the fused layer epilogue is a float32 path')
     x = x.contiguous()
-    y = torch.empty((major, out_h, out_w, minor), device=x.device, dtype=torch.float32)
+    y = torch.empty((major, out_h, out_w, minor), device=x.device, dtype=x.dtype)
     p = _abi.UpFirDn2DParams(
         x=x.data_ptr(), k=k.ctypes.data, y=y.data_ptr(),
         upx=upx, upy=upy, downx=downx, downy=downy,
@@ -130,7 +144,7 @@ def upfirdn2d_raw(x, k, upx, upy, downx, downy, padx0, padx1, pady0, pady1, epil
         _abi.check(lib.igan_upfirdn2d_ban(_stream(), ctypes.byref(p), _ptr(noise), _ptr(strength if noise is not None else None), bcast,
                                           _ptr(bias.contiguous() if bias is not None else None), int(act_idx), float(alpha), float(gain)))
         return y
-    _abi.check(lib.igan_upfirdn2d(_stream(), ctypes.byref(p)))
+    _abi.check((lib.igan_upfirdn2d_f16 if half else lib.igan_upfirdn2d)(_stream(), ctypes.byref(p)))
     return y
 
 
@@ -225,19 +239,21 @@ def fused_bias_act_raw(x, b, ref, grad, act_idx, alpha, gain, size_b, step_b):
     if _is_meta(x):
         return torch.empty_like(x)
     lib = _abi.get_plugin()
-    _require_cuda_f32(x, b, ref)
+    half = _require_cuda_io(x, b, ref)
     y = torch.empty_like(x)
     p = _abi.FusedBiasActParams(
         x=x.data_ptr(), b=(b.data_ptr() if b is not None else None),
         ref=(ref.data_ptr() if ref is not None else None), y=y.data_ptr(),
         grad=grad, act=act_idx, alpha=float(alpha), gain=float(gain),
         sizeX=x.numel(), sizeB=size_b, stepB=step_b)
-    _abi.check(lib.igan_fused_bias_act(_stream(), ctypes.byref(p)))
+    _abi.check((lib.igan_fused_bias_act_f16 if half else lib.igan_fused_bias_act)(_stream(), ctypes.byref(p)))
     return y
 
 
 def bias_grad_raw(dx, size_b, step_b):
     lib = _abi.get_plugin()
+    if dx.dtype == torch.float16:      # half instantiation: db = reduce_sum(dx) (fused_bias_act.py:137-146), accumulated in float
+        return dx.reshape(-1, size_b, step_b).float().sum(dim=(0, 2)).to(torch.float16)
     _require_cuda_f32(dx)
     n = dx.numel()
     ws_floats = lib.igan_bias_grad_workspace_floats(n, size_b, step_b)

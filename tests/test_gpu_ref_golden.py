@@ -101,3 +101,61 @@ def test_discriminator_against_reference_execution(cuda_device, arch):
     with torch.no_grad():
         s, f = net.get_output_for(x, torch.zeros(x.shape[0], 0, device=cuda_device), is_training=True, return_features=True)
     assert rel_err(s, G['D_%s_scores' % arch]) < 1e-4 and rel_err(f, G['D_%s_features' % arch]) < 1e-4
+
+
+# ---- the half instantiations of the two custom ops (upfirdn_2d.cu:323-324, fused_bias_act.cu:185-186) -------------------------
+
+@pytest.mark.parametrize('i', range(int(G['upfirdn_cases'])))
+def test_upfirdn_half_instantiation(cuda_device, i):
+    """T = half: inputs, taps and outputs in binary16, float accumulation (upfirdn_2d.cu:101,114).  Expected = the float64 oracle on
+    the half-rounded inputs and taps, rounded to half; 1.5 half ulps of the largest output.  Gradient through autograd too."""
+    from inclusivegan_amd.dnnlib.tflib.ops.upfirdn_2d import upfirdn_2d
+    from oracle import upfirdn_2d as OU
+    p = 'upfirdn_%d_' % i
+    upx, upy, downx, downy, px0, px1, py0, py1 = [int(v) for v in G[p + 'params']]
+    kw = dict(upx=upx, upy=upy, downx=downx, downy=downy, padx0=px0, padx1=px1, pady0=py0, pady1=py1)
+    xh = torch.from_numpy(G[p + 'x']).to(torch.float16)
+    kh = G[p + 'k'].astype(np.float16).astype(np.float64)
+    want = OU.upfirdn_2d_ref(xh.double(), kh, **kw)
+    x = xh.to(cuda_device).requires_grad_(True)
+    y = upfirdn_2d(x, G[p + 'k'], **kw)
+    assert y.dtype == torch.float16
+    tol = 1.5 * 2.0 ** -11 * float(want.abs().max())
+    assert float((y.detach().double().cpu() - want).abs().max()) <= tol
+    dyh = torch.from_numpy(G[p + 'dy']).to(torch.float16)
+    dx, = torch.autograd.grad(y, x, dyh.to(cuda_device))
+    gp = OU.upfirdn_2d_grad_params(xh.shape[1], xh.shape[2], kh, **kw)
+    want_dx = OU.upfirdn_2d_ref(dyh.double(), gp['k'], **{n: gp[n] for n in kw})
+    assert dx.dtype == torch.float16 and float((dx.double().cpu() - want_dx).abs().max()) <= 1.5 * 2.0 ** -11 * float(want_dx.abs().max())
+
+
+def test_fused_bias_act_half_instantiation(cuda_device):
+    """T = half for every activation and grad = 0 / 1 / 2 through the C ABI wrapper: each element is widened to float, evaluated with
+    the float table and rounded on store (fused_bias_act.cu:56-61,113) -- expected = the oracle's restatement of that table in
+    float on the half-rounded inputs, rounded to half (one half ulp)."""
+    from inclusivegan_amd import hip_ops
+    from inclusivegan_amd.dnnlib.tflib.ops.fused_bias_act import fused_bias_act, activation_funcs
+    from oracle import fused_bias_act as OF
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(3, 8, 5, 5, generator=g) * 2).to(torch.float16)
+    b = torch.randn(8, generator=g).to(torch.float16)
+    ref = torch.rand(3, 8, 5, 5, generator=g).to(torch.float16)
+    for name, spec in activation_funcs.items():
+        for grad in (0, 1, 2):
+            got = hip_ops.fused_bias_act_raw(x.to(cuda_device), b.to(cuda_device), None if grad == 0 else ref.to(cuda_device), grad, spec.hip_idx, 0.2, 1.3, 8, 25)
+            want = OF.fused_bias_act_kernel_ref(x.float(), b.float(), None if grad == 0 else ref.float(), grad, spec.hip_idx, 0.2, 1.3, 25).reshape(x.shape)
+            assert got.dtype == torch.float16
+            err = (got.float().cpu() - want).abs()
+            assert bool((err <= 2.0 ** -10 * want.abs() + 1e-4).all()), (name, grad, float(err.max()))
+    # the operator surface on half tensors, with gradients (lrelu: the generic Function; piecewise-linear fp32 fast path is not taken)
+    xg = x.to(cuda_device).requires_grad_(True)
+    bg = b.to(cuda_device).requires_grad_(True)
+    y = fused_bias_act(xg, bg, act='lrelu')
+    y.float().sum().backward()
+    yo = OF.fused_bias_act(x.double(), b.double(), act='lrelu')
+    assert y.dtype == torch.float16 and float((y.detach().double().cpu() - yo).abs().max()) <= 2.0 ** -10 * float(yo.abs().max())
+    assert xg.grad.dtype == torch.float16 and bg.grad.shape == (8,)
+    want_db = torch.where(x.double() + b.double().view(1, 8, 1, 1) > 0, 1.0, 0.2).mul(np.sqrt(2)).sum(dim=(0, 2, 3))
+    assert float((bg.grad.double().cpu() - want_db).abs().max()) <= 2e-2 * float(want_db.abs().max())
+    with pytest.raises(TypeError):
+        hip_ops.fused_bias_act_raw(x.to(cuda_device), b.float().to(cuda_device), None, 0, 3, 0.2, 1.0, 8, 25)      # mixed types
