@@ -843,11 +843,26 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_dma_kernel(ConvArgs a) {
             bf16x8 av[NP];
             split8(afq[2 * s][tm], afq[2 * s + 1][tm], av);
             // all products a_i b_j with i + j < PIECES, smallest first
+#ifdef IGAN_SPLIT_PROMOTE      // experiment: the step's products are summed from zero and added to the running sum by the vector ALU (RN)
+            f32x16 t;
+#pragma unroll
+            for (int r = 0; r < 16; r++) t[r] = 0.0f;
+#pragma unroll
+            for (int oo = 0; oo < NP; oo++) {
+                const int o = (IGAN_SPLIT_PROMOTE == 2) ? oo : NP - 1 - oo;       // 2: largest products first (the addend is never the small term)
+#pragma unroll
+                for (int i = 0; i <= o; i++)
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], b[o - i], t, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[tm][0][r] += t[r];
+#else
 #pragma unroll
             for (int o = NP - 1; o >= 0; o--)
 #pragma unroll
                 for (int i = 0; i <= o; i++)
                     acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], b[o - i], acc[tm][0], 0, 0, 0);
+#endif
         }
     };
 
