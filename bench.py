@@ -46,6 +46,7 @@ def parse_args():
     p.add_argument('--lpips-weight', type=float, default=2.5)
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true')
+    p.add_argument('--no-variant-line', action='store_true', help='skip the second, labelled measurement with the bf16-piece convolutions (a child run of this script)')
     p.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='process-group backend for --gpus > 1 (nccl = RCCL; gloo for the one-GPU tests)')
     p.add_argument('--one-gpu', action='store_true', help='test hook: every rank on device 0 (needs --backend gloo: RCCL refuses two ranks on one device)')
     p.add_argument('--op-times', action='store_true', help='also report the mean device time of each training op (HIP events)')
@@ -288,6 +289,28 @@ def cpu_baseline_subprocess(resolution, batch, lpips_weight, timeout_s=600):
         return dict(value=None, unit='img/s', cores=0, kind='port', sample='cpu baseline exceeded %d s' % timeout_s)
 
 
+def variant_line(args, timeout_s=900):
+    """The SECOND, labelled line: the same steady-state measurement with the forward / data-gradient convolutions in their
+    bf16-piece form (IGAN_CONV_PLANES=1: three bf16 pieces per fp32 operand, six products, fp32 sums -- csrc/conv2d_mfma.hip
+    conv_fwd_planes_kernel; passes the GPU parity suite at the fp32 path's tolerances but is not the fp32 instruction, so it is
+    never `value`).  A child process, because the switch is read once per process; small data set: its refresh is not the subject."""
+    import subprocess
+    env = dict(os.environ, IGAN_CONV_PLANES='1')
+    cmd = [sys.executable, os.path.abspath(__file__), '--steps', str(args.steps), '--warmup', str(args.warmup), '--data-size', '1152',
+           '--minibatch-gpu', str(args.minibatch_gpu), '--resolution', str(args.resolution), '--lpips-weight', str(args.lpips_weight),
+           '--no-cpu-baseline', '--no-variant-line']
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:      # a failed variant run never takes the headline with it
+        return {'label': 'bf16-piece convolutions (IGAN_CONV_PLANES=1)', 'error': repr(e)[:200]}
+    roof = d.get('roofline', {})
+    return {'label': 'VARIANT, not the product path: forward / data-gradient convolutions as 3 bf16 pieces x 6 products with fp32 sums (IGAN_CONV_PLANES=1); '
+                     'weight gradients and everything else as in the headline', 'value': d['value'], 'unit': d['unit'], 'ms_per_step': d['ms_per_step'],
+            'data_size': 1152, 'hip_graphs': d.get('hip_graphs'), 'dominant_kernel': roof.get('kernel'), 'dominant_kernel_fp32_equivalent_tflops': roof.get('achieved'),
+            'conv_family_fp32_equivalent_tflops': roof.get('conv_family_tflops')}
+
+
 def log(msg):
     if int(os.environ.get('RANK', '0')) == 0:
         print('[bench %7.1fs] %s' % (time.time() - _T0, msg), file=sys.stderr, flush=True)
@@ -412,7 +435,8 @@ def main():
         'metric': 'training img/sec (whole node), CelebA 128x128 StyleGAN2+IMLE',
         'value': round(imgs / elapsed, 3), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32', 'data': 'synthetic',
+        'dtype': 'f32' if os.environ.get('IGAN_CONV_PLANES') != '1' else 'f32 emulated with 3 bf16 pieces in the forward / data-gradient convolutions (variant)',
+        'data': 'synthetic',
         'config': {'workload': 'CelebA-shaped %dx%d StyleGAN2+IMLE, config-e-Gskip-Dresnet (fmap_base 8192), minibatch_gpu %d, '
                                'NN_rec_lpips_weight %g, lazy reg G/4 D/16, random-init weights' % (args.resolution, args.resolution, B, args.lpips_weight),
                    'global_batch': B * world, 'images_per_step': 2 * B * world, 'parallelism': 'dp%d' % world,
@@ -452,6 +476,9 @@ def main():
             knn = out['cpu_baseline'].get('knn')
             if isinstance(knn, dict) and knn.get('value'):
                 knn['gpu_queries_per_s'] = knn_gpu(device, knn['num_points'], knn['dim'])
+        if world == 1 and not args.no_variant_line and os.environ.get('IGAN_CONV_PLANES') != '1':
+            log('second line: the bf16-piece variant (child run)')
+            out['variant_bf16_pieces'] = variant_line(args)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()

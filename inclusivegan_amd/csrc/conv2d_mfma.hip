@@ -84,6 +84,8 @@ struct ConvArgs {
     const float* noise;     // [N or 1, OH, OW] or nullptr; strength = *noise_strength (device scalar)
     const float* noise_strength;
     int noise_bcast;        // noise has one sample, shared by the batch
+    const unsigned short* xp;   // bf16-piece form (conv_fwd_planes_kernel): x * in_scale as [pixel][Cin/16][3 pieces][16] bf16
+    const unsigned short* wp;   //   and the filter as [tap][n][Cin/16][3][16] (the orientation is resolved when it is written)
 };
 
 // noise[n, pixel] * strength of output pixel `pix` (linear index over [N, OH, OW]); 0 without noise or for padding rows
@@ -1059,6 +1061,353 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(ConvArgs a, int BM, int
 }
 
 // ------------------------------------------------------------------------------
+// bf16-piece form of the forward-type kernel (IGAN_CONV_PLANES=1; profiles/r03_bf16_split_rounding.txt).
+//
+// Arithmetic.  Every fp32 operand is written ONCE as three bf16 pieces, v = v0 + v1 + v2 exactly (v0 = bf16(v), v1 = bf16(v - v0),
+// v2 = v - v0 - v1; round to nearest), and a product runs as the six piece products a_i b_j, i + j <= 2, on
+// v_mfma_f32_32x32x16_bf16 (12 matrix instructions of 32 cycles per 16-deep step and 64x32 wave tile instead of 16 of 64 on the
+// fp32 instruction).  What the bf16 instruction does to its addend decides the order: it floors a small addend that sits next
+// to a larger product (tools/mfma_round_probe.hip), so every 16-deep step starts from an exact zero, takes the LARGEST products
+// first (the addend is then never the small term) and its sum t is added to the running fp32 sum by the vector ALU (round to
+// nearest).  The dropped terms (a1 b2 + a2 b1 + a2 b2) are below 2^-24 of the product.  Measured against fp64 this is a third
+// of the fp32 instruction's L2 error and the whole GPU parity suite passes at the fp32 path's tolerances.
+//
+// Data.  to_planes_kernel writes x * in_scale (the modulation: one fp32 rounding, as everywhere else) as
+// [pixel][Cin/16][piece][16] bf16 (96 B per pixel and 16 channels); filter_planes_kernel writes the filter as
+// [Cin/16][tap][n][piece][16] for either orientation, so the tile kernel has ONE form: both LDS images are [piece][row][2 x 16 B]
+// (the two 8-deep halves of the row, the half of row r stored at position h ^ ((r >> 3) & 1): conflict-free ds_read_b128), a
+// stage is 16 deep (12 KiB + 12 KiB), three stages, filled by `buffer_load_dwordx4 ... lds` two stages ahead.  A wave's step:
+//     [vmcnt: chunk c landed] [barrier] [9 fragment reads] [6 MFMAs] [3 DMA instructions for chunk c+2] [6 MFMAs] [32 adds].
+// The reduction runs 16-channel slice outermost, taps inside (the taps of a slice re-read the same shifted rows: L2 hits).
+// Tile list, slicing, fix-up and the whole epilogue are those of conv_fwd_dma_kernel (same accumulator layout).
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+constexpr int PK = 16;                          // reduction depth of a stage
+constexpr int P_IMG = 3 * 128 * 32;             // bytes of one operand image: [3 pieces][128 rows][32 B]
+constexpr int P_STAGE = 2 * P_IMG;              // A + B
+constexpr int P_NSTAGE = 3;
+
+__device__ __forceinline__ void split3(float v, unsigned short (&o)[3]) {
+    float r = v;
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        const __bf16 b = (__bf16)r;             // v_cvt_pk_bf16_f32: round to nearest even
+        o[q] = __builtin_bit_cast(unsigned short, b);
+        r -= (float)b;
+    }
+}
+
+// x [P][C] fp32 (times scale[p / HW][C] when given) -> [P][C/16][3][16] bf16.  One thread per (pixel, 16 channels): 64 B in, 96 B out.
+__global__ __launch_bounds__(256) void to_planes_kernel(const float* __restrict__ x, const float* __restrict__ scale, unsigned short* __restrict__ out,
+                                                         int total, int cpp, int C, int HW) {
+    const int idx = min((int)(blockIdx.x * 256 + threadIdx.x), total - 1);      // the last block's spare threads repeat its last unit (not stored)
+    const int p = idx / cpp, c = idx - p * cpp;
+    const float4* src = reinterpret_cast<const float4*>(x + (size_t)p * C + 16 * c);
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const float4 f = src[i]; v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w; }
+    if (scale != nullptr) {
+        const float4* sc = reinterpret_cast<const float4*>(scale + (size_t)(p / HW) * C + 16 * c);
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const float4 f = sc[i]; v[4 * i] *= f.x; v[4 * i + 1] *= f.y; v[4 * i + 2] *= f.z; v[4 * i + 3] *= f.w; }
+    }
+    unsigned short pc[3][16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        unsigned short o[3];
+        split3(v[i], o);
+        pc[0][i] = o[0]; pc[1][i] = o[1]; pc[2][i] = o[2];
+    }
+    // the block's 256 units are 24 KiB of contiguous output: staged through LDS so that every store instruction of a wave
+    // writes one contiguous KiB (whole 128 B lines) instead of 64 pieces 96 B apart
+    __shared__ uint4 stage[256 * 6];
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++) {
+            uint4 u;
+            u.x = pc[q][8 * hh + 0] | ((unsigned)pc[q][8 * hh + 1] << 16); u.y = pc[q][8 * hh + 2] | ((unsigned)pc[q][8 * hh + 3] << 16);
+            u.z = pc[q][8 * hh + 4] | ((unsigned)pc[q][8 * hh + 5] << 16); u.w = pc[q][8 * hh + 6] | ((unsigned)pc[q][8 * hh + 7] << 16);
+            stage[threadIdx.x * 6 + 2 * q + hh] = u;
+        }
+    __syncthreads();
+    const int units = min(256, total - (int)blockIdx.x * 256);
+    uint4* dst = reinterpret_cast<uint4*>(out + (size_t)blockIdx.x * 256 * 48);
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const int j = k * 256 + threadIdx.x;
+        if (j < units * 6) dst[j] = stage[j];
+    }
+}
+
+// filter -> [K/16][tap][n][3][16] bf16 (one 16-deep slice of one tap's 128-row tile is 12 KiB contiguous), element (tap (ky, kx), n, k):
+//   !WT: w[ky][kx][k][n] (HWIO; n fastest across threads: coalesced reads)     WT: w[KH-1-ky][KW-1-kx][n][k] (k contiguous)
+template <bool WT>
+__global__ __launch_bounds__(256) void filter_planes_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int taps, int KW_, int Nn, int K) {
+    const int cpk = K >> 4;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= taps * Nn * cpk) return;
+    int tap, n, c;
+    if constexpr (WT) { c = idx % cpk; const int r = idx / cpk; n = r % Nn; tap = r / Nn; }
+    else { n = idx % Nn; const int r = idx / Nn; c = r % cpk; tap = r / cpk; }
+    float v[16];
+    if constexpr (WT) {
+        const float4* src = reinterpret_cast<const float4*>(w + ((size_t)(taps - 1 - tap) * Nn + n) * K + 16 * c);   // both axes flipped = reversed tap index
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const float4 f = src[i]; v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; i++) v[i] = w[((size_t)tap * K + 16 * c + i) * Nn + n];
+    }
+    unsigned short pc[3][16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        unsigned short o[3];
+        split3(v[i], o);
+        pc[0][i] = o[0]; pc[1][i] = o[1]; pc[2][i] = o[2];
+    }
+    uint4* dst = reinterpret_cast<uint4*>(out + (((size_t)c * taps + tap) * Nn + n) * 48);
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++) {
+            uint4 u;
+            u.x = pc[q][8 * hh + 0] | ((unsigned)pc[q][8 * hh + 1] << 16); u.y = pc[q][8 * hh + 2] | ((unsigned)pc[q][8 * hh + 3] << 16);
+            u.z = pc[q][8 * hh + 4] | ((unsigned)pc[q][8 * hh + 5] << 16); u.w = pc[q][8 * hh + 6] | ((unsigned)pc[q][8 * hh + 7] << 16);
+            dst[2 * q + hh] = u;
+        }
+}
+
+__global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
+    constexpr int BM = 128, BN = 128, WN = 4, TM = 2;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[P_NSTAGE * P_STAGE + 3 * BM * 4];
+    int* row_pix = reinterpret_cast<int*>(smem + P_NSTAGE * P_STAGE);
+    int* row_n = row_pix + BM;
+    float* row_nz = reinterpret_cast<float*>(row_n + BM);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int up = 1 << a.up_shift;
+    auto stamp = [&](int k) {       // diagnostic only, as in conv_fwd_dma_kernel
+        if (a.diag != nullptr && (threadIdx.x >> 6) == 0) {
+            const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+            if ((threadIdx.x & 63) == 0) a.diag[(size_t)blockIdx.x * 4 + k] = t;
+        }
+    };
+    stamp(0);
+    if (a.prio) __builtin_amdgcn_s_setprio(3);
+    int bid = blockIdx.x;
+    if (a.xcd_remap && bid < a.full_tiles) {
+        const int per_class = a.nx * a.ny;
+        const int lo = (bid / per_class) * per_class;
+        bid = lo + remap_xcd(bid - lo, min(per_class, a.full_tiles - lo));
+    }
+    const bool sliced = bid >= a.full_tiles;
+    const int tail = bid - a.full_tiles;
+    const int tile = sliced ? a.full_tiles + tail / a.splits : bid;
+    const int split = sliced ? tail % a.splits : 0;
+    const int nsplit = sliced ? a.splits : 1;
+    const int mt = tile % a.nx, nt = (tile / a.nx) % a.ny, cls = tile / (a.nx * a.ny);
+    const int py = cls >> a.up_shift, px = cls & (up - 1);
+    const int QH = (a.OH - py + up - 1) >> a.up_shift;
+    const int QW = (a.OW - px + up - 1) >> a.up_shift;
+    const int Mcls = a.N * QH * QW;
+    const int m0 = mt * BM;
+    if (m0 >= Mcls) return;
+    const int n0 = nt * BN;
+    const int ky0 = (a.pad_y - py * a.stride) & (up - 1);
+    const int kx0 = (a.pad_x - px * a.stride) & (up - 1);
+    const int nky = (ky0 < a.KH) ? ((a.KH - ky0 + up - 1) >> a.up_shift) : 0;
+    const int nkx = (kx0 < a.KW) ? ((a.KW - kx0 + up - 1) >> a.up_shift) : 0;
+    const int chunks = nky * nkx * a.cpt;                 // a.cpt = Cin / 16 here
+    const int c_begin = sliced ? (int)(((long long)split * chunks) / nsplit) : 0;
+    const int c_end = sliced ? (int)(((long long)(split + 1) * chunks) / nsplit) : chunks;
+
+    const float inv_hw = 1.0f / (float)(QH * QW), inv_w = 1.0f / (float)QW;
+    // ---- DMA lane geometry: every lane fills the same LDS position in each of its three instructions: row 32 (wave & 3) + lane / 2,
+    // position lane & 1, i.e. half (lane & 1) ^ ((row >> 3) & 1).  Waves 0-3 fetch A pieces 0, 2 and B piece 1, waves 4-7 A piece 1
+    // and B pieces 0, 2 (24 wave instructions per stage, three per wave).
+    const int drow = 32 * (wave & 3) + (lane >> 1);
+    const int dhalf = (lane & 1) ^ ((drow >> 3) & 1);
+    const bool lowave = wave < 4;
+    int rn, rby, rbx;
+    bool rok;
+    {
+        const int m = m0 + drow;
+        rok = m < Mcls;
+        const int mm = rok ? m : 0;
+        const int nn = div_small(mm, QH * QW, inv_hw);
+        const int r = mm - nn * (QH * QW);
+        const int qy = div_small(r, QW, inv_w), qx = r - qy * QW;
+        rn = nn;
+        rby = (qy * up + py) * a.stride - a.pad_y;
+        rbx = (qx * up + px) * a.stride - a.pad_x;
+    }
+    // reduction order: 16-channel slice outermost, taps inside it -- the taps of a slice re-read the same (shifted) 96 B row
+    // pieces back to back, so eight of the nine fetches of a row piece hit the XCD's L2 (tap-outermost re-reads a row only after a
+    // pass over all channels: 25 MB per XCD in flight, served from the Infinity Cache at half the rate)
+    const int ntap = nky * nkx;
+    int ld_cc = (c_begin < c_end) ? c_begin / ntap : 0;
+    int ld_t0 = (c_begin < c_end) ? c_begin - ld_cc * ntap : 0;
+    int ld_ta = (c_begin < c_end) ? ld_t0 / nkx : 0;
+    int ld_tb = (c_begin < c_end) ? ld_t0 - ld_ta * nkx : 0;
+    const unsigned xbytes = (unsigned)a.N * a.H * a.W * a.Cin * 6u, wbytes = (unsigned)a.KH * a.KW * a.Cin * a.Cout * 6u;   // host: both < OOB
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.xp), 0, (int)xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.wp), 0, (int)wbytes, 0x00020000);
+    const unsigned pixA = (unsigned)a.Cin * 6u;           // bytes per pixel
+    unsigned offA = OOB, offB = OOB;
+    auto decode_tap = [&]() {
+        const int ky = ky0 + (ld_ta << a.up_shift), kx = kx0 + (ld_tb << a.up_shift);
+        const int vy = rby + ky, vx = rbx + kx;
+        const int iy = vy >> a.up_shift, ix = vx >> a.up_shift;
+        const bool ok = rok & (vy >= 0) & (vx >= 0) & (iy < a.H) & (ix < a.W);
+        offA = ok ? (unsigned)((rn * a.H + iy) * a.W + ix) * pixA + (unsigned)ld_cc * 96u + (unsigned)dhalf * 16u : OOB;
+        const int co = n0 + drow;
+        offB = (co < a.Cout) ? (unsigned)((ld_cc * (a.KH * a.KW) + ky * a.KW + kx) * a.Cout + co) * 96u + (unsigned)dhalf * 16u : OOB;
+    };
+    typedef __attribute__((address_space(3))) void lds_void;
+    constexpr unsigned PSTEP = 32u;          // bytes between the pieces of one (pixel, slice)
+    unsigned char* dA = nullptr;
+    auto dma_prep = [&](int stage) {        // addresses of the next chunk, then one step forward in (slice, tap) order
+        decode_tap();
+        dA = smem + stage * P_STAGE + (wave & 3) * 1024;
+        ++ld_tb;
+        const int w1 = (ld_tb == nkx) ? 1 : 0;
+        ld_tb = w1 ? 0 : ld_tb;
+        ld_ta += w1;
+        const int w2 = (ld_ta == nky) ? 1 : 0;
+        ld_ta = w2 ? 0 : ld_ta;
+        ld_cc += w2;
+    };
+    auto dma_piece = [&](int j) {           // one of this wave's three KiB of the 24 KiB stage
+        unsigned char* A = dA;
+        unsigned char* B = dA + P_IMG;
+        // an out-of-range offset stays out of range with the piece offset added (OOB + 64 < 2^31 <= any wrap)
+        if (lowave) {
+            if (j == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)A, 16, offA, 0, 0, 0);
+            if (j == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(A + 2 * 4096), 16, offA + 2u * PSTEP, 0, 0, 0);
+            if (j == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(B + 4096), 16, offB + PSTEP, 0, 0, 0);
+        } else {
+            if (j == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(A + 4096), 16, offA + PSTEP, 0, 0, 0);
+            if (j == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)B, 16, offB, 0, 0, 0);
+            if (j == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(B + 2 * 4096), 16, offB + 2u * PSTEP, 0, 0, 0);
+        }
+    };
+    auto dma_chunk = [&](int stage) { dma_prep(stage); dma_piece(0); dma_piece(1); dma_piece(2); };
+
+    f32x16 acc[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[tm][r] = 0.0f;
+
+    if (c_begin < c_end) { dma_chunk(0); dma_chunk(1); }
+    // the epilogue's row tables, computed while the first chunks are in flight
+    if (tid < BM) {
+        const int m = m0 + tid;
+        int pix = -1, nn = 0;
+        if (m < Mcls) {
+            nn = div_small(m, QH * QW, inv_hw);
+            const int r = m - nn * (QH * QW);
+            const int qy = div_small(r, QW, inv_w), qx = r - qy * QW;
+            pix = (nn * a.OH + (qy * up + py)) * a.OW + (qx * up + px);
+        }
+        row_pix[tid] = pix;
+        row_n[tid] = nn;
+        row_nz[tid] = noise_term(a, pix);
+    }
+    // fragment addresses: row r of an image sits at [piece][2 r + (half ^ ((r >> 3) & 1))] x 16 B
+    int fa[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; tm++) {
+        const int r = wm * 64 + tm * 32 + l31;
+        fa[tm] = (2 * r + (h ^ ((r >> 3) & 1))) * 16;
+    }
+    const int rb_ = wn * 32 + l31;
+    const int fb = P_IMG + (2 * rb_ + (h ^ ((rb_ >> 3) & 1))) * 16;
+    if (a.prio) __builtin_amdgcn_s_setprio(0);
+    stamp(1);
+
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int st = 0;
+    for (int c = c_begin; c < c_end; c++) {
+        // chunk c: issued two iterations ago (three instructions of this wave are younger: chunk c+1)
+        asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
+        // everyone has chunk c in stage st, and has finished reading stage st + 2 (chunk c-1): it is refilled with chunk c+2
+        const int nst = st >= 1 ? st - 1 : P_NSTAGE - 1;
+        const unsigned char* S = smem + st * P_STAGE;
+        bf16x8 af[TM][3], bfr[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            bfr[q] = *reinterpret_cast<const bf16x8*>(S + fb + q * 4096);
+#pragma unroll
+            for (int tm = 0; tm < TM; tm++) af[tm][q] = *reinterpret_cast<const bf16x8*>(S + fa[tm] + q * 4096);
+        }
+        dma_prep(nst);
+        f32x16 t[TM];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tm = 0; tm < TM; tm++) t[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][0], bfr[0], zero, 0, 0, 0);
+        int g = 0;
+#pragma unroll
+        for (int o = 1; o < 3; o++)
+#pragma unroll
+            for (int i = 0; i <= o; i++) {
+                // the next-but-one chunk's three DMA instructions go out in the middle of the matrix cluster (their issue, ~60+ cycles
+                // each, then overlaps the cluster instead of delaying its start: 753 -> 648 us on the 32x32 C512 layer; placed
+                // after 0 / 1 / 2 / 3 / 4 product groups: 671 / 660 / 648 / 672 / 676)
+                if (g == 2) { __builtin_amdgcn_sched_barrier(0); dma_piece(0); dma_piece(1); dma_piece(2); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+                for (int tm = 0; tm < TM; tm++) t[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][i], bfr[o - i], t[tm], 0, 0, 0);
+                ++g;
+            }
+#pragma unroll
+        for (int tm = 0; tm < TM; tm++) acc[tm] += t[tm];
+        st = (st + 1 == P_NSTAGE) ? 0 : st + 1;
+    }
+    stamp(2);
+    // ---- epilogue (as conv_fwd_dma_kernel) ----
+    if (sliced && nsplit > 1) {
+        float* wst = a.y + ((size_t)(tile - a.full_tiles) * a.splits + split) * (BM * BN);
+#pragma unroll
+        for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                wst[row * BN + wn * 32 + l31] = acc[tm][r];
+            }
+        return;
+    }
+    __syncthreads();        // the row tables (written before the loop; a tile with no chunk has passed no barrier yet)
+    float* out = a.out;
+    const bool scale = a.out_scale != nullptr;
+    const float alpha = a.alpha;
+    const int co = n0 + wn * 32 + l31;
+    const bool in = co < a.Cout;
+    const int n_first = row_n[0], n_last = row_n[min(BM, Mcls - m0) - 1];
+    const bool one_sample = n_first == n_last;
+    const float mul = (scale && one_sample && in) ? a.out_scale[n_first * a.Cout + co] : 1.0f;
+    const float bia = (a.act && a.bias && in) ? a.bias[co] : 0.0f;
+    const bool row_scale = scale && !one_sample;
+#pragma unroll
+    for (int tm = 0; tm < TM; tm++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int pix = row_pix[row];
+            if (pix < 0 || !in) continue;
+            float v = acc[tm][r] * alpha;
+            if (scale && one_sample) v *= mul;
+            if (row_scale) v *= a.out_scale[row_n[row] * a.Cout + co];
+            if (a.act) v = epi_act(a.act, v + row_nz[row] + bia, a.act_alpha) * a.act_gain;
+            out[(size_t)pix * a.Cout + co] = v;
+        }
+    }
+    stamp(3);
+}
+
+// ------------------------------------------------------------------------------
 // Weight-gradient kernel: dw[tap][ci][co] = sum_pixels xs[pixel(tap)][ci] * dys[pixel][co].
 // GEMM view: M = Cin tile, N = Cout tile, K = pixels of the tap's parity class.
 // grid = (ci tiles, co tiles, taps * splits)
@@ -1476,12 +1825,34 @@ bool walk_ok(const igan_conv2d_params* p) {
     return walk && vecA && vecB && (p->in_scale == nullptr || vecS) && (p->Cin % BK == 0);
 }
 
+// Does this launch take the bf16-piece form (conv_fwd_planes_kernel)?  IGAN_CONV_PLANES=1, the 128x128 tile, Cin % 32 == 0, both
+// piece images addressable with 32-bit offsets below the out-of-range marker -- and a reduction deep enough to pay for writing
+// the piece images: 3x3 taps on at least 128 channels (taps * Cin >= 1152) over at least 2048 output rows.  Measured per layer
+// (tools/conv_layers.py): the 1x1 Skip convolutions and the 4x4 / 8x8 layers lose (D 128 Skip 77 -> 220 us), everything from
+// 16x16 Conv1 up gains.  planes_shape_ok() is what the PLAN sizes the workspace by (shapes only: plans are cached per shape);
+// the launch also needs 16 B aligned operands.
+bool planes_shape_ok(const igan_conv2d_params* p, const FwdTile& t, int Mmax) {
+    static const bool planes = getenv("IGAN_CONV_PLANES") && atoi(getenv("IGAN_CONV_PLANES")) == 1;
+    if (!planes || t.BM != 128 || t.BN != 128 || p->Cin % BK != 0) return false;
+    if (p->KH * p->KW == 1 || (long long)p->KH * p->KW * p->Cin < 1152 || Mmax < 2048) return false;      // 1x1: the Skip layers and the nearest-neighbour distance GEMM stay on the fp32 instruction
+    if ((long long)p->N * p->OH * p->OW >= (1LL << 24)) return false;
+    if ((long long)p->N * p->H * p->W * p->Cin * 6 >= 0x7FFFFF00LL || (long long)p->KH * p->KW * p->Cin * p->Cout * 6 >= 0x7FFFFF00LL) return false;
+    return true;
+}
+bool use_planes_kernel(const igan_conv2d_params* p, const FwdTile& t, int Mmax) {
+    return planes_shape_ok(p, t, Mmax) && (((uintptr_t)p->x | (uintptr_t)p->w | (uintptr_t)p->in_scale) & 15) == 0;
+}
+size_t planes_x_floats(const igan_conv2d_params* p) { return (size_t)p->N * p->H * p->W * p->Cin * 6 / 4; }
+size_t planes_w_floats(const igan_conv2d_params* p) { return (size_t)p->KH * p->KW * p->Cin * p->Cout * 6 / 4; }
+
 }  // namespace
 
 // Diagnostic hook (tools/conv_phases.py): when set, every forward-type launch writes 4 time stamps per workgroup (entry, main
 // loop start, main loop end, exit; 100 MHz ticks) to this buffer.  Not part of the operator surface.
 static unsigned long long* g_conv_diag = nullptr;
 extern "C" void igan_debug_set_conv_diag(unsigned long long* p) { g_conv_diag = p; }
+
+static int conv2d_plan_tiles(const igan_conv2d_params* p, int* splits, int* sliced_tiles, size_t* workspace_floats);
 
 extern "C" int igan_conv2d_plan(const igan_conv2d_params* p, int* splits, int* sliced_tiles, size_t* workspace_floats) {
     IGAN_REQUIRE(p && splits && sliced_tiles && workspace_floats, "conv2d_plan: null argument");
@@ -1490,6 +1861,15 @@ extern "C" int igan_conv2d_plan(const igan_conv2d_params* p, int* splits, int* s
     *sliced_tiles = 0;
     *workspace_floats = 0;
     if (is_small_dense(p) || igan::thin_conv_kind(p)) return IGAN_OK;
+    if (int rc = conv2d_plan_tiles(p, splits, sliced_tiles, workspace_floats)) return rc;
+    int Mmax, chunks_max, nclass;
+    fwd_counts(p, Mmax, chunks_max, nclass);
+    if (planes_shape_ok(p, pick_fwd_tile(Mmax, p->Cout), Mmax))      // the piece images of x and of the filter follow the partial tiles
+        *workspace_floats += planes_x_floats(p) + planes_w_floats(p);
+    return IGAN_OK;
+}
+
+static int conv2d_plan_tiles(const igan_conv2d_params* p, int* splits, int* sliced_tiles, size_t* workspace_floats) {
     int Mmax, chunks_max, nclass;
     fwd_counts(p, Mmax, chunks_max, nclass);
     const FwdTile t = pick_fwd_tile(Mmax, p->Cout);
@@ -1556,6 +1936,10 @@ extern "C" int igan_conv2d_kernel_name(const igan_conv2d_params* p, char* buf, i
     const bool vecS = (p->Cin % 4 == 0) && (((uintptr_t)p->in_scale & 15) == 0);
     const bool vecB = ((wt ? p->Cin : p->Cout) % 4 == 0) && (((uintptr_t)p->w & 15) == 0);
     const bool vec = vecA && vecB && (p->in_scale == nullptr || vecS);
+    if (use_planes_kernel(p, t, Mmax)) {
+        snprintf(buf, (size_t)buflen, "conv_fwd_planes_kernel");
+        return IGAN_OK;
+    }
     if (use_dma_kernel(p, t, walk_ok(p))) {
         const int split = getenv("IGAN_CONV_BF16X3") ? atoi(getenv("IGAN_CONV_BF16X3")) : 0;
         snprintf(buf, (size_t)buflen, split == 6 ? "conv_fwd_dma_kernel<%s, %s, 3>" : split ? "conv_fwd_dma_kernel<%s, %s, 2>" : "conv_fwd_dma_kernel<%s, %s>",
@@ -1596,11 +1980,15 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
     int splits = std::max(1, p->splits);
     const int sliced = std::min(std::max(p->sliced_tiles, 0), l.T);   // trailing tiles cut along the reduction axis
     if (sliced == 0) splits = 1;
+    const size_t partial_floats = (splits > 1) ? (size_t)sliced * splits * t.BM * t.BN : 0;
+    // the variant needs its piece images' room behind the partial tiles; a caller that did not provide it gets the fp32 kernel
+    const bool planes = use_planes_kernel(p, t, Mmax) && p->workspace != nullptr &&
+                        p->workspace_floats >= partial_floats + planes_x_floats(p) + planes_w_floats(p);
     if (splits > 1) {
         IGAN_REQUIRE(p->workspace != nullptr, "conv2d: splits > 1 needs a workspace");
-        IGAN_REQUIRE(p->workspace_floats >= (size_t)sliced * splits * t.BM * t.BN, "conv2d: workspace too small");
-        IGAN_REQUIRE((((uintptr_t)p->workspace) & 15) == 0, "conv2d: workspace must be 16-byte aligned");
+        IGAN_REQUIRE(p->workspace_floats >= partial_floats, "conv2d: workspace too small");
     }
+    if (splits > 1 || planes) IGAN_REQUIRE((((uintptr_t)p->workspace) & 15) == 0, "conv2d: workspace must be 16-byte aligned");
 
     ConvArgs a;
     a.x = p->x; a.w = p->w;
@@ -1638,11 +2026,27 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
     }
     a.bias = p->bias; a.act = p->act; a.act_alpha = p->act_alpha; a.act_gain = p->act_gain;
     a.noise = p->act ? p->noise : nullptr; a.noise_strength = p->noise_strength; a.noise_bcast = p->noise_bcast;
+    a.xp = nullptr; a.wp = nullptr;
 
     dim3 grid(a.full_tiles + (l.T - a.full_tiles) * splits);
     const bool wt = p->w_transposed != 0;
     const bool vec = a.vecA && a.vecB && (a.in_scale == nullptr || a.vecS);
     bool launched = false;
+    if (planes) {       // bf16-piece form: write the two piece images, then the tile kernel
+        unsigned short* xp = reinterpret_cast<unsigned short*>(p->workspace + partial_floats);
+        unsigned short* wp = reinterpret_cast<unsigned short*>(p->workspace + partial_floats + planes_x_floats(p));
+        const int cpp = p->Cin / PK;
+        const int total = p->N * p->H * p->W * cpp;
+        hipLaunchKernelGGL(to_planes_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, p->x, p->in_scale, xp, total, cpp, p->Cin, p->H * p->W);
+        const int wtotal = p->KH * p->KW * p->Cout * cpp;
+        if (wt) hipLaunchKernelGGL((filter_planes_kernel<true>), dim3(ceil_div(wtotal, 256)), dim3(256), 0, stream, p->w, wp, p->KH * p->KW, p->KW, p->Cout, p->Cin);
+        else hipLaunchKernelGGL((filter_planes_kernel<false>), dim3(ceil_div(wtotal, 256)), dim3(256), 0, stream, p->w, wp, p->KH * p->KW, p->KW, p->Cout, p->Cin);
+        a.xp = xp; a.wp = wp;
+        a.cpt = cpp;
+        hipLaunchKernelGGL(conv_fwd_planes_kernel, grid, dim3(512), 0, stream, a);
+        IGAN_LAUNCH_CHECK("conv2d (bf16-piece) launch");
+        launched = true;
+    } else
     if (use_dma_kernel(p, t, a.walk != 0)) {       // LDS-DMA form of the 128x128 tile
         // measure-only: IGAN_CONV_BF16X3=1 (two bf16 pieces per operand, three products) / IGAN_CONV_BF16X3=6 (three pieces, six
         // products) run these launches on the bf16 matrix pipe; not fp32-exact

@@ -559,10 +559,11 @@ def conv2d_raw(x, w, geom, out_hw, cout, w_transposed=False, in_scale=None, out_
         plan = (splits.value, wsf.value, sliced.value)
         _plan_cache[key] = plan
     ws = None
-    if plan[0] > 1:
+    if plan[1] > 0:     # partial tiles of the sliced tail and / or the piece images of the bf16-piece form
         ws = torch.empty((plan[1],), device=x.device, dtype=torch.float32)
         p.workspace = ws.data_ptr()
         p.workspace_floats = plan[1]
+    if plan[0] > 1:
         p.splits = plan[0]
         p.sliced_tiles = plan[2]
     if stamp_log is not None:

@@ -1,0 +1,98 @@
+"""GPU: the bf16-piece form of the forward / data-gradient convolution (IGAN_CONV_PLANES=1, csrc/conv2d_mfma.hip
+conv_fwd_planes_kernel) against fp64.  It is a labelled VARIANT, not the product path: the switch is read
+once per process, so the checks run in a child process.  Tolerances are those of the exact-fp32 path's own full-size tests
+(3e-6 relative to the output rms per element, tests/test_gpu_fullsize.py), plus the property that made the variant acceptable at
+all: no coherent shift of the outputs (|mean error| below 5e-8 rms; profiles/r03_bf16_split_rounding.txt)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r'''
+import ctypes, sys
+import torch
+import torch.nn.functional as F
+sys.path.insert(0, %r)
+from inclusivegan_amd import hip_ops, _abi
+dev = torch.device('cuda', 0)
+g = torch.Generator().manual_seed(7)
+lib = _abi.get_plugin()
+seen = set()
+_orig = lib.igan_conv2d
+def check(name, N, Cin, H, Cout, k, stride, up, pad, out, transposed=False, scales=False, act=None):
+    x = torch.randn(N, Cin, H, H, generator=g)
+    w = torch.randn(k, k, Cin, Cout, generator=g) / (k * k * Cin) ** 0.5
+    s = (torch.rand(N, Cin, generator=g) + 0.5) if scales else None
+    d = (torch.rand(N, Cout, generator=g) + 0.5) if scales else None
+    geom = hip_ops.ConvGeom(k, k, stride, up, pad, pad)
+    xs = x.double() * (s.double()[:, :, None, None] if scales else 1.0)
+    wd = w.double().permute(3, 2, 0, 1)             # OIHW
+    # include/igan_hip.h's formula stated with torch ops, as tests/test_gpu_ops.py _conv_oracle: zero-stuff, pad, correlate
+    xu = xs
+    if up > 1:
+        xu = torch.zeros(N, Cin, (H - 1) * up + 1, (H - 1) * up + 1, dtype=torch.float64)
+        xu[:, :, ::up, ::up] = xs
+    need = (out - 1) * stride + k
+    xp = F.pad(xu, [pad, max(need - pad - xu.shape[3], 0), pad, max(need - pad - xu.shape[2], 0)])
+    want = F.conv2d(xp, wd, stride=stride)[:, :, :out, :out]
+    if scales:
+        want = want * d.double()[:, :, None, None]
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last)
+    got = hip_ops.conv2d_raw(xd, w.to(dev), geom, (out, out), Cout, in_scale=(s.to(dev) if scales else None), out_scale=(d.to(dev) if scales else None))
+    assert tuple(got.shape) == tuple(want.shape), (name, got.shape, want.shape)
+    err = got.double().cpu() - want
+    rms = float(want.pow(2).mean().sqrt())
+    rel, mean, mx = float(err.pow(2).mean().sqrt()) / rms, float(err.mean()) / rms, float(err.abs().max()) / rms
+    print('%%-28s rel L2 %%.2e  mean %%+.2e  max %%.2e' %% (name, rel, mean, mx))
+    assert rel < 3e-7 and abs(mean) < 5e-8 and mx < 3e-6, (name, rel, mean, mx)
+
+def kernel_of(N, Cin, H, Cout, k, stride, up, pad, out):
+    p = _abi.Conv2DParams(x=1 << 20, w=1 << 20, y=1 << 20, in_scale=None, out_scale=None, workspace=None, workspace_floats=0, N=N, H=H, W=H, Cin=Cin, OH=out, OW=out,
+                          Cout=Cout, KH=k, KW=k, stride=stride, up=up, pad_y=pad, pad_x=pad, w_transposed=0, splits=1, alpha=1.0, bias=None, act=0, act_alpha=0.0, act_gain=1.0)
+    buf = ctypes.create_string_buffer(128)
+    _abi.check(lib.igan_conv2d_kernel_name(ctypes.byref(p), buf, 128))
+    return buf.value.decode()
+
+cases = [
+    ('3x3 32x32 C256 modulated', 3, 256, 32, 256, 3, 1, 1, 1, 32, dict(scales=True)),
+    ('3x3 16x16 C512 (sliced)', 9, 512, 16, 512, 3, 1, 1, 1, 16, dict()),
+    ('3x3 s2 33->16 C256->512', 9, 256, 33, 512, 3, 2, 1, 0, 16, dict()),
+    ('3x3 up2 16->33 C512->256', 8, 512, 16, 256, 3, 1, 2, 2, 33, dict(scales=True)),
+    ('3x3 24x24 C128->384 ragged', 4, 128, 24, 384, 3, 1, 1, 1, 24, dict()),
+]
+# shapes the variant leaves to the fp32 kernels: 1x1 (Skip, the distance GEMM), shallow reductions, few rows
+for args in ((2, 128, 64, 256, 1, 1, 1, 0, 64), (2, 64, 32, 128, 3, 1, 1, 1, 32), (3, 512, 8, 512, 3, 1, 1, 1, 8)):
+    assert kernel_of(*args) != 'conv_fwd_planes_kernel', args
+cases = cases
+for name, N, Cin, H, Cout, k, stride, up, pad, out, kw in cases:
+    assert kernel_of(N, Cin, H, Cout, k, stride, up, pad, out) == 'conv_fwd_planes_kernel', (name, kernel_of(N, Cin, H, Cout, k, stride, up, pad, out))
+    check(name, N, Cin, H, Cout, k, stride, up, pad, out, **kw)
+# gradients through the operator surface: data gradient = the same kernel with the filter transposed
+from inclusivegan_amd.hip_ops import conv2d
+x = torch.randn(3, 256, 32, 32, generator=g)
+w = torch.randn(3, 3, 256, 256, generator=g) / 48.0
+dy = torch.randn(3, 256, 32, 32, generator=g)
+xd = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+wdv = w.to(dev).requires_grad_(True)
+y = conv2d(xd, wdv, hip_ops.ConvGeom(3, 3, 1, 1, 1, 1), (32, 32))
+y.backward(dy.to(dev).contiguous(memory_format=torch.channels_last))
+x64 = x.double().requires_grad_(True); w64 = w.double().requires_grad_(True)
+F.conv2d(x64, w64.permute(3, 2, 0, 1), padding=1).backward(dy.double())
+for nm, got, want in (('dx', xd.grad, x64.grad), ('dw', wdv.grad, w64.grad)):
+    e = got.double().cpu() - want
+    rel = float(e.pow(2).mean().sqrt() / want.pow(2).mean().sqrt())
+    print('%%-28s rel L2 %%.2e' %% (nm, rel))
+    assert rel < 1e-6, (nm, rel)
+print('PLANES-VARIANT-OK')
+'''
+
+
+def test_bf16_piece_variant_against_fp64(cuda_device):
+    env = dict(os.environ, IGAN_CONV_PLANES='1')
+    r = subprocess.run([sys.executable, '-c', CHILD % ROOT], env=env, capture_output=True, text=True, timeout=600)
+    sys.stdout.write(r.stdout[-3000:])
+    assert r.returncode == 0 and 'PLANES-VARIANT-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
