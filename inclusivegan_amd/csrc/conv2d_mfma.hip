@@ -1185,7 +1185,7 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
     float* row_nz = reinterpret_cast<float*>(row_n + BM);
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: kept in a scalar register
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
     const int up = 1 << a.up_shift;
@@ -1231,22 +1231,8 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
     const int drow = 32 * (wave & 3) + (lane >> 1);
     const int dhalf = (lane & 1) ^ ((drow >> 3) & 1);
     const bool lowave = wave < 4;
-    int rn, rby, rbx;
-    bool rok;
-    {
-        const int m = m0 + drow;
-        rok = m < Mcls;
-        const int mm = rok ? m : 0;
-        const int nn = div_small(mm, QH * QW, inv_hw);
-        const int r = mm - nn * (QH * QW);
-        const int qy = div_small(r, QW, inv_w), qx = r - qy * QW;
-        rn = nn;
-        rby = (qy * up + py) * a.stride - a.pad_y;
-        rbx = (qx * up + px) * a.stride - a.pad_x;
-    }
     // reduction order: 16-channel slice outermost, taps inside it -- the taps of a slice re-read the same (shifted) 96 B row
-    // pieces back to back, so eight of the nine fetches of a row piece hit the XCD's L2 (tap-outermost re-reads a row only after a
-    // pass over all channels: 25 MB per XCD in flight, served from the Infinity Cache at half the rate)
+    // pieces back to back, so eight of the nine fetches of a row piece hit the XCD's L2
     const int ntap = nky * nkx;
     int ld_cc = (c_begin < c_end) ? c_begin / ntap : 0;
     int ld_t0 = (c_begin < c_end) ? c_begin - ld_cc * ntap : 0;
@@ -1256,21 +1242,39 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.xp), 0, (int)xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.wp), 0, (int)wbytes, 0x00020000);
     const unsigned pixA = (unsigned)a.Cin * 6u;           // bytes per pixel
-    unsigned offA = OOB, offB = OOB;
-    auto decode_tap = [&]() {
-        const int ky = ky0 + (ld_ta << a.up_shift), kx = kx0 + (ld_tb << a.up_shift);
-        const int vy = rby + ky, vx = rbx + kx;
-        const int iy = vy >> a.up_shift, ix = vx >> a.up_shift;
-        const bool ok = rok & (vy >= 0) & (vx >= 0) & (iy < a.H) & (ix < a.W);
-        offA = ok ? (unsigned)((rn * a.H + iy) * a.W + ix) * pixA + (unsigned)ld_cc * 96u + (unsigned)dhalf * 16u : OOB;
+    // Per lane, once per tile: the byte offset of its A row under tap (0, 0) of the class and one validity bit per tap (tap (ta, tb)
+    // reads input pixel (iy0 + ta, ix0 + tb): the class's taps are `up` apart and the parity makes the shift exact), and the
+    // offset of its B row inside a (slice, tap) block.  A step then costs four vector instructions of address work: add the
+    // wave-uniform (tap, slice) displacement, test the tap's bit, select the out-of-range marker.
+    unsigned baseA, maskA = 0u, voffB;
+    {
+        const int m = m0 + drow;
+        const bool rok = m < Mcls;
+        const int mm = rok ? m : 0;
+        const int nn = div_small(mm, QH * QW, inv_hw);
+        const int r = mm - nn * (QH * QW);
+        const int qy = div_small(r, QW, inv_w), qx = r - qy * QW;
+        const int vy0 = (qy * up + py) * a.stride - a.pad_y + ky0, vx0 = (qx * up + px) * a.stride - a.pad_x + kx0;
+        const int iy0 = vy0 >> a.up_shift, ix0 = vx0 >> a.up_shift;
+        baseA = (unsigned)((nn * a.H + iy0) * a.W + ix0) * pixA + (unsigned)dhalf * 16u;     // modulo 2^32; exact for every valid tap
+        for (int ta = 0; ta < nky; ta++)
+            for (int tb = 0; tb < nkx; tb++) {
+                const int iy = iy0 + ta, ix = ix0 + tb;
+                const bool ok = rok & (iy >= 0) & (ix >= 0) & (iy < a.H) & (ix < a.W);
+                maskA |= ok ? (1u << (ta * nkx + tb)) : 0u;
+            }
         const int co = n0 + drow;
-        offB = (co < a.Cout) ? (unsigned)((ld_cc * (a.KH * a.KW) + ky * a.KW + kx) * a.Cout + co) * 96u + (unsigned)dhalf * 16u : OOB;
-    };
+        voffB = (co < a.Cout) ? (unsigned)co * 96u + (unsigned)dhalf * 16u : OOB;
+    }
+    unsigned offA = OOB, soffB = 0u;
     typedef __attribute__((address_space(3))) void lds_void;
-    constexpr unsigned PSTEP = 32u;          // bytes between the pieces of one (pixel, slice)
     unsigned char* dA = nullptr;
     auto dma_prep = [&](int stage) {        // addresses of the next chunk, then one step forward in (slice, tap) order
-        decode_tap();
+        const unsigned disp = (unsigned)(ld_ta * a.W + ld_tb) * pixA + (unsigned)ld_cc * 96u;                      // scalar
+        const unsigned bit = 1u << (ld_ta * nkx + ld_tb);                                                           // scalar
+        offA = (maskA & bit) ? baseA + disp : OOB;
+        const int ky = ky0 + (ld_ta << a.up_shift), kx = kx0 + (ld_tb << a.up_shift);
+        soffB = (unsigned)((ld_cc * (a.KH * a.KW) + ky * a.KW + kx) * a.Cout) * 96u;                               // scalar
         dA = smem + stage * P_STAGE + (wave & 3) * 1024;
         ++ld_tb;
         const int w1 = (ld_tb == nkx) ? 1 : 0;
@@ -1280,18 +1284,19 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
         ld_ta = w2 ? 0 : ld_ta;
         ld_cc += w2;
     };
-    auto dma_piece = [&](int j) {           // one of this wave's three KiB of the 24 KiB stage
+    auto dma_piece = [&](int j) {           // one of this wave's three KiB of the 24 KiB stage; the pieces of a (pixel, slice) are 32 B apart
         unsigned char* A = dA;
         unsigned char* B = dA + P_IMG;
-        // an out-of-range offset stays out of range with the piece offset added (OOB + 64 < 2^31 <= any wrap)
+        // an out-of-range offset stays out of range with the piece offset added
+        // (the piece displacement rides in the scalar offset: the instruction's immediate offset would also move the LDS address)
         if (lowave) {
             if (j == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)A, 16, offA, 0, 0, 0);
-            if (j == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(A + 2 * 4096), 16, offA + 2u * PSTEP, 0, 0, 0);
-            if (j == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(B + 4096), 16, offB + PSTEP, 0, 0, 0);
+            if (j == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(A + 2 * 4096), 16, offA, 64, 0, 0);
+            if (j == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(B + 4096), 16, voffB, soffB + 32u, 0, 0);
         } else {
-            if (j == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(A + 4096), 16, offA + PSTEP, 0, 0, 0);
-            if (j == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)B, 16, offB, 0, 0, 0);
-            if (j == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(B + 2 * 4096), 16, offB + 2u * PSTEP, 0, 0, 0);
+            if (j == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(A + 4096), 16, offA, 32, 0, 0);
+            if (j == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)B, 16, voffB, soffB, 0, 0);
+            if (j == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(B + 2 * 4096), 16, voffB, soffB + 64u, 0, 0);
         }
     };
     auto dma_chunk = [&](int stage) { dma_prep(stage); dma_piece(0); dma_piece(1); dma_piece(2); };
