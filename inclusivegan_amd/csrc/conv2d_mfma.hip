@@ -1432,6 +1432,8 @@ struct WgradArgs {
     int vecY;   // 8 B stores usable (Cout even, destination 8 B aligned)
     int xcd_remap;  // XCD-aware block order (remap_xcd)
     float alpha;  // dw multiplier (applied here when splits == 1, else by the reduce kernel)
+    const unsigned short* xp;    // bf16-piece form (conv_wgrad_planes_kernel): x * in_scale and dy * out_scale as [pixel][C/16][3][16] bf16
+    const unsigned short* dyp;
 };
 
 // SCM (scale mode, host dispatch on the two pointers): 0 = neither in_scale nor out_scale (plain
@@ -1679,6 +1681,185 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_wgr
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------
+// Weight gradient in bf16-piece form (IGAN_CONV_PLANES=1; the arithmetic of conv_fwd_planes_kernel).  GEMM view as in
+// conv_wgrad_kernel: M = 128 input channels, N = 128 output channels, K = the pixels of the tap's parity class, 16 per step.
+// Both operands are read ALONG the pixel axis, which the piece images ([pixel][C/16][piece][16]) do not have contiguous: a stage
+// holds them as they are -- per piece a [16 pixel rows][128 channels] bf16 image, 256 B per row -- and the fragments are read
+// with ds_read_b64_tr_b16 (a 16-lane group fetches 4 rows x 16 columns and every lane receives one COLUMN: four consecutive
+// pixels of its channel; two reads make the eight k values of a 32x32x16 operand; tools/tr_read_probe.hip).  The 16 B chunk
+// (8 channels) ch of row r sits at 256 r + 16 (ch ^ (((r & 3) << 2) | ((r >> 2) & 3))): conflict-free transposed reads
+// (cdna_hip_programming.md T10, image (b)).  A DMA instruction fills four rows of one piece (1 KiB); its lanes fetch the chunk
+// that belongs in their slot; padding taps, the ragged end of the pixel axis and channel tails are out-of-range offsets (zeros).
+// grid and split as conv_wgrad_kernel; partial tiles go to the same workspace and plain_reduce_kernel adds them in fixed order.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+__global__ __launch_bounds__(512, 4) void conv_wgrad_planes_kernel(WgradArgs a) {
+    constexpr int TM = 2, WN = 4;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[P_NSTAGE * P_STAGE];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int up = 1 << a.up_shift;
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    int tap = bz / a.splits, split = bz - tap * a.splits;
+    if (a.xcd_remap) {       // block order of conv_wgrad_kernel: the taps of one pixel slice are neighbours on one XCD
+        const int gx = gridDim.x, gy = gridDim.y, taps = a.KH * a.KW;
+        const int lin = remap_xcd(bx + gx * (by + gy * bz), gx * gy * (int)gridDim.z);
+        tap = lin % taps;
+        int rest = lin / taps;
+        bx = rest % gx; rest /= gx;
+        by = rest % gy;
+        split = rest / gy;
+    }
+    const int ky = tap / a.KW, kx = tap - ky * a.KW;
+    const int py = (a.pad_y - ky) & (up - 1);
+    const int px = (a.pad_x - kx) & (up - 1);
+    const int QH = (a.OH - py + up - 1) >> a.up_shift;
+    const int QW = (a.OW - px + up - 1) >> a.up_shift;
+    const int Kpix = (QH > 0 && QW > 0) ? a.N * QH * QW : 0;
+    const int chunks = (Kpix + PK - 1) / PK;
+    const int c_begin = (int)(((long long)split * chunks) / a.splits);
+    const int c_end = (int)(((long long)(split + 1) * chunks) / a.splits);
+    const int m0 = bx * 128, n0 = by * 128;
+    const int s_in = (up == 1) ? a.stride : 1;
+    const int cy = (up == 1) ? ky - a.pad_y : (py + ky - a.pad_y) >> 1;
+    const int cx = (up == 1) ? kx - a.pad_x : (px + kx - a.pad_x) >> 1;
+
+    // ---- DMA lane geometry: wave w fills rows 4 (w & 3) .. +3 of its three (operand, piece) images; lane -> row 4 (w & 3) + lane / 16,
+    // slot lane & 15, channel chunk = slot ^ x(row)
+    const int drow = 4 * (wave & 3) + (lane >> 4);
+    const int dch = (lane & 15) ^ (((drow & 3) << 2) | ((drow >> 2) & 3));
+    const bool lowave = wave < 4;
+    const unsigned rowA = (unsigned)a.Cin * 6u, rowB = (unsigned)a.Cout * 6u;       // bytes per pixel
+    const bool chA = m0 + 8 * dch < a.Cin, chB = n0 + 8 * dch < a.Cout;
+    const unsigned constA = (unsigned)((m0 >> 4) + (dch >> 1)) * 96u + (unsigned)(dch & 1) * 16u;
+    const unsigned constB = (unsigned)((n0 >> 4) + (dch >> 1)) * 96u + (unsigned)(dch & 1) * 16u;
+    const int dQW = max(QW, 1), dQH = max(QH, 1);
+    const int st_b = PK % dQW, st_a = PK / dQW, st_a2 = st_a % dQH, st_a1 = st_a / dQH;     // one step = 16 pixels = st_a1 samples + st_a2 rows + st_b columns
+    int kp = c_begin * PK + drow, wn_ = 0, wqy = 0, wqx = 0;      // this lane's pixel of the next chunk to fetch
+    {
+        wn_ = kp / (dQH * dQW);
+        const int r = kp - wn_ * (dQH * dQW);
+        wqy = r / dQW; wqx = r - wqy * dQW;
+    }
+    const unsigned xbytes = (unsigned)a.N * a.H * a.W * a.Cin * 6u, dybytes = (unsigned)a.N * a.OH * a.OW * a.Cout * 6u;   // host: both < OOB
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.xp), 0, (int)xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.dyp), 0, (int)dybytes, 0x00020000);
+    typedef __attribute__((address_space(3))) void lds_void;
+    unsigned offA = OOB, offB = OOB;
+    unsigned char* dA = nullptr;
+    auto dma_prep = [&](int stage) {
+        const int iy = __mul24(wqy, s_in) + cy, ix = __mul24(wqx, s_in) + cx;
+        const bool live = kp < Kpix;
+        const bool okA = live & chA & ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);
+        offA = okA ? (unsigned)((wn_ * a.H + iy) * a.W + ix) * rowA + constA : OOB;
+        const int oy = (wqy << a.up_shift) + py, ox = (wqx << a.up_shift) + px;
+        offB = (live & chB) ? (unsigned)((wn_ * a.OH + oy) * a.OW + ox) * rowB + constB : OOB;
+        dA = smem + stage * P_STAGE + (wave & 3) * 1024;
+        kp += PK;                                   // walk to the same row of the next chunk
+        wqx += st_b;
+        const bool c1 = wqx >= QW;
+        wqx -= c1 ? QW : 0;
+        wqy += st_a2 + (c1 ? 1 : 0);
+        const bool c2 = wqy >= QH;
+        wqy -= c2 ? QH : 0;
+        wn_ += st_a1 + (c2 ? 1 : 0);
+    };
+    auto dma_piece = [&](int j) {       // as in conv_fwd_planes_kernel: waves 0-3 A pieces 0, 2 and B piece 1; waves 4-7 A piece 1 and B pieces 0, 2
+        unsigned char* A = dA;
+        unsigned char* B = dA + P_IMG;
+        if (lowave) {
+            if (j == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)A, 16, offA, 0, 0, 0);
+            if (j == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(A + 2 * 4096), 16, offA, 64, 0, 0);
+            if (j == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (lds_void*)(B + 4096), 16, offB, 32, 0, 0);
+        } else {
+            if (j == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(A + 4096), 16, offA, 32, 0, 0);
+            if (j == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (lds_void*)B, 16, offB, 0, 0, 0);
+            if (j == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (lds_void*)(B + 2 * 4096), 16, offB, 64, 0, 0);
+        }
+    };
+
+    // ---- transposed fragment reads: lane 16 g + 4 q + p supplies row q, columns 4 p .. 4 p + 3 of its group's block
+    // (k group g >> 1, channels 16 (g & 1) .. + 15 of the 32-wide fragment); the second read takes the block four rows below
+    const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+    int fA[TM][2], fB[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; hf++) {
+        const int row = 8 * (tg >> 1) + 4 * hf + tq;
+        const int xr = ((row & 3) << 2) | ((row >> 2) & 3);
+#pragma unroll
+        for (int tm = 0; tm < TM; tm++) {
+            const int chunk = wm * 8 + tm * 4 + 2 * (tg & 1) + (tp >> 1);
+            fA[tm][hf] = 256 * row + 16 * (chunk ^ xr) + 8 * (tp & 1);
+        }
+        const int chunkb = wn * 4 + 2 * (tg & 1) + (tp >> 1);
+        fB[hf] = P_IMG + 256 * row + 16 * (chunkb ^ xr) + 8 * (tp & 1);
+    }
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    auto tr8 = [&](const unsigned char* base, int o0, int o1) -> bf16x8 {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + o0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + o1));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, v);
+    };
+
+    f32x16 acc[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[tm][r] = 0.0f;
+    if (c_begin < c_end) {
+        dma_prep(0); dma_piece(0); dma_piece(1); dma_piece(2);
+        dma_prep(1); dma_piece(0); dma_piece(1); dma_piece(2);
+    }
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int st = 0;
+    for (int c = c_begin; c < c_end; c++) {
+        asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
+        const int nst = st >= 1 ? st - 1 : P_NSTAGE - 1;
+        const unsigned char* S = smem + st * P_STAGE;
+        bf16x8 af[TM][3], bfr[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            bfr[q] = tr8(S + q * 4096, fB[0], fB[1]);
+#pragma unroll
+            for (int tm = 0; tm < TM; tm++) af[tm][q] = tr8(S + q * 4096, fA[tm][0], fA[tm][1]);
+        }
+        dma_prep(nst);
+        f32x16 t[TM];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tm = 0; tm < TM; tm++) t[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][0], bfr[0], zero, 0, 0, 0);
+        int g = 0;
+#pragma unroll
+        for (int o = 1; o < 3; o++)
+#pragma unroll
+            for (int i = 0; i <= o; i++) {
+                if (g == 2) { __builtin_amdgcn_sched_barrier(0); dma_piece(0); dma_piece(1); dma_piece(2); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+                for (int tm = 0; tm < TM; tm++) t[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][i], bfr[o - i], t[tm], 0, 0, 0);
+                ++g;
+            }
+#pragma unroll
+        for (int tm = 0; tm < TM; tm++) acc[tm] += t[tm];
+        st = (st + 1 == P_NSTAGE) ? 0 : st + 1;
+    }
+    // epilogue: rows = input channels, columns = output channels (contiguous across lanes)
+    const size_t wsize = (size_t)a.KH * a.KW * a.Cin * a.Cout;
+    float* out = a.out + (a.splits > 1 ? (size_t)split * wsize : (size_t)0) + (size_t)tap * a.Cin * a.Cout;
+    const float alpha = (a.splits == 1) ? a.alpha : 1.0f;
+    const int co = n0 + wn * 32 + l31;
+#pragma unroll
+    for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int ci = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (ci < a.Cin && co < a.Cout) out[(size_t)ci * a.Cout + co] = acc[tm][r] * alpha;
+        }
 }
 
 // y[i] = alpha * sum_k ws[k][i], fixed order.  Four partial sums so that four loads are in flight per lane (a single
@@ -2161,6 +2342,20 @@ int wgrad_splits(const igan_conv2d_wgrad_params* p) {
     return std::max(s, 1);
 }
 
+// The weight gradient's bf16-piece form (conv_wgrad_planes_kernel): same switch and the same kind of shapes as the forward one --
+// 3x3 filters between at least 128 channels on each side (the 128x128 tile), channel counts in whole 32s, a pixel axis of at least
+// 2048, both piece images below the out-of-range marker.
+bool wgrad_planes_shape_ok(const igan_conv2d_wgrad_params* p) {
+    static const bool planes = getenv("IGAN_CONV_PLANES") && atoi(getenv("IGAN_CONV_PLANES")) == 1;
+    static const bool wg = !(getenv("IGAN_WGRAD_PLANES") && atoi(getenv("IGAN_WGRAD_PLANES")) == 0);      // A/B switch inside the variant
+    if (!planes || !wg || p->KH * p->KW == 1 || p->Cin < 128 || p->Cout < 128 || p->Cin % 32 != 0 || p->Cout % 32 != 0) return false;
+    if ((long long)p->N * p->OH * p->OW < 2048 * (long long)p->up * p->up) return false;
+    if ((long long)p->N * p->H * p->W * p->Cin * 6 >= 0x7FFFFF00LL || (long long)p->N * p->OH * p->OW * p->Cout * 6 >= 0x7FFFFF00LL) return false;
+    return true;
+}
+size_t wgrad_planes_x_floats(const igan_conv2d_wgrad_params* p) { return (size_t)p->N * p->H * p->W * p->Cin * 6 / 4; }
+size_t wgrad_planes_dy_floats(const igan_conv2d_wgrad_params* p) { return (size_t)p->N * p->OH * p->OW * p->Cout * 6 / 4; }
+
 }  // namespace
 
 extern "C" int igan_conv2d_wgrad_plan(const igan_conv2d_wgrad_params* p, int* splits, size_t* workspace_floats) {
@@ -2175,6 +2370,8 @@ extern "C" int igan_conv2d_wgrad_plan(const igan_conv2d_wgrad_params* p, int* sp
     const int s = wgrad_splits(p);
     *splits = s;
     *workspace_floats = (s > 1) ? (size_t)s * p->KH * p->KW * p->Cin * p->Cout : 0;
+    if (wgrad_planes_shape_ok(p))       // the piece images of x and dy follow the partial filters
+        *workspace_floats += wgrad_planes_x_floats(p) + wgrad_planes_dy_floats(p);
     return IGAN_OK;
 }
 
@@ -2225,6 +2422,27 @@ extern "C" int igan_conv2d_wgrad(igan_stream_t stream_, const igan_conv2d_wgrad_
 
     const WgTile t = pick_wg_tile(p->Cin, p->Cout);
     dim3 grid(ceil_div(p->Cin, t.BM), ceil_div(p->Cout, t.BN), p->KH * p->KW * splits);
+    a.xp = nullptr; a.dyp = nullptr;
+    const size_t partial_floats = (splits > 1) ? (size_t)splits * wsize : 0;
+    if (wgrad_planes_shape_ok(p) && p->workspace != nullptr && (((uintptr_t)p->workspace | (uintptr_t)p->x | (uintptr_t)p->dy | (uintptr_t)p->in_scale | (uintptr_t)p->out_scale) & 15) == 0 &&
+        p->workspace_floats >= partial_floats + wgrad_planes_x_floats(p) + wgrad_planes_dy_floats(p)) {
+        unsigned short* xp = reinterpret_cast<unsigned short*>(p->workspace + partial_floats);
+        unsigned short* dyp = reinterpret_cast<unsigned short*>(p->workspace + partial_floats + wgrad_planes_x_floats(p));
+        const int cpa = p->Cin / PK, cpb = p->Cout / PK;
+        const int ta = p->N * p->H * p->W * cpa, tb = p->N * p->OH * p->OW * cpb;
+        hipLaunchKernelGGL(to_planes_kernel, dim3(ceil_div(ta, 256)), dim3(256), 0, stream, p->x, p->in_scale, xp, ta, cpa, p->Cin, p->H * p->W);
+        hipLaunchKernelGGL(to_planes_kernel, dim3(ceil_div(tb, 256)), dim3(256), 0, stream, p->dy, p->out_scale, dyp, tb, cpb, p->Cout, p->OH * p->OW);
+        a.xp = xp; a.dyp = dyp;
+        hipLaunchKernelGGL(conv_wgrad_planes_kernel, grid, dim3(512), 0, stream, a);
+        IGAN_LAUNCH_CHECK("conv2d_wgrad (bf16-piece) launch");
+        if (splits > 1) {
+            const int total = (int)wsize;
+            const int rg = std::min(ceil_div(total, 256), 2048);
+            hipLaunchKernelGGL(plain_reduce_kernel, dim3(rg), dim3(256), 0, stream, (const float*)p->workspace, p->dw, total, splits, p->alpha);
+            IGAN_LAUNCH_CHECK("conv2d_wgrad reduce launch");
+        }
+        return IGAN_OK;
+    }
     const bool vec = a.vecA && a.vecB && (a.in_scale == nullptr || a.vecSA) && (a.out_scale == nullptr || a.vecSB);
     const int scm = (a.in_scale && a.out_scale) ? 1 : ((a.in_scale || a.out_scale) ? 2 : 0);
     // 8 waves pay on the short pixel axes (32x32 and below: +1.5 %), 4 waves on the 128x128 layers (+3-4 %): measured, tools/conv_bench.py

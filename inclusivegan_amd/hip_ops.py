@@ -625,10 +625,11 @@ def conv2d_wgrad_raw(x, dy, geom, in_scale=None, out_scale=None):
         plan = (splits.value, wsf.value)
         _wplan_cache[key] = plan
     ws = None
-    if plan[0] > 1:
+    if plan[1] > 0:     # partial filters of the pixel slices and / or the piece images of the bf16-piece form
         ws = torch.empty((plan[1],), device=x.device, dtype=torch.float32)
         p.workspace = ws.data_ptr()
         p.workspace_floats = plan[1]
+    if plan[0] > 1:
         p.splits = plan[0]
     if stamp_log is not None:
         stamp_log.bracket('conv_wgrad_kernel (+ reduce)', conv_flops(n, h, wd, cin, oh, ow, cout, geom),

@@ -87,6 +87,38 @@ for nm, got, want in (('dx', xd.grad, x64.grad), ('dw', wdv.grad, w64.grad)):
     rel = float(e.pow(2).mean().sqrt() / want.pow(2).mean().sqrt())
     print('%%-28s rel L2 %%.2e' %% (nm, rel))
     assert rel < 1e-6, (nm, rel)
+# weight gradient in piece form (conv_wgrad_planes_kernel): plain, modulated (both scales), stride 2, up 2, ragged pixel axis
+def wgrad_case(name, N, Cin, H, Cout, k, stride, up, pad, out, scales=False):
+    x = torch.randn(N, Cin, H, H, generator=g)
+    dy = torch.randn(N, Cout, out, out, generator=g)
+    s = (torch.rand(N, Cin, generator=g) + 0.5) if scales else None
+    d = (torch.rand(N, Cout, generator=g) + 0.5) if scales else None
+    xs = (x.double() * (s.double()[:, :, None, None] if scales else 1.0))
+    dys = dy.double() * (d.double()[:, :, None, None] if scales else 1.0)
+    w0 = torch.zeros(k, k, Cin, Cout, dtype=torch.float64, requires_grad=True)
+    xu = xs
+    if up > 1:
+        xu = torch.zeros(N, Cin, (H - 1) * up + 1, (H - 1) * up + 1, dtype=torch.float64)
+        xu[:, :, ::up, ::up] = xs
+    need = (out - 1) * stride + k
+    xp = F.pad(xu, [pad, max(need - pad - xu.shape[3], 0), pad, max(need - pad - xu.shape[2], 0)])
+    y = F.conv2d(xp, w0.permute(3, 2, 0, 1), stride=stride)[:, :, :out, :out]
+    (y * dys).sum().backward()
+    want = w0.grad
+    geom = hip_ops.ConvGeom(k, k, stride, up, pad, pad)
+    got = hip_ops.conv2d_wgrad_raw(x.to(dev).contiguous(memory_format=torch.channels_last), dy.to(dev).contiguous(memory_format=torch.channels_last), geom,
+                                   in_scale=(s.to(dev) if scales else None), out_scale=(d.to(dev) if scales else None))
+    err = got.double().cpu() - want
+    rms = float(want.pow(2).mean().sqrt())
+    rel, mean, mx = float(err.pow(2).mean().sqrt()) / rms, float(err.mean()) / rms, float(err.abs().max()) / rms
+    print('%%-28s rel L2 %%.2e  mean %%+.2e  max %%.2e' %% ('wgrad ' + name, rel, mean, mx))
+    assert rel < 5e-7 and abs(mean) < 1e-7 and mx < 5e-6, (name, rel, mean, mx)
+
+wgrad_case('3x3 32x32 C256 modulated', 3, 256, 32, 256, 3, 1, 1, 1, 32, scales=True)
+wgrad_case('3x3 24x24 C128->384', 4, 128, 24, 384, 3, 1, 1, 1, 24)
+wgrad_case('3x3 s2 33->16 C256->512', 9, 256, 33, 512, 3, 2, 1, 0, 16)
+wgrad_case('3x3 up2 16->33 C512->256', 8, 512, 16, 256, 3, 1, 2, 2, 33, scales=True)
+wgrad_case('3x3 19x19 C160->224 ragged', 6, 160, 19, 224, 3, 1, 1, 1, 19)
 print('PLANES-VARIANT-OK')
 '''
 
