@@ -305,8 +305,8 @@ def variant_line(args, timeout_s=900):
     except Exception as e:      # a failed variant run never takes the headline with it
         return {'label': 'bf16-piece convolutions (IGAN_CONV_PLANES=1)', 'error': repr(e)[:200]}
     roof = d.get('roofline', {})
-    return {'label': 'VARIANT, not the product path: forward / data-gradient convolutions as 3 bf16 pieces x 6 products with fp32 sums (IGAN_CONV_PLANES=1); '
-                     'weight gradients and everything else as in the headline', 'value': d['value'], 'unit': d['unit'], 'ms_per_step': d['ms_per_step'],
+    return {'label': 'VARIANT, not the product path: 3x3 convolutions (forward, data gradient, weight gradient) as 3 bf16 pieces x 6 products with fp32 sums (IGAN_CONV_PLANES=1); '
+                     'everything else as in the headline', 'value': d['value'], 'unit': d['unit'], 'ms_per_step': d['ms_per_step'],
             'data_size': 1152, 'hip_graphs': d.get('hip_graphs'), 'dominant_kernel': roof.get('kernel'), 'dominant_kernel_fp32_equivalent_tflops': roof.get('achieved'),
             'conv_family_fp32_equivalent_tflops': roof.get('conv_family_tflops')}
 
@@ -435,7 +435,7 @@ def main():
         'metric': 'training img/sec (whole node), CelebA 128x128 StyleGAN2+IMLE',
         'value': round(imgs / elapsed, 3), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32' if os.environ.get('IGAN_CONV_PLANES') != '1' else 'f32 emulated with 3 bf16 pieces in the forward / data-gradient convolutions (variant)',
+        'dtype': 'f32' if os.environ.get('IGAN_CONV_PLANES') != '1' else 'f32 emulated with 3 bf16 pieces in the 3x3 convolutions (variant)',
         'data': 'synthetic',
         'config': {'workload': 'CelebA-shaped %dx%d StyleGAN2+IMLE, config-e-Gskip-Dresnet (fmap_base 8192), minibatch_gpu %d, '
                                'NN_rec_lpips_weight %g, lazy reg G/4 D/16, random-init weights' % (args.resolution, args.resolution, B, args.lpips_weight),
