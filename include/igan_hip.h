@@ -182,7 +182,10 @@ typedef struct igan_conv2d_params {
     float* y;               /* [N, OH, OW, Cout] */
     const float* in_scale;  /* [N, Cin] or NULL */
     const float* out_scale; /* [N, Cout] or NULL */
-    float* workspace;       /* NULL iff splits <= 1 */
+    float* workspace;       /* igan_conv2d_plan()'s workspace_floats floats, 16-byte aligned; NULL iff the plan asked for none.  It
+                             * holds the partial tiles of the sliced tail (splits > 1) and, when the library runs in its bf16-piece
+                             * variant (environment IGAN_CONV_PLANES=1, not the default), the piece images behind them; a launch that
+                             * gets no room for the images runs the fp32 kernel */
     size_t workspace_floats;
     int N, H, W, Cin;
     int OH, OW, Cout;
@@ -215,7 +218,8 @@ int igan_conv2d_kernel_name(const igan_conv2d_params* p, char* buf, int buflen);
  *                                   * in_scale[n,ci] * dy[n,oy,ox,co] * out_scale[n,co]
  * written in HWIO [KH][KW][Cin][Cout].  The pixel axis is always reduced through
  * the caller's workspace in fixed order (bit-reproducible);
- * igan_conv2d_wgrad_plan() returns the split count and workspace size. */
+ * igan_conv2d_wgrad_plan() returns the split count and workspace size (the partial filters of the pixel
+ * slices; in the bf16-piece variant also the piece images of x and dy, as for igan_conv2d). */
 typedef struct igan_conv2d_wgrad_params {
     const float* x;         /* [N, H, W, Cin] */
     const float* dy;        /* [N, OH, OW, Cout] */
