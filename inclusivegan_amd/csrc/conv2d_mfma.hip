@@ -12,6 +12,10 @@
 // geometry, see include/igan_hip.h).  fp32 in, fp32 accumulate, like the reference
 // (dtype='float32', networks_stylegan2.py:264,323,422).
 //
+// A second, switchable form of the large 3x3 layers (IGAN_CONV_PLANES=1: conv_fwd_planes_kernel, conv_wgrad_planes_kernel, with
+// to_planes_kernel / filter_planes_kernel) runs the same products on the bf16 matrix instruction from three bf16 pieces per fp32
+// operand.  It is a labelled VARIANT, never selected unless the environment asks for it.
+//
 // MI355X design (none of it is in the reference, which calls cuDNN):
 //  * activations are channel-minor [N,H,W,C]: an A-tile row (one output pixel, 32
 //    input channels of one tap) is a contiguous 128 B segment -> coalesced 16 B
