@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 /* Bumped whenever a struct layout or a signature changes (2: fused conv epilogue fields, fp64 nearest-neighbour state). */
-#define IGAN_ABI_VERSION 4
+#define IGAN_ABI_VERSION 5
 
 typedef void* igan_stream_t; /* hipStream_t */
 
@@ -205,6 +205,8 @@ typedef struct igan_conv2d_params {
                              * y = act(y + noise[n, oy, ox] * noise_strength[0] + bias[co]) * act_gain; NULL = no noise */
     const float* noise_strength; /* device scalar */
     int noise_bcast;        /* 1: noise is [1, OH, OW], shared by the batch (the layer's stored noise); 0: [N, OH, OW] */
+    const void* x_pieces;   /* bf16-piece variant only (else NULL / ignored): the piece image of x * in_scale, written by igan_to_pieces(),
+                             * so that a caller who runs several convolutions on one tensor writes its image once */
 } igan_conv2d_params;
 
 int igan_conv2d_plan(const igan_conv2d_params* p, int* splits, int* sliced_tiles, size_t* workspace_floats);
@@ -235,10 +237,18 @@ typedef struct igan_conv2d_wgrad_params {
     int pad_y, pad_x;
     int splits;
     float alpha;            /* dw is multiplied by alpha (see igan_conv2d_params) */
+    const void* x_pieces;   /* bf16-piece variant only (else NULL / ignored): piece images of x * in_scale and dy * out_scale */
+    const void* dy_pieces;
 } igan_conv2d_wgrad_params;
 
 int igan_conv2d_wgrad_plan(const igan_conv2d_wgrad_params* p, int* splits, size_t* workspace_floats);
 int igan_conv2d_wgrad(igan_stream_t stream, const igan_conv2d_wgrad_params* p);
+
+/* bf16-piece variant (IGAN_CONV_PLANES=1; not the default path -- DESIGN.md section 4): the piece image of a channel-minor tensor
+ * x [N, HW, C] (times scale [N, C] when given), `out` = N * HW * C * 6 bytes, 16-byte aligned, C % 16 == 0.  The convolution entry
+ * points write the images they need themselves; a caller that feeds one tensor to several of them (dy to the data and the
+ * weight gradient, x to the forward pass and the weight gradient) writes it once with this and passes it as x_pieces / dy_pieces. */
+int igan_to_pieces(igan_stream_t stream, const float* x, const float* scale, void* out, int N, int HW, int C);
 
 /* ------------------------------------------------------------------------
  * Small-batch dense layers with the StyleGAN2 style-path arithmetic folded in (M <= 64 rows; larger

@@ -2030,7 +2030,7 @@ bool planes_shape_ok(const igan_conv2d_params* p, const FwdTile& t, int Mmax) {
     return true;
 }
 bool use_planes_kernel(const igan_conv2d_params* p, const FwdTile& t, int Mmax) {
-    return planes_shape_ok(p, t, Mmax) && (((uintptr_t)p->x | (uintptr_t)p->w | (uintptr_t)p->in_scale) & 15) == 0;
+    return planes_shape_ok(p, t, Mmax) && (((uintptr_t)p->x | (uintptr_t)p->w | (uintptr_t)p->in_scale | (uintptr_t)p->x_pieces) & 15) == 0;
 }
 size_t planes_x_floats(const igan_conv2d_params* p) { return (size_t)p->N * p->H * p->W * p->Cin * 6 / 4; }
 size_t planes_w_floats(const igan_conv2d_params* p) { return (size_t)p->KH * p->KW * p->Cin * p->Cout * 6 / 4; }
@@ -2223,11 +2223,15 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
     const bool vec = a.vecA && a.vecB && (a.in_scale == nullptr || a.vecS);
     bool launched = false;
     if (planes) {       // bf16-piece form: write the two piece images, then the tile kernel
-        unsigned short* xp = reinterpret_cast<unsigned short*>(p->workspace + partial_floats);
+        const unsigned short* xp = reinterpret_cast<const unsigned short*>(p->x_pieces);
         unsigned short* wp = reinterpret_cast<unsigned short*>(p->workspace + partial_floats + planes_x_floats(p));
         const int cpp = p->Cin / PK;
-        const int total = p->N * p->H * p->W * cpp;
-        hipLaunchKernelGGL(to_planes_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, p->x, p->in_scale, xp, total, cpp, p->Cin, p->H * p->W);
+        if (xp == nullptr) {         // no image from the caller: write it behind the partial tiles
+            unsigned short* own = reinterpret_cast<unsigned short*>(p->workspace + partial_floats);
+            const int total = p->N * p->H * p->W * cpp;
+            hipLaunchKernelGGL(to_planes_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, p->x, p->in_scale, own, total, cpp, p->Cin, p->H * p->W);
+            xp = own;
+        }
         const int wtotal = p->KH * p->KW * p->Cout * cpp;
         if (wt) hipLaunchKernelGGL((filter_planes_kernel<true>), dim3(ceil_div(wtotal, 256)), dim3(256), 0, stream, p->w, wp, p->KH * p->KW, p->KW, p->Cout, p->Cin);
         else hipLaunchKernelGGL((filter_planes_kernel<false>), dim3(ceil_div(wtotal, 256)), dim3(256), 0, stream, p->w, wp, p->KH * p->KW, p->KW, p->Cout, p->Cin);
@@ -2428,14 +2432,22 @@ extern "C" int igan_conv2d_wgrad(igan_stream_t stream_, const igan_conv2d_wgrad_
     dim3 grid(ceil_div(p->Cin, t.BM), ceil_div(p->Cout, t.BN), p->KH * p->KW * splits);
     a.xp = nullptr; a.dyp = nullptr;
     const size_t partial_floats = (splits > 1) ? (size_t)splits * wsize : 0;
-    if (wgrad_planes_shape_ok(p) && p->workspace != nullptr && (((uintptr_t)p->workspace | (uintptr_t)p->x | (uintptr_t)p->dy | (uintptr_t)p->in_scale | (uintptr_t)p->out_scale) & 15) == 0 &&
+    if (wgrad_planes_shape_ok(p) && p->workspace != nullptr && (((uintptr_t)p->workspace | (uintptr_t)p->x | (uintptr_t)p->dy | (uintptr_t)p->in_scale | (uintptr_t)p->out_scale | (uintptr_t)p->x_pieces | (uintptr_t)p->dy_pieces) & 15) == 0 &&
         p->workspace_floats >= partial_floats + wgrad_planes_x_floats(p) + wgrad_planes_dy_floats(p)) {
-        unsigned short* xp = reinterpret_cast<unsigned short*>(p->workspace + partial_floats);
-        unsigned short* dyp = reinterpret_cast<unsigned short*>(p->workspace + partial_floats + wgrad_planes_x_floats(p));
+        const unsigned short* xp = reinterpret_cast<const unsigned short*>(p->x_pieces);
+        const unsigned short* dyp = reinterpret_cast<const unsigned short*>(p->dy_pieces);
         const int cpa = p->Cin / PK, cpb = p->Cout / PK;
         const int ta = p->N * p->H * p->W * cpa, tb = p->N * p->OH * p->OW * cpb;
-        hipLaunchKernelGGL(to_planes_kernel, dim3(ceil_div(ta, 256)), dim3(256), 0, stream, p->x, p->in_scale, xp, ta, cpa, p->Cin, p->H * p->W);
-        hipLaunchKernelGGL(to_planes_kernel, dim3(ceil_div(tb, 256)), dim3(256), 0, stream, p->dy, p->out_scale, dyp, tb, cpb, p->Cout, p->OH * p->OW);
+        if (xp == nullptr) {
+            unsigned short* own = reinterpret_cast<unsigned short*>(p->workspace + partial_floats);
+            hipLaunchKernelGGL(to_planes_kernel, dim3(ceil_div(ta, 256)), dim3(256), 0, stream, p->x, p->in_scale, own, ta, cpa, p->Cin, p->H * p->W);
+            xp = own;
+        }
+        if (dyp == nullptr) {
+            unsigned short* own = reinterpret_cast<unsigned short*>(p->workspace + partial_floats + wgrad_planes_x_floats(p));
+            hipLaunchKernelGGL(to_planes_kernel, dim3(ceil_div(tb, 256)), dim3(256), 0, stream, p->dy, p->out_scale, own, tb, cpb, p->Cout, p->OH * p->OW);
+            dyp = own;
+        }
         a.xp = xp; a.dyp = dyp;
         hipLaunchKernelGGL(conv_wgrad_planes_kernel, grid, dim3(512), 0, stream, a);
         IGAN_LAUNCH_CHECK("conv2d_wgrad (bf16-piece) launch");
@@ -2462,5 +2474,18 @@ extern "C" int igan_conv2d_wgrad(igan_stream_t stream_, const igan_conv2d_wgrad_
         hipLaunchKernelGGL(plain_reduce_kernel, dim3(rg), dim3(256), 0, stream, (const float*)p->workspace, p->dw, total, splits, p->alpha);
         IGAN_LAUNCH_CHECK("conv2d_wgrad reduce launch");
     }
+    return IGAN_OK;
+}
+
+extern "C" int igan_to_pieces(igan_stream_t stream_, const float* x, const float* scale, void* out, int N, int HW, int C) {
+    using namespace igan;
+    IGAN_REQUIRE(x != nullptr && out != nullptr, "to_pieces: null buffer");
+    IGAN_REQUIRE(N >= 1 && HW >= 1 && C >= 16 && C % 16 == 0, "to_pieces: C must be a positive multiple of 16");
+    IGAN_REQUIRE((((uintptr_t)x | (uintptr_t)scale | (uintptr_t)out) & 15) == 0, "to_pieces: buffers must be 16-byte aligned");
+    IGAN_REQUIRE((long long)N * HW * C * 6 < 0x7FFFFF00LL, "to_pieces: image too large (32-bit offsets)");
+    const int cpp = C / PK;
+    const int total = N * HW * cpp;
+    hipLaunchKernelGGL(to_planes_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream_, x, scale, reinterpret_cast<unsigned short*>(out), total, cpp, C, HW);
+    IGAN_LAUNCH_CHECK("to_pieces launch");
     return IGAN_OK;
 }

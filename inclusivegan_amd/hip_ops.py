@@ -513,7 +513,38 @@ def conv_flops(n, h, w, cin, oh, ow, cout, geom):
     return 2.0 * n * pairs * cin * cout
 
 
-def conv2d_raw(x, w, geom, out_hw, cout, w_transposed=False, in_scale=None, out_scale=None, bias=None, act=None, noise=None, strength=None):
+PIECES = os.environ.get('IGAN_CONV_PLANES') == '1' and os.environ.get('IGAN_PIECES_SHARE', '1') != '0'
+# ^ the bf16-piece variant of the large 3x3 convolutions (csrc/conv2d_mfma.hip; off by default) with its piece images shared between the calls of
+#   a layer (IGAN_PIECES_SHARE=0: every convolution call writes its own images, A/B switch)
+
+
+def pieces_wanted(geom, cin, cout):
+    """Will the convolution calls of a layer with this filter take the piece form (so that writing ONE shared image pays)?  The shape
+    rules of csrc/conv2d_mfma.hip (planes_shape_ok / wgrad_planes_shape_ok) that do not depend on the batch: 3x3 taps, both channel
+    counts at least 128 and whole 32s.  (A call the library then runs in fp32 after all simply ignores the image.)"""
+    return PIECES and geom.kh * geom.kw > 1 and cin >= 128 and cout >= 128 and cin % 32 == 0 and cout % 32 == 0
+
+
+def to_pieces(x, scale=None):
+    """Piece image of a channels-last tensor (times scale[n, c]) for the bf16-piece variant: written once when several convolution
+    calls consume the same tensor (dy in the data and the weight gradient, x in the forward pass and the weight gradient).
+    Returns None when the variant is off or the tensor is not of a kind the piece kernels take (they then make their own, or run fp32)."""
+    if not PIECES or _is_meta(x) or x.dim() != 4:
+        return None
+    n, c, h, w = x.shape
+    if c < 128 or c % 32 != 0 or n * h * w < 2048 or n * h * w * c * 6 >= 0x7FFFFF00:
+        return None
+    x = nhwc(x)
+    if scale is not None:
+        scale = scale.contiguous()
+    out = torch.empty((n * h * w * c * 6 // 4,), device=x.device, dtype=torch.float32)
+    if (x.data_ptr() | out.data_ptr() | (scale.data_ptr() if scale is not None else 0)) & 15:
+        return None
+    _abi.check(_abi.get_plugin().igan_to_pieces(_stream(), _ptr(x), (_ptr(scale) if scale is not None else None), _ptr(out), n, h * w, c))
+    return out
+
+
+def conv2d_raw(x, w, geom, out_hw, cout, w_transposed=False, in_scale=None, out_scale=None, bias=None, act=None, noise=None, strength=None, x_pieces=None):
     """x: logical [N,Cin,H,W] (channels_last).  w: HWIO [KH,KW,Cin,Cout] (or the forward layer's
     [KH,KW,Cout,Cin] when w_transposed).  Returns logical [N,Cout,OH,OW] channels_last.
     act = (act_idx, alpha, gain) fuses y = act(y + bias) * gain into the kernel's epilogue (bias may be None)."""
@@ -543,6 +574,8 @@ def conv2d_raw(x, w, geom, out_hw, cout, w_transposed=False, in_scale=None, out_
         w_transposed=1 if w_transposed else 0, splits=1, alpha=float(geom.alpha),
         bias=(bias.data_ptr() if bias is not None else None), act=(int(act[0]) if act is not None else 0),
         act_alpha=(float(act[1]) if act is not None else 0.0), act_gain=(float(act[2]) if act is not None else 1.0))
+    if x_pieces is not None:    # bf16-piece variant: the image of x * in_scale, written once by to_pieces() for several consumers
+        p.x_pieces = x_pieces.data_ptr()
     if noise is not None:       # epilogue noise: [N or 1, 1, OH, OW] contiguous + device scalar strength (needs act)
         noise = noise.contiguous()
         _require_cuda_f32(noise, strength)
@@ -593,7 +626,7 @@ def conv2d_raw(x, w, geom, out_hw, cout, w_transposed=False, in_scale=None, out_
     return y
 
 
-def conv2d_wgrad_raw(x, dy, geom, in_scale=None, out_scale=None):
+def conv2d_wgrad_raw(x, dy, geom, in_scale=None, out_scale=None, x_pieces=None, dy_pieces=None):
     """dw[KH,KW,Cin,Cout] for y = conv(x, w) with geometry `geom`."""
     lib = _abi.get_plugin()
     _require_cuda_f32(x, dy, in_scale, out_scale)
@@ -616,6 +649,10 @@ def conv2d_wgrad_raw(x, dy, geom, in_scale=None, out_scale=None):
         N=n, H=h, W=wd, Cin=cin, OH=oh, OW=ow, Cout=cout,
         KH=geom.kh, KW=geom.kw, stride=geom.stride, up=geom.up,
         pad_y=geom.pad_y, pad_x=geom.pad_x, splits=1, alpha=float(geom.alpha))
+    if x_pieces is not None:
+        p.x_pieces = x_pieces.data_ptr()
+    if dy_pieces is not None:
+        p.dy_pieces = dy_pieces.data_ptr()
     key = (n, h, wd, cin, oh, ow, cout, geom, in_scale is not None, out_scale is not None)
     plan = _wplan_cache.get(key)
     if plan is None:
@@ -721,8 +758,10 @@ class ConvBiasActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, geom, out_hw, act_idx, alpha, gain):
-        y = conv2d_raw(x, w, geom, out_hw, w.shape[3], bias=b, act=(act_idx, alpha, gain))
+        xp = to_pieces(x) if (pieces_wanted(geom, x.shape[1], w.shape[3]) and ctx.needs_input_grad[1]) else None      # variant: one piece image for the forward pass and the weight gradient
+        y = conv2d_raw(x, w, geom, out_hw, w.shape[3], bias=b, act=(act_idx, alpha, gain), x_pieces=xp)
         ctx.save_for_backward(x, w, y)
+        ctx.xp = xp
         ctx.geom, ctx.cfg = geom, (act_idx, alpha, gain)
         ctx.in_hw = (x.shape[2], x.shape[3])
         ctx.has_b = b is not None
@@ -746,10 +785,11 @@ class ConvBiasActFn(torch.autograd.Function):
                 dw = ConvWgradFn.apply(x, dxp, ctx.geom)
             return dx, dw, db, None, None, None, None, None
         dxp, db, _ = bias_act_noise_bwd_raw(dy, y, None, act_idx, alpha, gain, need_b)
+        dyp = to_pieces(dxp) if (pieces_wanted(ctx.geom, x.shape[1], y.shape[1]) and need_x and need_w) else None                # variant: one image of dy for both gradients
         if need_x:
-            dx = conv2d_raw(dxp, w, dgrad_geom(ctx.geom), ctx.in_hw, w.shape[2], w_transposed=True)
+            dx = conv2d_raw(dxp, w, dgrad_geom(ctx.geom), ctx.in_hw, w.shape[2], w_transposed=True, x_pieces=dyp)
         if need_w:
-            dw = conv2d_wgrad_raw(x, dxp, ctx.geom)
+            dw = conv2d_wgrad_raw(x, dxp, ctx.geom, x_pieces=ctx.xp, dy_pieces=dyp)
         return dx, dw, (db if need_b else None), None, None, None, None, None
 
 
@@ -803,8 +843,10 @@ class ModConv2dFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, s, d, geom, out_hw):
-        y = conv2d_raw(x, w, geom, out_hw, w.shape[3], in_scale=s, out_scale=d)
+        xp = to_pieces(x, s) if (pieces_wanted(geom, x.shape[1], w.shape[3]) and ctx.needs_input_grad[1]) else None   # variant: one piece image of x * s for the forward pass and the weight gradient
+        y = conv2d_raw(x, w, geom, out_hw, w.shape[3], in_scale=s, out_scale=d, x_pieces=xp)
         ctx.save_for_backward(x, w, s, d, y)
+        ctx.xp = xp
         ctx.geom = geom
         ctx.out_hw = out_hw
         return y
@@ -843,9 +885,10 @@ class ModConv2dFn(torch.autograd.Function):
             return dx, dw, ds, dd, None, None
         dx = dw = ds = dd = None
         dy = nhwc(dy)
+        dyp = to_pieces(dy, d) if (pieces_wanted(geom, x.shape[1], y.shape[1]) and (need_x or need_s) and need_w) else None  # variant: one image of dy * d for both gradients
         if need_x or need_s:
             # dxs = dgrad(dy * d, w)   (un-modulated input gradient)
-            dxs = conv2d_raw(dy, w, dgrad_geom(geom), in_hw, w.shape[2], w_transposed=True, in_scale=d)
+            dxs = conv2d_raw(dy, w, dgrad_geom(geom), in_hw, w.shape[2], w_transposed=True, in_scale=d, x_pieces=dyp)
             if x.shape[1] % 4 == 0:
                 # one pass: ds = sum_hw x * dxs, and dx = dxs * s written in place over dxs
                 ds, dx = scale_dot_raw(x, dxs, s, want_scaled=need_x)
@@ -857,7 +900,7 @@ class ModConv2dFn(torch.autograd.Function):
                 if need_x:
                     dx = dxs * s[:, :, None, None]
         if need_w:
-            dw = conv2d_wgrad_raw(x, dy, geom, in_scale=s, out_scale=d)
+            dw = conv2d_wgrad_raw(x, dy, geom, in_scale=s, out_scale=d, x_pieces=ctx.xp, dy_pieces=dyp)
         if need_d and d is not None:
             if y.shape[1] % 4 == 0:
                 dd = scale_dot_raw(dy, y)[0] / d
@@ -964,8 +1007,10 @@ class ModConvBanFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, s, d, b, noise, strength, geom, out_hw, act_idx, alpha, gain):
         _mark_inputs(ctx, x, w, s, d, b, noise, strength, geom, out_hw, act_idx, alpha, gain)
-        y = conv2d_raw(x, w, geom, out_hw, w.shape[3], in_scale=s, out_scale=d, bias=b, act=(act_idx, alpha, gain), noise=noise, strength=strength)
+        xp = to_pieces(x, s) if (pieces_wanted(geom, x.shape[1], w.shape[3]) and ctx.needs_input_grad[1]) else None   # variant: as ModConv2dFn
+        y = conv2d_raw(x, w, geom, out_hw, w.shape[3], in_scale=s, out_scale=d, bias=b, act=(act_idx, alpha, gain), noise=noise, strength=strength, x_pieces=xp)
         ctx.save_for_backward(x, w, s, d, b, noise, strength, y)
+        ctx.xp = xp
         ctx.geom, ctx.out_hw, ctx.cfg = geom, out_hw, (act_idx, alpha, gain)
         return y
 
@@ -981,13 +1026,14 @@ class ModConvBanFn(torch.autograd.Function):
         dxp, db, dst, dd = bias_act_noise_bwd_dd_raw(dy, y, noise, strength, b, d, act_idx, alpha, gain)
         dx = dw = ds = None
         in_hw = (x.shape[2], x.shape[3])
+        dyp = to_pieces(dxp, d) if (pieces_wanted(geom, x.shape[1], y.shape[1]) and (need_x or need_s) and need_w) else None
         if need_x or need_s:
-            dxs = conv2d_raw(dxp, w, dgrad_geom(geom), in_hw, w.shape[2], w_transposed=True, in_scale=d)
+            dxs = conv2d_raw(dxp, w, dgrad_geom(geom), in_hw, w.shape[2], w_transposed=True, in_scale=d, x_pieces=dyp)
             ds, dx = scale_dot_raw(x, dxs, s, want_scaled=need_x)
             if not need_s:
                 ds = None
         if need_w:
-            dw = conv2d_wgrad_raw(x, dxp, geom, in_scale=s, out_scale=d)
+            dw = conv2d_wgrad_raw(x, dxp, geom, in_scale=s, out_scale=d, x_pieces=ctx.xp, dy_pieces=dyp)
         return dx, dw, ds, (dd if need_d else None), (db if need_b else None), None, (dst if need_st else None), None, None, None, None, None
 
 
