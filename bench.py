@@ -296,7 +296,10 @@ def variant_line(args, timeout_s=900):
     never `value`).  A child process, because the switch is read once per process; small data set: its refresh is not the subject."""
     import subprocess
     env = dict(os.environ, IGAN_CONV_PLANES='1')
-    cmd = [sys.executable, os.path.abspath(__file__), '--steps', str(args.steps), '--warmup', str(args.warmup), '--data-size', '1152',
+    # at least 200 timed iterations after 40 of warm-up: the variant's short-window rate swings with the thermal state the headline run left
+    # behind (219-282 img/s over 32 iterations on the same code; 254 +- 0.3 over 800) -- the labelled line should be the sustained figure
+    steps, warmup = max(args.steps, 200), max(args.warmup, 40)
+    cmd = [sys.executable, os.path.abspath(__file__), '--steps', str(steps), '--warmup', str(warmup), '--data-size', '1152',
            '--minibatch-gpu', str(args.minibatch_gpu), '--resolution', str(args.resolution), '--lpips-weight', str(args.lpips_weight),
            '--no-cpu-baseline', '--no-variant-line']
     try:
@@ -306,7 +309,7 @@ def variant_line(args, timeout_s=900):
         return {'label': 'bf16-piece convolutions (IGAN_CONV_PLANES=1)', 'error': repr(e)[:200]}
     roof = d.get('roofline', {})
     return {'label': 'VARIANT, not the product path: 3x3 convolutions (forward, data gradient, weight gradient) as 3 bf16 pieces x 6 products with fp32 sums (IGAN_CONV_PLANES=1); '
-                     'everything else as in the headline', 'value': d['value'], 'unit': d['unit'], 'ms_per_step': d['ms_per_step'],
+                     'everything else as in the headline', 'value': d['value'], 'unit': d['unit'], 'ms_per_step': d['ms_per_step'], 'steps': d['steps'], 'warmup': d['warmup'],
             'data_size': 1152, 'hip_graphs': d.get('hip_graphs'), 'dominant_kernel': roof.get('kernel'), 'dominant_kernel_fp32_equivalent_tflops': roof.get('achieved'),
             'conv_family_fp32_equivalent_tflops': roof.get('conv_family_tflops')}
 
