@@ -128,3 +128,51 @@ def test_bf16_piece_variant_against_fp64(cuda_device):
     r = subprocess.run([sys.executable, '-c', CHILD % ROOT], env=env, capture_output=True, text=True, timeout=600)
     sys.stdout.write(r.stdout[-3000:])
     assert r.returncode == 0 and 'PLANES-VARIANT-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+SHARE_CHILD = r'''
+import hashlib, sys
+import torch
+sys.path.insert(0, %r)
+from inclusivegan_amd import hip_ops
+dev = torch.device('cuda', 0)
+g = torch.Generator().manual_seed(11)
+def dig(*ts):
+    h = hashlib.sha1()
+    for t in ts:
+        h.update(t.detach().float().cpu().contiguous().numpy().tobytes())
+    return h.hexdigest()
+out = []
+geom = hip_ops.ConvGeom(3, 3, 1, 1, 1, 1)
+# modulated layer (ModConv2dFn), fused synthesis layer (ModConvBanFn) and plain layer with epilogue (ConvBiasActFn): forward + first-order backward
+x = torch.randn(4, 256, 32, 32, generator=g).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+w = (torch.randn(3, 3, 256, 256, generator=g) / 48.0).to(dev).requires_grad_(True)
+s = (torch.rand(4, 256, generator=g) + 0.5).to(dev).requires_grad_(True)
+d = (torch.rand(4, 256, generator=g) + 0.5).to(dev).requires_grad_(True)
+dy = torch.randn(4, 256, 32, 32, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+y = hip_ops.ModConv2dFn.apply(x, w, s, d, geom, (32, 32))
+gx, gw, gs, gd = torch.autograd.grad(y, [x, w, s, d], dy)
+out.append(dig(y, gx, gw, gs, gd))
+b = torch.randn(256, generator=g).to(dev).requires_grad_(True)
+y = hip_ops.ConvBiasActFn.apply(x, w, b, geom, (32, 32), 3, 0.2, 2 ** 0.5)
+gx, gw, gb = torch.autograd.grad(y, [x, w, b], dy)
+out.append(dig(y, gx, gw, gb))
+noise = torch.randn(1, 1, 32, 32, generator=g).to(dev)
+strength = torch.tensor(0.3, device=dev, requires_grad=True)
+y = hip_ops.ModConvBanFn.apply(x, w, s, d, b, noise, strength, geom, (32, 32), 3, 0.2, 2 ** 0.5)
+gx, gw, gs, gd, gb = torch.autograd.grad(y, [x, w, s, d, b], dy)
+out.append(dig(y, gx, gw, gs, gd, gb))
+print('DIGESTS ' + ' '.join(out))
+'''
+
+
+def test_shared_piece_images_change_nothing(cuda_device):
+    """The piece images written once per layer (hip_ops.to_pieces -> x_pieces / dy_pieces, ABI v5) against every convolution call
+    writing its own (IGAN_PIECES_SHARE=0): the same arithmetic on the same images, so outputs and all gradients are bit-identical."""
+    digs = []
+    for share in ('1', '0'):
+        env = dict(os.environ, IGAN_CONV_PLANES='1', IGAN_PIECES_SHARE=share)
+        r = subprocess.run([sys.executable, '-c', SHARE_CHILD % ROOT], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        digs.append([l for l in r.stdout.splitlines() if l.startswith('DIGESTS ')][-1])
+    assert digs[0] == digs[1], digs
