@@ -64,9 +64,31 @@ def process_reals(x, labels, lod, mirror_augment, drange_data, drange_net):
     if mirror_augment:
         flip = tfutil.random_uniform([x.shape[0]], x.device) >= 0.5
         x = torch.where(flip[:, None, None, None], x.flip(3), x)
-    # FadeLOD / UpscaleLOD are the identity at lod == 0, the only value config-e produces (:93-94).
-    assert lod == 0
+    lod = float(lod)
+    if lod != 0:
+        # FadeLOD (:50-57): cross-fade towards the 2x2 box-filtered image by the fractional part; UpscaleLOD (:58-59): nearest-neighbour
+        # upscale by 2^floor(lod).  Both are the identity at lod == 0, the only value config-e/f produce (:93-94), so this is torch glue.
+        n, c, h, w = x.shape
+        y = x.reshape(n, c, h // 2, 2, w // 2, 2).mean(dim=(3, 5), keepdim=True).expand(n, c, h // 2, 2, w // 2, 2).reshape(n, c, h, w)
+        x = tfutil.lerp(x, y, lod - np.floor(lod))
+        factor = int(2 ** np.floor(lod))
+        if factor != 1:
+            x = x.reshape(n, c, h, 1, w, 1).expand(n, c, h, factor, w, factor).reshape(n, c, h * factor, w * factor)
     return x.contiguous(memory_format=torch.channels_last), labels
+
+def lazy_regularization_args(opt_args, reg_interval, lazy_regularization):
+    """:244-251: with lazy regularisation the main and the regularisation optimizer of a network both run with the learning rate
+    times mb_ratio = interval / (interval + 1) and with beta1, beta2 raised to that power.  -> (learning-rate ratio, adjusted args)."""
+    args = dict(opt_args)
+    mb_ratio = reg_interval / (reg_interval + 1) if lazy_regularization else 1.0
+    if lazy_regularization:
+        if 'beta1' in args: args['beta1'] **= mb_ratio
+        if 'beta2' in args: args['beta2'] **= mb_ratio
+    return mb_ratio, args
+
+def smoothing_beta(minibatch_size, G_smoothing_kimg):
+    """:222: Gs_beta = 0.5 ** (minibatch_size / (G_smoothing_kimg * 1000)), 0 when the smoothing is switched off."""
+    return 0.5 ** (minibatch_size / (G_smoothing_kimg * 1000.0)) if G_smoothing_kimg > 0.0 else 0.0
 
 #----------------------------------------------------------------------------
 # Evaluate time-varying training parameters (:65-118).
@@ -377,15 +399,9 @@ def training_loop(
 
     # Setup optimizers (:242-255).
     cur_lrate = [sched.G_lrate]
-    G_opt_args = dict(G_opt_args)
-    D_opt_args = dict(D_opt_args)
     ratios = {}
-    for key, args, reg_interval in [('G', G_opt_args, G_reg_interval), ('D', D_opt_args, D_reg_interval)]:
-        mb_ratio = reg_interval / (reg_interval + 1) if lazy_regularization else 1.0
-        ratios[key] = mb_ratio
-        if lazy_regularization:
-            if 'beta1' in args: args['beta1'] **= mb_ratio
-            if 'beta2' in args: args['beta2'] **= mb_ratio
+    ratios['G'], G_opt_args = lazy_regularization_args(G_opt_args, G_reg_interval, lazy_regularization)
+    ratios['D'], D_opt_args = lazy_regularization_args(D_opt_args, D_reg_interval, lazy_regularization)
     G_lr = lambda: cur_lrate[0] * ratios['G']
     D_lr = lambda: cur_lrate[0] * ratios['D']      # both optimizers are fed sched.G_lrate (:218,246,347)
     G_opt = tflib.Optimizer(name='TrainG', learning_rate=G_lr, **G_opt_args)
@@ -398,7 +414,7 @@ def training_loop(
     D_loss_fn = dnnlib.util.get_obj_by_name(_retarget(D_loss_args.pop('func_name')))
 
     minibatch_size_holder = [sched.minibatch_size]
-    Gs_beta = (lambda: 0.5 ** (minibatch_size_holder[0] / (G_smoothing_kimg * 1000.0))) if G_smoothing_kimg > 0.0 else 0.0  # :222
+    Gs_beta = lambda: smoothing_beta(minibatch_size_holder[0], G_smoothing_kimg)      # :222
     Gs_update_op = Gs.setup_as_moving_average_of(G, beta=Gs_beta)
 
     # ---- the four training ops (:278-297) ------------------------------------------

@@ -27,7 +27,9 @@ def G_loss(G_params, D_params, lpips_params, cfg, rand, minibatch_size, reals_re
         if 'dlatent_avg' in state:
             p['dlatent_avg'] = state['dlatent_avg']
         return N.G_main(p, z, rand, cfg['resolution'], num_channels=cfg['num_channels'], fmap_base=cfg['fmap_base'],
-                        architecture=cfg['G_arch'], is_training=True, state=state, fused_modconv=cfg.get('fused_modconv', True), **kw)
+                        architecture=cfg['G_arch'], is_training=True, state=state, fused_modconv=cfg.get('fused_modconv', True),
+                        **cfg.get('G_kwargs', {}), **kw)
+    latent_size = int(latents_rec_1.shape[1])        # G.input_shapes[0][1:] (:46,59); 512 in every BASELINE config
     def D(img):
         return N.D_stylegan2_feature(D_params, img, cfg['resolution'], num_channels=cfg['num_channels'], fmap_base=cfg['fmap_base'],
                                      architecture=cfg['D_arch'])
@@ -47,14 +49,14 @@ def G_loss(G_params, D_params, lpips_params, cfg, rand, minibatch_size, reals_re
             terms['loss_NN_rec_lpips'] = l_rec
             terms['loss_NN_interp_lpips'] = l_int
             loss = l_rec + l_int
-        z = rand.normal([minibatch_size, 512]).to(dt)                                    # :46
+        z = rand.normal([minibatch_size, latent_size]).to(dt)                            # :46
         scores, _ = D(G(z))                                                              # :48-49
         l_adv = F.softplus(-scores)                                                      # :50
         terms['loss_G_arb'] = l_adv
         loss = l_adv if loss is None else loss + l_adv
     if phase in ('both', 'reg'):
         pl_minibatch = minibatch_size // pl_minibatch_shrink                             # :58
-        z = rand.normal([pl_minibatch, 512]).to(dt)                                      # :59
+        z = rand.normal([pl_minibatch, latent_size]).to(dt)                              # :59
         imgs, dl = G(z, return_dlatents=True)                                            # :61
         noise = rand.normal(list(imgs.shape)).to(dt) / np.sqrt(np.prod(imgs.shape[2:]))  # :64
         g = torch.autograd.grad(torch.sum(imgs * noise), [dl], create_graph=True)[0]     # :65
@@ -78,13 +80,14 @@ def D_loss(G_params, D_params, cfg, rand, minibatch_size, reals, gamma=10.0, pha
     if phase in ('both', 'reg'):
         reals = reals.detach().requires_grad_(True)
     if phase in ('both', 'loss'):
-        z = rand.normal([minibatch_size * 2, 512]).to(dt)                                # :98
+        z = rand.normal([minibatch_size * 2, cfg.get('latent_size', 512)]).to(dt)        # :98
         p = dict(G_params)
         if 'dlatent_avg' in state:
             p['dlatent_avg'] = state['dlatent_avg']
         with torch.no_grad():
             fakes = N.G_main(p, z, rand, cfg['resolution'], num_channels=cfg['num_channels'], fmap_base=cfg['fmap_base'],
-                             architecture=cfg['G_arch'], is_training=True, state=state, fused_modconv=cfg.get('fused_modconv', True))
+                             architecture=cfg['G_arch'], is_training=True, state=state, fused_modconv=cfg.get('fused_modconv', True),
+                             **cfg.get('G_kwargs', {}))
         fake_scores, _ = D(fakes)                                                        # :101
         real_scores, _ = D(reals)                                                        # :102
         loss = F.softplus(fake_scores) + F.softplus(-real_scores)                        # :103

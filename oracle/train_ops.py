@@ -22,6 +22,7 @@ import torch
 
 from . import loss as OL
 from . import optimizer as OO
+from . import training_loop as OT
 from .misc import adjust_dynamic_range, Tape
 
 
@@ -47,9 +48,9 @@ class TrainOps:
         self.interval = dict(G=G_reg_interval, D=D_reg_interval)
         self.adam = {}
         for key in ('G', 'D'):
-            c = self.interval[key] / (self.interval[key] + 1) if lazy_regularization else 1.0      # :247-251
-            self.adam[key] = OO.SimpleAdam(self.w[key].size, lrate * c, beta1 ** c, beta2 ** c, epsilon)
-        self.Gs_beta = 0.5 ** (minibatch_gpu * world / (G_smoothing_kimg * 1000.0))                 # :222
+            lr, b1, b2 = OT.lazy_regularization_args(lrate, beta1, beta2, self.interval[key], lazy_regularization)      # :247-251
+            self.adam[key] = OO.SimpleAdam(self.w[key].size, lr, b1, b2, epsilon)
+        self.Gs_beta = OT.smoothing_beta(minibatch_gpu * world, G_smoothing_kimg)                   # :222
         self.drange = (list(drange_data), list(drange_net))
         # per-tower state (:70 pl_mean under the tower's scope; dlatent_avg of the tower's own G)
         avg0 = self.fixed['G']['dlatent_avg']

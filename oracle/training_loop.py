@@ -134,11 +134,46 @@ def imle_host_loop(training_set, training_set_rec, latent_shape, generate, make_
 def process_reals(x, labels, lod, mirror_augment, drange_data, drange_net, coin=None):
     """training_loop.py:40-60 in NumPy: cast to float32 (:42), dynamic range (:43-44), random mirror (:45-49: a per-image uniform
     draw `coin` < 0.5 keeps the image, otherwise it is reversed along W -- tf.where(coin < 0.5, x, reverse(x, [3]))), then the
-    level-of-detail fade (:50-57) and upscale (:58-59), which are the identity at lod = 0 -- the only value configs e/f produce."""
+    level-of-detail fade (:50-57: lerp towards the 2x2 box-filtered image by frac(lod)) and upscale (:58-59: every pixel repeated
+    2^floor(lod) times along H and W), which are the identity at lod = 0 -- the only value configs e/f produce.
+    PINNED: tests/golden/ref_train_golden.npz `preals_*` (the reference's own function executed under np_tf)."""
     x = np.asarray(x).astype(np.float32)
     x = adjust_dynamic_range(x, list(drange_data), list(drange_net))
     if mirror_augment:
         coin = np.asarray(coin, np.float32).reshape(-1, 1, 1, 1)
         x = np.where(coin < 0.5, x, x[:, :, :, ::-1])
-    assert lod == 0
+    n, c, h, w = x.shape
+    y = x.reshape(n, c, h // 2, 2, w // 2, 2).mean(axis=(3, 5), keepdims=True)                     # :52-53
+    y = np.tile(y, [1, 1, 1, 2, 1, 2]).reshape(n, c, h, w)                                        # :54-55
+    x = x + (y - x) * np.float32(lod - np.floor(lod))                                             # :56
+    factor = int(2 ** np.floor(lod))                                                              # :59
+    x = np.tile(x.reshape(n, c, h, 1, w, 1), [1, 1, 1, factor, 1, factor]).reshape(n, c, h * factor, w * factor)   # :60-62
     return x, labels
+
+
+def lazy_regularization_args(lrate, beta1, beta2, reg_interval, lazy_regularization):
+    """:244-251 -> (learning rate, beta1, beta2) the main AND the regularisation optimizer of a network run with.
+    PINNED: `setup_*` of ref_train_golden.npz."""
+    if not lazy_regularization:
+        return lrate, beta1, beta2
+    mb_ratio = reg_interval / (reg_interval + 1)
+    return lrate * mb_ratio, beta1 ** mb_ratio, beta2 ** mb_ratio
+
+
+def smoothing_beta(minibatch_size, G_smoothing_kimg):
+    """:222.  PINNED: `gs_beta` of ref_train_golden.npz."""
+    return 0.5 ** (minibatch_size / (G_smoothing_kimg * 1000.0)) if G_smoothing_kimg > 0.0 else 0.0
+
+
+def registered_objectives(G_loss, G_reg, D_loss, D_reg, G_reg_interval, D_reg_interval, lazy_regularization):
+    """:283-291 -> the scalars each optimizer differentiates: {'TrainG': [...], 'RegG': [...], 'TrainD': [...], 'RegD': [...]}."""
+    out = dict(TrainG=[], RegG=[], TrainD=[], RegD=[])
+    if not lazy_regularization:
+        G_loss = G_loss + G_reg
+        D_loss = D_loss + D_reg
+    else:
+        out['RegG'].append(np.mean(G_reg * G_reg_interval))
+        out['RegD'].append(np.mean(D_reg * D_reg_interval))
+    out['TrainG'].append(np.mean(G_loss))
+    out['TrainD'].append(np.mean(D_loss))
+    return out

@@ -15,6 +15,19 @@ runs unchanged.  The primitives themselves are restated here from TensorFlow's d
     tf.random_normal / random_uniform     the next entry of an injected tape (TF's Philox streams cannot be reproduced)
     tf.get_variable         looked up by '<variable scopes>/<name>' in an injected dict (the reference's own variable names)
 
+Round 4 adds what the TRAINING statements call (training/loss.py, training_loop.process_reals, dnnlib/tflib/optimizer.py,
+Network.setup_as_moving_average_of; driven by tests/golden/make_ref_train_golden.py):
+
+    tf.Variable             a mutable Tensor; under `variable_replay(store)` the k-th creation of a run returns the k-th
+                            variable of `store` (so re-running graph-BUILDING code once per step acts on persistent state:
+                            every read of a variable in those files precedes its assign through a data dependency, so the
+                            eager order is the order a session.run would produce)
+    tf.assign / assign_sub / Variable.assign    in-place update of the variable's value
+    tf.gradients            cannot be executed: answered by an injected hook `session(..., grad_hook=f)`; f(ys, xs) -> list
+    tf.where                TF1 semantics: a rank-1 condition selects whole rows of higher-rank operands
+    tf.cond / group / no_op / stack / add_n / reduce_all / is_finite / zeros / zeros_like / floor / reverse / split / div
+    tf.device               recorded on the tensors created inside (Optimizer keys its per-device state on it)
+
 All arithmetic is float64 (dtype labels are kept and compared, values are never rounded to float32), so a restatement that
 follows the same formulas agrees to ~1e-13.  TEST INFRASTRUCTURE ONLY -- never imported by the package."""
 import contextlib
@@ -138,6 +151,7 @@ class Tensor:
         self.dtype = as_dtype(dtype)
         self.v = v.astype(np.float64) if self.dtype.is_floating else v
         self.name = 'tensor'
+        self.device = STATE.device if 'STATE' in globals() else ''
 
     @property
     def shape(self):
@@ -162,7 +176,23 @@ class Tensor:
     __lt__ = lambda s, o: s._bin(o, np.less);            __le__ = lambda s, o: s._bin(o, np.less_equal)
     __gt__ = lambda s, o: s._bin(o, np.greater);         __ge__ = lambda s, o: s._bin(o, np.greater_equal)
     __neg__ = lambda s: Tensor(-s.v, s.dtype)
-    __pow__ = lambda s, o: s._bin(o, np.power)
+    __pow__ = lambda s, o: s._bin(o, np.power);          __rpow__ = lambda s, o: s._bin(o, np.power, True)
+    __floordiv__ = lambda s, o: s._bin(o, np.floor_divide); __rfloordiv__ = lambda s, o: s._bin(o, np.floor_divide, True)
+    __mod__ = lambda s, o: s._bin(o, np.mod)
+
+    def __int__(self):
+        return int(self.v)
+
+    __index__ = __int__
+
+    def __float__(self):
+        return float(self.v)
+
+    def __hash__(self):
+        return id(self)
+
+    def __eq__(self, o):          # identity, like TF1 tensors (they are dictionary keys in Optimizer)
+        return self is o
 
     def __getitem__(self, idx):
         return Tensor(self.v[idx], self.dtype)
@@ -175,7 +205,34 @@ class Tensor:
 
 
 class Variable(Tensor):
-    pass
+    """tf.Variable(initial_value, trainable, name, dtype).  Under `variable_replay` creation returns persistent objects."""
+
+    def __new__(cls, initial_value=None, *a, **k):
+        st = globals().get('STATE')
+        if st is not None and st.var_store is not None:
+            if st.var_cursor < len(st.var_store):
+                v = st.var_store[st.var_cursor]
+                st.var_cursor += 1
+                return v
+            v = super().__new__(cls)
+            st.var_store.append(v)
+            st.var_cursor += 1
+            return v
+        return super().__new__(cls)
+
+    def __init__(self, initial_value=None, dtype=None, name=None, trainable=True, **_kw):
+        if getattr(self, '_made', False):
+            return                    # replayed: keep the current value
+        if isinstance(dtype, bool):   # positional (initial_value, trainable) is never used by the reference; guard anyway
+            trainable, dtype = dtype, None
+        Tensor.__init__(self, _val(initial_value), dtype if dtype is not None else (initial_value.dtype if isinstance(initial_value, Tensor) else None))
+        self.name = name or 'Variable'
+        self.trainable = trainable
+        self.initializer = ('init', self)
+        self._made = True
+
+    def assign(self, value):
+        return assign(self, value)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -188,19 +245,44 @@ class State:
         self.tape = None            # object with .normal(shape) / .uniform(shape) / .randint(lo, hi) returning arrays
         self.assigned = {}
         self.created = []
+        self.device = ''
+        self.var_store = None       # list of Variables when replaying (see Variable.__new__)
+        self.var_cursor = 0
+        self.grad_hook = None
 
 STATE = State()
 
 
 @contextlib.contextmanager
-def session(params, tape=None):
-    """Run reference code against `params` (full variable name -> array) and `tape` (random draws, in call order)."""
-    old = (STATE.params, STATE.tape, STATE.scopes, STATE.assigned, STATE.created)
-    STATE.params, STATE.tape, STATE.scopes, STATE.assigned, STATE.created = dict(params), tape, [], {}, []
+def session(params, tape=None, grad_hook=None):
+    """Run reference code against `params` (full variable name -> array), `tape` (random draws, in call order) and
+    `grad_hook` (the answer to tf.gradients)."""
+    old = (STATE.params, STATE.tape, STATE.scopes, STATE.assigned, STATE.created, STATE.grad_hook)
+    STATE.params, STATE.tape, STATE.scopes, STATE.assigned, STATE.created, STATE.grad_hook = dict(params), tape, [], {}, [], grad_hook
     try:
         yield STATE
     finally:
-        STATE.params, STATE.tape, STATE.scopes, STATE.assigned, STATE.created = old
+        STATE.params, STATE.tape, STATE.scopes, STATE.assigned, STATE.created, STATE.grad_hook = old
+
+
+@contextlib.contextmanager
+def variable_replay(store):
+    """Inside, the k-th `tf.Variable(...)` creation returns store[k] (created and appended on first use)."""
+    old = (STATE.var_store, STATE.var_cursor)
+    STATE.var_store, STATE.var_cursor = store, 0
+    try:
+        yield store
+    finally:
+        STATE.var_store, STATE.var_cursor = old
+
+
+@contextlib.contextmanager
+def device(name):
+    old, STATE.device = STATE.device, (name or '')
+    try:
+        yield
+    finally:
+        STATE.device = old
 
 
 @contextlib.contextmanager
@@ -240,7 +322,11 @@ def get_variable(name, shape=None, initializer=None, trainable=True, dtype=None,
     STATE.created.append(full)
     if full not in STATE.params:
         raise KeyError('np_tf.get_variable: no value injected for %r' % full)
-    v = Variable(np.asarray(STATE.params[full]), float32)
+    saved, STATE.var_store = STATE.var_store, None       # a named variable is looked up, never replayed by creation order
+    try:
+        v = Variable(np.asarray(STATE.params[full]), float32)
+    finally:
+        STATE.var_store = saved
     v.name = full
     if shape is not None:
         assert list(v.v.shape) == _ints(shape), (full, v.v.shape, _ints(shape))
@@ -248,9 +334,27 @@ def get_variable(name, shape=None, initializer=None, trainable=True, dtype=None,
 
 
 def assign(var, value):
-    STATE.assigned[var.name] = np.array(_val(value), dtype=np.float64)
-    STATE.params[var.name] = STATE.assigned[var.name]
-    return Tensor(STATE.assigned[var.name], var.dtype)
+    new = np.array(_val(value), dtype=np.float64 if var.dtype.is_floating else None)
+    assert new.shape == var.v.shape, (var.name, new.shape, var.v.shape)
+    var.v = new
+    STATE.assigned[var.name] = new
+    if var.name in STATE.params:
+        STATE.params[var.name] = new
+    return Tensor(new, var.dtype)
+
+
+def assign_sub(var, value):
+    return assign(var, var.v - np.asarray(_val(value)))
+
+
+def assign_add(var, value):
+    return assign(var, var.v + np.asarray(_val(value)))
+
+
+def gradients(ys, xs, *a, **k):
+    assert STATE.grad_hook is not None, 'np_tf.gradients: tf.gradients cannot be executed; inject session(grad_hook=...)'
+    out = STATE.grad_hook(ys, xs)
+    return [g if g is None or isinstance(g, Tensor) else Tensor(g, float32) for g in out]
 
 
 class initializers:
@@ -329,11 +433,96 @@ def broadcast_to(x, shp):
 
 
 def where(cond, a, b):
-    return Tensor(np.where(_val(cond), _val(a), _val(b)), a.dtype if isinstance(a, Tensor) else float32)
+    c, av, bv = np.asarray(_val(cond)), np.asarray(_val(a)), np.asarray(_val(b))
+    if c.ndim == 1 and av.ndim > 1:       # TF1: a vector condition picks rows
+        assert c.shape[0] == av.shape[0]
+        c = c.reshape((-1,) + (1,) * (av.ndim - 1))
+    else:
+        assert c.shape == av.shape or c.ndim == 0, (c.shape, av.shape)
+    return Tensor(np.where(c, av, bv), a.dtype if isinstance(a, Tensor) else (b.dtype if isinstance(b, Tensor) else None))
 
 
 def cond(pred, true_fn, false_fn):
     return true_fn() if bool(_val(pred)) else false_fn()
+
+
+class Operation:
+    def __init__(self, parts=()):
+        self.parts = list(parts)
+        self.device = STATE.device
+
+
+def group(*ops, name=None):
+    return Operation(ops)
+
+
+def no_op(name=None):
+    return Operation()
+
+
+def stack(values, axis=0):
+    return Tensor(np.stack([np.asarray(_val(v)) for v in values], axis=axis))
+
+
+def add_n(values):
+    out = np.asarray(_val(values[0])).copy()
+    for v in values[1:]:
+        out = out + np.asarray(_val(v))
+    return Tensor(out, values[0].dtype)
+
+
+def zeros(shape, dtype=None, **_kw):
+    shp = shape.as_list() if isinstance(shape, TensorShape) else _ints(shape)
+    return Tensor(np.zeros(shp), dtype if dtype is not None else float32)
+
+
+def zeros_like(x, **_kw):
+    return Tensor(np.zeros_like(np.asarray(_val(x))), x.dtype if isinstance(x, Tensor) else None)
+
+
+def is_finite(x):
+    return Tensor(np.isfinite(np.asarray(_val(x))))
+
+
+def reduce_all(x, axis=None, **_kw):
+    return Tensor(np.all(np.asarray(_val(x)), axis=axis))
+
+
+def floor(x):
+    return Tensor(np.floor(np.asarray(_val(x), dtype=np.float64)), x.dtype if isinstance(x, Tensor) else float32)
+
+
+def reverse(x, axis):
+    return Tensor(np.flip(_val(x), axis=tuple(_ints(axis))), x.dtype)
+
+
+def split(x, num, axis=0):
+    return [Tensor(p, x.dtype) for p in np.split(_val(x), int(_val(num)), axis=axis)]
+
+
+def div(a, b):
+    return Tensor(np.asarray(_val(a)) / np.asarray(_val(b)), a.dtype if isinstance(a, Tensor) else float32)
+
+
+class _Graph:
+    def __init__(self):
+        self.names = {}
+
+    def unique_name(self, name):
+        n = self.names.get(name, 0)
+        self.names[name] = n + 1
+        return name if n == 0 else '%s_%d' % (name, n)
+
+
+_GRAPH = _Graph()
+
+
+def get_default_graph():
+    return _GRAPH
+
+
+def get_default_session():
+    return _GRAPH           # anything that is not None: "a session exists" (tfutil.assert_tf_initialized)
 
 
 def minimum(a, b):
@@ -488,7 +677,7 @@ class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
             for k in dir(me):
                 if not k.startswith('_') and k not in ('sys', 'types', 'np', 'contextlib', 'importlib'):
                     setattr(m, k, getattr(me, k))
-            m.Tensor, m.Variable, m.Operation, m.Dimension, m.VariableScope = Tensor, Variable, type('Operation', (), {}), Dimension, VariableScope
+            m.Tensor, m.Variable, m.Operation, m.Dimension, m.VariableScope = Tensor, Variable, Operation, Dimension, VariableScope
             return m
         return _Hollow(spec.name)
 

@@ -159,3 +159,159 @@ def test_fused_bias_act_half_instantiation(cuda_device):
     assert float((bg.grad.double().cpu() - want_db).abs().max()) <= 2e-2 * float(want_db.abs().max())
     with pytest.raises(TypeError):
         hip_ops.fused_bias_act_raw(x.to(cuda_device), b.float().to(cuda_device), None, 0, 3, 0.2, 1.0, 8, 25)      # mixed types
+
+
+# ---- round 4: the training-side statements (tests/golden/make_ref_train_golden.py -> ref_train_golden.npz) ----------------------
+# training/loss.py, training_loop.process_reals, dnnlib/tflib/optimizer.py (Optimizer + SimpleAdam) and
+# Network.setup_as_moving_average_of EXECUTED by the reference; here the HIP path (product functions) meets the same vectors.
+
+TG = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'ref_train_golden.npz'), allow_pickle=False)
+
+
+def _tg_tape(prefix):
+    kinds = [str(k) for k in TG[prefix + 'tape_kinds']]
+    return [(k, TG['%stape_%03d' % (prefix, i)]) for i, k in enumerate(kinds)]
+
+
+def _loss_networks(dev):
+    from inclusivegan_amd.dnnlib import tflib
+    from tests.util import lpips_params_from_seed
+    res, fmap, B, latent, dlatent, mfmaps, seed = [int(v) for v in TG['loss_cfg']]
+    kw = dict(num_channels=3, resolution=res, label_size=0, fmap_base=fmap, device=dev, seed=1)
+    Gn = tflib.Network('G', func_name='inclusivegan_amd.training.networks_stylegan2.G_main', architecture='skip', latent_size=latent, dlatent_size=dlatent, mapping_fmaps=mfmaps, **kw)
+    Dn = tflib.Network('D', func_name='inclusivegan_amd.training.networks_stylegan2.D_stylegan2_feature', architecture='resnet', **kw)
+    Ln = tflib.Network('lpips', func_name='inclusivegan_amd.metrics.lpips.vgg16_zhang_perceptual', resolution=res, device=dev, seed=1)
+    lp = lpips_params_from_seed(seed)
+    with torch.no_grad():
+        for net, src in ((Gn, lambda n: TG['loss_Gparam.' + n.replace('/', '.')]), (Dn, lambda n: TG['loss_Dparam.' + n.replace('/', '.')]), (Ln, lambda n: lp[n])):
+            for name, v in net.vars.items():
+                v.copy_(dev32(src(name), dev).reshape(v.shape))
+    return Gn, Dn, Ln, res, B
+
+
+@pytest.mark.parametrize('w', [2.5, 0.0], ids=['weight_2.5', 'weight_0'])
+def test_generator_loss_against_reference_execution(cuda_device, w):
+    """G_logistic_ns_rec_interp_arb_pathreg on the HIP path vs the values the reference's own loss.py produced on the same weights, inputs and
+    draws: main term (rec + interp LPIPS + adversarial) and the path-length regulariser with its pl_mean update."""
+    from inclusivegan_amd.dnnlib.tflib import tfutil
+    from inclusivegan_amd.training import loss as PL
+    from inclusivegan_amd.training.dataset import SyntheticDataset
+    from tests.util import gloss_tape_in_product_order
+    Gn, Dn, Ln, res, B = _loss_networks(cuda_device)
+    ts = SyntheticDataset(resolution=res, label_size=0, data_size=24, device=cuda_device)
+    cl = lambda a: dev32(a, cuda_device).contiguous(memory_format=torch.channels_last)
+    lab = torch.zeros(B, 0, device=cuda_device)
+    p = 'Gloss_w%d_' % int(w * 10)
+    args = (Gn, Dn, Ln, ts, B, cl(TG['loss_reals_rec_1']), lab, dev32(TG['loss_latents_rec_1'], cuda_device), cl(TG['loss_reals_rec_2']), lab, dev32(TG['loss_latents_rec_2'], cuda_device))
+    tape = tfutil.RandomTape(gloss_tape_in_product_order(_tg_tape(p + 'main_'), B, w))
+    with tfutil.use_random(tape), torch.no_grad():
+        loss, reg = PL.G_logistic_ns_rec_interp_arb_pathreg(*args, NN_rec_lpips_weight=w, phase='loss')
+    assert reg is None and tape.pos == len(tape.entries)
+    assert rel_err(loss, TG[p + 'loss']) < 2e-4
+    Gn.pl_mean_var = torch.tensor(float(TG[p + 'pl_mean_before']), device=cuda_device)
+    tape = tfutil.RandomTape(_tg_tape(p + 'pl_'))
+    with tfutil.use_random(tape):
+        loss, reg = PL.G_logistic_ns_rec_interp_arb_pathreg(*args, NN_rec_lpips_weight=w, phase='reg')
+    assert loss is None and tape.pos == len(tape.entries)
+    assert rel_err(reg.detach(), TG[p + 'reg']) < 1e-3
+    assert abs(float(Gn.pl_mean_var) - float(TG[p + 'pl_mean_after'])) < 1e-5 * float(TG[p + 'pl_mean_after'])
+
+
+def test_discriminator_loss_against_reference_execution(cuda_device):
+    """D_logistic_r1 on the HIP path (the one-pass interleaved form for the main term, the second-order path for R1) vs the reference's
+    own loss.py."""
+    from inclusivegan_amd.dnnlib.tflib import tfutil
+    from inclusivegan_amd.training import loss as PL
+    from inclusivegan_amd.training.dataset import SyntheticDataset
+    Gn, Dn, _, res, B = _loss_networks(cuda_device)
+    ts = SyntheticDataset(resolution=res, label_size=0, data_size=24, device=cuda_device)
+    reals = dev32(TG['Dloss_reals'], cuda_device).contiguous(memory_format=torch.channels_last)
+    lab = torch.zeros(2 * B, 0, device=cuda_device)
+    for phase, key, tol in (('loss', 'Dloss_loss', 2e-4), ('reg', 'Dloss_reg', 1e-3), ('both', None, None)):
+        tape = tfutil.RandomTape(_tg_tape('Dloss_') if phase != 'reg' else [])
+        with tfutil.use_random(tape):
+            loss, reg = PL.D_logistic_r1(Gn, Dn, ts, B, reals, lab, gamma=float(TG['Dloss_gamma']), phase=phase)
+        assert tape.pos == len(tape.entries)
+        if phase == 'both':
+            assert rel_err(loss.detach(), TG['Dloss_loss']) < 2e-4 and rel_err(reg.detach(), TG['Dloss_reg']) < 1e-3
+        else:
+            assert rel_err((loss if phase == 'loss' else reg).detach(), TG[key]) < tol, phase
+
+
+def test_process_reals_against_reference_execution(cuda_device):
+    from inclusivegan_amd.dnnlib.tflib import tfutil
+    from inclusivegan_amd.training.training_loop import process_reals
+    for p in [str(c) for c in TG['preals_cases']]:
+        lod, mirror, d0, d1 = TG[p + 'cfg']
+        x = torch.from_numpy(TG[p + 'x']).to(cuda_device)
+        with tfutil.use_random(tfutil.RandomTape([('uniform', TG[p + 'coin'])] if mirror else [])):
+            y, _ = process_reals(x, None, lod, bool(mirror), [d0, d1], [-1, 1])
+        assert y.dtype == torch.float32 and rel_err(y, TG[p + 'y']) < 1e-6, p
+
+
+def _toy_build(latents_in, **_kw):
+    """Four trainables with the shapes of the optimizer goldens (one of them a scalar: the bucket pads every slot to 16 bytes)."""
+    from inclusivegan_amd.dnnlib.tflib.tfutil import get_variable
+    for i, s in enumerate([(3, 3, 4, 5), (5,), (7, 2), ()]):
+        get_variable('w%d' % i, shape=list(s), initializer=('zeros',))
+    return latents_in
+
+
+@pytest.mark.parametrize('p', [str(c) for c in TG['opt_cases']])
+def test_optimizer_against_reference_execution(cuda_device, p):
+    """tflib.Optimizer.apply_updates (finite gate + flat Adam kernel, slots and beta powers shared between a main and a `share=`
+    optimizer that take turns) vs the weights the reference's Optimizer + SimpleAdam produced step by step.  The reference's devices are
+    summed here the way GradientExchange / allreduce_mean_ do it: each gradient times 1 / devices, then added (optimizer.py:186,199)."""
+    from inclusivegan_amd.dnnlib import tflib
+    lr, b1, b2, eps, devices, _mult, steps = TG[p + 'hp']
+    net = tflib.Network('T', func_name=_toy_build, device=cuda_device, latent_size=4)
+    names = list(net.trainables)
+    with torch.no_grad():
+        for i, n in enumerate(names):
+            net.vars[n].copy_(dev32(TG['%sw0_%d' % (p, i)], cuda_device).reshape(net.vars[n].shape))
+    main = tflib.Optimizer(name='Train', learning_rate=lr, beta1=b1, beta2=b2, epsilon=eps)
+    reg = tflib.Optimizer(name='Reg', share=main, learning_rate=lr, beta1=b1, beta2=b2, epsilon=eps)
+    for s in range(int(steps)):
+        opt = (main, reg)[s % 2]
+        opt.mark_registered(net)
+        net.flat_grads.zero_()
+        with torch.no_grad():
+            for i, n in enumerate(names):
+                for d in range(int(devices)):
+                    net.trainables[n].grad.add_(dev32(TG['%sgrad_s%d_d%d_%d' % (p, s, d, i)], cuda_device).reshape(net.trainables[n].shape) * np.float32(1.0 / devices))
+        opt.apply_updates()
+        for i, n in enumerate(names):
+            want = TG['%sw_s%d_%d' % (p, s, i)]
+            got = net.vars[n].detach().double().cpu().numpy().reshape(want.shape)
+            assert np.abs(got - want).max() <= 2e-6 * max(np.abs(want).max(), 1e-3), (p, s, n)
+    assert main.overflow_count() == (1 if p == 'opt_two_devices_' else 0)
+
+
+def test_moving_average_against_reference_execution(cuda_device):
+    """Network.setup_as_moving_average_of (flat EMA kernel for the trainables, copy / lerp for the rest) vs network.py:341-351 executed."""
+    from inclusivegan_amd import hip_ops
+    trainable = set(str(n) for n in TG['ema_trainable'])
+    names = [k[len('ema_src.'):] for k in TG.files if k.startswith('ema_src.')]
+    for p in [str(c) for c in TG['ema_cases']]:
+        beta, beta_nt = TG[p + 'betas']
+        tn = [n for n in names if n.replace('.', '/') in trainable]
+        dst = torch.cat([dev32(TG['ema_dst.' + n], cuda_device).reshape(-1) for n in tn])
+        src = torch.cat([dev32(TG['ema_src.' + n], cuda_device).reshape(-1) for n in tn])
+        hip_ops.ema_raw(dst, src, float(beta))
+        want = np.concatenate([TG[p + 'after.' + n].reshape(-1) for n in tn])
+        assert np.abs(dst.double().cpu().numpy() - want).max() <= 1e-6 * np.abs(want).max(), p
+    # through the Network method, non-trainables included (beta_nontrainable = 0: copied)
+    from inclusivegan_amd.dnnlib import tflib
+    res, fmap, _B, latent, dlatent, mfmaps, _seed = [int(v) for v in TG['loss_cfg']]
+    kw = dict(num_channels=3, resolution=res, label_size=0, fmap_base=fmap, device=cuda_device, architecture='skip', latent_size=latent, dlatent_size=dlatent, mapping_fmaps=mfmaps)
+    Gn = tflib.Network('G', func_name='inclusivegan_amd.training.networks_stylegan2.G_main', seed=1, **kw)
+    Gs = tflib.Network('Gs', func_name='inclusivegan_amd.training.networks_stylegan2.G_main', seed=2, **kw)
+    with torch.no_grad():
+        Gn.vars['dlatent_avg'].normal_()
+    before = {n: v.detach().double().cpu().numpy().copy() for n, v in Gs.vars.items()}
+    beta = float(TG['ema_1_betas'][0])
+    Gs.setup_as_moving_average_of(Gn, beta=beta)()
+    for n, v in Gs.vars.items():
+        src = Gn.vars[n].detach().double().cpu().numpy()
+        want = src + (before[n] - src) * (beta if n in Gs.trainables else 0.0)          # lerp(src, dst, beta), network.py:348
+        assert np.abs(v.detach().double().cpu().numpy() - want).max() <= 1e-6 * max(np.abs(want).max(), 1e-6), n
