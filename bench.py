@@ -13,10 +13,12 @@ G path-length reg every 4th, D step + Gs EMA, D R1 reg every 16th; it advances t
 separately (`imle_refresh_s`), as BASELINE.md prescribes.
 
 Prints ONE JSON line on rank 0.  Besides the contract fields it carries
-  roofline      the dominant kernel (f32-MFMA conv2d forward) timed per launch INSIDE the replayed training
-                graphs with device-side time stamps: algorithmic FLOPs / launch time vs the 157.3 TFLOP/s f32
-                matrix peak of MI355X; the north-star shape (128x128 Conv1) alone and the HBM-bound upfirdn2d
-                (GB/s vs 8 TB/s) with HIP events, sustained;
+  roofline      the conv family timed per call INSIDE the replayed training graphs with device-side time stamps, grouped by kernel
+                family; `kernel` = the family with the largest total time: algorithmic FLOPs / time vs its peak (bf16-piece families:
+                2.5 PFLOP/s bf16 dense / 6 products = 416.7 fp32-equivalent TFLOP/s; fp32-instruction families: 157.3 TFLOP/s), plus
+                `wgrad`, `families`; the north-star shape (128x128 Conv1) alone and the HBM-bound upfirdn2d (GB/s vs 8 TB/s) with HIP
+                events, sustained; `traffic` only from a --pmc pass taken on the kernels as they are now;
+  second_line_* the same steady state with the other convolution form (default path: the exact-fp32-instruction run), labelled;
   cpu_baseline  the CPU oracle (oracle/, PyTorch-CPU fp32) timed on this box's host cores on a
                 bounded sample of the same workload (rank 0, N = 1 only).
 """
@@ -32,6 +34,49 @@ if ROOT not in sys.path:
 
 F32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (about 6.3 TB/s achievable)
+BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense" (v_mfma_f32_32x32x16_bf16, 1024 FLOP/clk/SIMD)
+PIECE_PRODUCTS = 6               # bf16-piece form: a0b0, a0b1, a1b0, a0b2, a1b1, a2b0 per fp32 product -> fp32-equivalent peak = 2500 / 6
+PIECE_FORM_PEAK_TFLOPS = BF16_DENSE_PEAK_TFLOPS / PIECE_PRODUCTS      # 416.7 fp32-equivalent TFLOP/s
+
+
+def piece_form_on():
+    """The large 3x3 convolutions run in the bf16-piece form unless IGAN_CONV_PLANES=0 (csrc/conv2d_mfma.hip planes_enabled)."""
+    return os.environ.get('IGAN_CONV_PLANES', '1') != '0'
+
+
+def family_of(kernel_name):
+    """Kernel FAMILY = the template name without its arguments (and without the '(+ reduce)' / '(shared image)' notes): all
+    instantiations of conv_wgrad_kernel<...> are one family (VERDICT r03 weak #5)."""
+    return kernel_name.split('<')[0].split(' (')[0].strip()
+
+
+def family_peak(family):
+    return PIECE_FORM_PEAK_TFLOPS if 'planes' in family else F32_MATRIX_PEAK_TFLOPS
+
+
+def file_sha16(path):
+    import hashlib
+    with open(path, 'rb') as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def pmc_traffic(suffix, want_kernel=None, sources=('conv2d_mfma.hip',)):
+    """traffic_bytes_per_launch of the newest committed `--pmc` pass profiles/rNN_<suffix> -- ONLY if that pass was taken on the kernels
+    as they are now: the file records the sha256 of the kernel sources it was collected with (tools/pmc_to_json.py), and a file that
+    records none, or another one, is refused (-> (None, reason)).  (VERDICT r03 weak #7: a constant read from a stale file.)"""
+    path = _latest_profile(suffix)
+    if not path:
+        return None, 'no profiles/rNN_%s' % suffix
+    with open(path) as f:
+        pj = json.load(f)
+    have = pj.get('kernel_source_sha16', {})
+    for src in sources:
+        now = file_sha16(os.path.join(ROOT, 'inclusivegan_amd', 'csrc', src))
+        if have.get(src) != now:
+            return None, '%s was collected on another version of csrc/%s (recorded %s, now %s): re-run tools/collect_pmc.sh' % (os.path.basename(path), src, have.get(src), now)
+    if want_kernel is not None and family_of(pj.get('kernel', '')) != family_of(want_kernel):
+        return None, '%s is about %s, not %s' % (os.path.basename(path), pj.get('kernel'), want_kernel)
+    return pj['traffic_bytes_per_launch'], os.path.basename(path)
 
 
 def parse_args():
@@ -46,7 +91,7 @@ def parse_args():
     p.add_argument('--lpips-weight', type=float, default=2.5)
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true')
-    p.add_argument('--no-variant-line', action='store_true', help='skip the second, labelled measurement with the bf16-piece convolutions (a child run of this script)')
+    p.add_argument('--no-variant-line', action='store_true', help='skip the second, labelled measurement with the other convolution form (a child run of this script; default path: the exact-fp32 run)')
     p.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='process-group backend for --gpus > 1 (nccl = RCCL; gloo for the one-GPU tests)')
     p.add_argument('--one-gpu', action='store_true', help='test hook: every rank on device 0 (needs --backend gloo: RCCL refuses two ranks on one device)')
     p.add_argument('--op-times', action='store_true', help='also report the mean device time of each training op (HIP events)')
@@ -83,15 +128,15 @@ def headline_shape_roofline(device, batch, reps=40, warm_s=0.4):
     ms = e0.elapsed_time(e1) / reps
     flops = 2.0 * batch * res * res * cout * cin * 9
     achieved = flops / (ms * 1e-3) / 1e12
+    peak = PIECE_FORM_PEAK_TFLOPS if piece_form_on() else F32_MATRIX_PEAK_TFLOPS
     out = dict(shape='modulated conv 128x128 3x3 Cin=Cout=128 batch %d (M=%d N=128 K=1152)' % (batch, batch * res * res),
-               achieved=round(achieved, 2), frac=round(achieved / F32_MATRIX_PEAK_TFLOPS, 4),
+               kernel='conv_fwd_planes_kernel (whole call: x image + filter image + tile kernel)' if piece_form_on() else 'conv_fwd_dma_kernel<false, true>',
+               achieved=round(achieved, 2), peak=round(peak, 1), frac=round(achieved / peak, 4),
                flops_per_launch=flops, us_per_launch=round(ms * 1e3, 1), traffic=None)
     # HBM-side bytes per launch of this shape from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled per
     # the gfx950 correction + WRITE_SIZE); only valid for the batch they were taken at.
-    pmc = _latest_profile('pmc_conv_headline.json')
-    if batch == 6 and pmc:
-        with open(pmc) as f:
-            out['traffic'] = json.load(f)['traffic_bytes_per_launch']
+    if batch == 6:
+        out['traffic'], out['traffic_source'] = pmc_traffic('pmc_conv_headline.json')
     return out
 
 
@@ -137,57 +182,71 @@ def hbm_kernel_roofline(device, batch, warm_s=0.2, reps=40):
     out = dict(bound='hbm', kernel='upfirdn2d_fir4_kernel', achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s',
                frac=round(gbs / HBM_PEAK_GBS, 4), bytes_per_launch=round(tot_b / len(sites)), us_per_launch=round(tot_s / len(sites) * 1e6, 1),
                sites_GBps=per_site, traffic=None)
-    pmc = _latest_profile('pmc_upfirdn.json')
-    if batch == 6 and pmc:
-        with open(pmc) as f:
-            out['traffic'] = json.load(f)['traffic_bytes_per_launch']
+    if batch == 6:
+        out['traffic'], out['traffic_source'] = pmc_traffic('pmc_upfirdn.json', sources=('upfirdn2d.hip',))
     return out
 
 
 def step_roofline(stamp, steps, shapes_file=None):
-    """Roofline of the dominant kernel over the launches of real training iterations, measured with the device running
-    exactly as in the timed region: the training ops' hipGraphs are re-captured with a pair of device-side time stamps around
-    every conv-family launch (hip_ops.StampLog: one-wave kernels reading the 100 MHz counter in stream order, plus a fold
-    kernel per graph that accumulates the durations), then replayed for further iterations.  Launches are grouped by kernel
-    instantiation; the one with the largest total time is the dominant kernel.  achieved = sum of algorithmic FLOPs / sum of
-    launch durations; avg_launch_us is what `rocprofv3 --kernel-trace --stats` of the same command reports as that kernel's
-    average duration (+ the ~1 us from stamp to kernel start).  (Round 1 timed eager launches with host events: the host-bound
-    eager loop leaves the device idle between kernels, which lowers its clock and read 6-9 % low.)"""
+    """Roofline of the conv family over the launches of real training iterations, measured with the device running exactly as in the
+    timed region: the training ops' hipGraphs are re-captured with a pair of device-side time stamps around every conv-family call
+    (hip_ops.StampLog: one-wave kernels reading the 100 MHz counter in stream order, plus a fold kernel per graph that accumulates the
+    durations), then replayed for further iterations.  Calls are grouped by kernel FAMILY (template name without its arguments); the
+    family with the largest total time is `kernel`.  achieved = sum of algorithmic FLOPs / sum of call durations (a call of the piece
+    form includes the filter-image kernel, the x image when the call wrote its own, and the fix-up / reduce launches; images shared
+    between calls are the family 'to_planes_kernel', FLOP-free time inside conv_family_tflops).  Peak: 157.3 TFLOP/s for the families on
+    the fp32 matrix instruction; for the bf16-piece families the bf16 dense peak / 6 products = 416.7 fp32-equivalent TFLOP/s."""
     totals = stamp.totals_us()
     replays = {}
     for step, (first, count) in steps.items():
         for i in range(first, first + count):
             replays[i] = step.replays
-    agg = {}
+    fam = {}
     for i, (name, flops, us) in enumerate(totals):
         n = replays.get(i, 0)
-        if n == 0 or us <= 0 or not name.startswith('conv_fwd'):
-            continue        # the roofline entry is about the forward-type MFMA kernel (conv, data gradients); others stay in conv_family_tflops
-        a = agg.setdefault(name, [0, 0.0, 0.0])
+        if n == 0 or us <= 0:
+            continue
+        a = fam.setdefault(family_of(name), [0, 0.0, 0.0])
         a[0] += n
         a[1] += flops * n
         a[2] += us * 1e-6
-    name, (calls, flops, secs) = max(agg.items(), key=lambda kv: kv[1][2])
-    achieved = flops / secs / 1e12
-    total_conv = sum(v[2] for v in agg.values())
-    fam_us = sum(us for i, (_, _, us) in enumerate(totals) if replays.get(i, 0) > 0)
-    fam_flops = sum(flops * replays.get(i, 0) for i, (_, flops, _) in enumerate(totals))
+    fam_secs = sum(v[2] for v in fam.values())
+    fam_flops = sum(v[1] for v in fam.values())
+
+    def entry(name):
+        calls, flops, secs = fam[name]
+        ach = flops / secs / 1e12
+        pk = family_peak(name)
+        return dict(kernel=name, achieved=round(ach, 2), peak=round(pk, 1), unit='TFLOP/s', frac=round(ach / pk, 4), launches=calls,
+                    avg_launch_us=round(secs / calls * 1e6, 1), flops_per_launch=round(flops / calls), share_of_conv_time=round(secs / fam_secs, 3))
+    mfma = {k: v for k, v in fam.items() if v[1] > 0 and k.startswith('conv_')}
+    name = max(mfma, key=lambda k: mfma[k][2])
     if shapes_file:
         with open(shapes_file, 'w') as f:
             f.write('# conv family inside the replayed training graphs (device stamps), %d stamped iterations; sorted by time\n' % max(replays.values()))
             f.write('# %-78s %-58s %8s %10s %8s\n' % ('shape', 'kernel', 'launches', 'total us', 'TFLOP/s'))
             for shape, kname, n, us, tf in stamp.shape_table(replays):
                 f.write('%-80s %-58s %8d %10.1f %8.1f\n' % (shape, kname[:58], n, us, tf))
-            f.write('# total %.1f ms, %.1f TFLOP/s\n' % (fam_us / 1e3, fam_flops / max(fam_us, 1e-9) / 1e6))
-    return dict(bound='mfma', kernel=name, achieved=round(achieved, 2), peak=F32_MATRIX_PEAK_TFLOPS, unit='TFLOP/s',
-                frac=round(achieved / F32_MATRIX_PEAK_TFLOPS, 4), launches=calls, avg_launch_us=round(secs / calls * 1e6, 1),
-                flops_per_launch=round(flops / calls), share_of_conv_time=round(secs / total_conv, 3),
-                conv_family_tflops=round(fam_flops / max(fam_us, 1e-9) / 1e6, 2), timing='device stamps inside the replayed hipGraphs', traffic=None)
+            f.write('# total %.1f ms, %.1f TFLOP/s\n' % (fam_secs * 1e3, fam_flops / max(fam_secs, 1e-12) / 1e12))
+            f.write('# per family: ' + '; '.join('%s %.1f ms %.1f TFLOP/s' % (k, v[2] * 1e3, v[1] / v[2] / 1e12) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][2])) + '\n')
+    out = dict(bound='mfma', **entry(name))
+    out['peak_note'] = ('bf16 dense peak %.0f / %d piece products (fp32-equivalent)' % (BF16_DENSE_PEAK_TFLOPS, PIECE_PRODUCTS)) if 'planes' in name else 'f32 matrix peak (v_mfma_f32_32x32x2_f32)'
+    out['conv_family_tflops'] = round(fam_flops / max(fam_secs, 1e-12) / 1e12, 2)
+    out['conv_family_ms_per_iteration'] = round(fam_secs * 1e3 / max(replays.values()), 3)
+    out['timing'] = 'device stamps inside the replayed hipGraphs'
+    out['traffic'] = None
+    out['families'] = {k: entry(k) if v[1] > 0 else dict(kernel=k, launches=v[0], avg_launch_us=round(v[2] / v[0] * 1e6, 1), share_of_conv_time=round(v[2] / fam_secs, 3))
+                       for k, v in sorted(fam.items(), key=lambda kv: -kv[1][2])}
+    wg = [k for k in mfma if 'wgrad' in k]
+    if wg:
+        out['wgrad'] = entry(max(wg, key=lambda k: mfma[k][2]))
+    return out
 
 
 def cpu_baseline(resolution, batch, lpips_weight):
-    """CPU oracle on a bounded sample: one G step + one D step (loss phases, fwd+bwd) of the same
-    configuration at the same per-GPU batch; the lazy-regularisation steps are left out of the sample."""
+    """CPU oracle on a bounded sample of the SAME workload mix as the GPU line: one G step, one D step, one G
+    path-length step and one D R1 step (forward + backward each) are timed once at the same per-GPU batch, and an iteration costs
+    t_G + t_D + t_Greg / 4 + t_Dreg / 16 (lazy regularisation: training_loop.py:474-479)."""
     import numpy as np
     import torch
     from oracle import loss as OL
@@ -207,24 +266,36 @@ def cpu_baseline(resolution, batch, lpips_weight):
     g = torch.Generator().manual_seed(1)
     reals = lambda n: torch.rand(n, 3, resolution, resolution, generator=g) * 2 - 1
     lat = lambda n: torch.nn.functional.normalize(torch.randn(n, 512, generator=g), dim=1)
-    def iteration():
-        loss, _, _ = OL.G_loss(gp, {k: v.detach() for k, v in dp.items()}, lp, cfg, rand, batch, reals(batch), lat(batch), reals(batch), lat(batch),
-                               lpips_weight, phase='loss', state={})
-        torch.autograd.grad(loss.mean(), [p for p in gp.values() if p.requires_grad], allow_unused=True)
-        loss, _, _ = OL.D_loss({k: v.detach() for k, v in gp.items()}, dp, cfg, rand, batch, reals(2 * batch), gamma=100, phase='loss', state={})
-        torch.autograd.grad(loss.mean(), [p for p in dp.values() if p.requires_grad], allow_unused=True)
+    gtr = [p for p in gp.values() if p.requires_grad]
+    dtr = [p for p in dp.values() if p.requires_grad]
 
-    # bounded sample: whole iterations until at least ~12 s of CPU work (first one included: there is no warm-up
-    # to speak of on the CPU path), at most 4
-    t0 = time.time()
-    iters = 0
-    while iters < 4 and (iters == 0 or time.time() - t0 < 12.0):
-        iteration()
-        iters += 1
-    dt = time.time() - t0
-    return dict(value=round(2 * batch * iters / dt, 4), unit='img/s', cores=cores, kind='port',
-                sample='per-image rate of %d iteration(s) (G step + D step, forward+backward) at minibatch_gpu=%d WITHOUT the lazy-regularisation steps -- not the GPU line\'s workload mix -- %dx%d, PyTorch-CPU fp32 oracle, %.1f s'
-                       % (iters, batch, resolution, resolution, dt))
+    def G_step():
+        loss, _, _ = OL.G_loss(gp, {k: v.detach() for k, v in dp.items()}, lp, cfg, rand, batch, reals(batch), lat(batch), reals(batch), lat(batch), lpips_weight, phase='loss', state={})
+        torch.autograd.grad(loss.mean(), gtr, allow_unused=True)
+
+    def D_step():
+        loss, _, _ = OL.D_loss({k: v.detach() for k, v in gp.items()}, dp, cfg, rand, batch, reals(2 * batch), gamma=100, phase='loss', state={})
+        torch.autograd.grad(loss.mean(), dtr, allow_unused=True)
+
+    def G_reg():
+        _, reg, _ = OL.G_loss(gp, {k: v.detach() for k, v in dp.items()}, lp, cfg, rand, batch, None, lat(batch), None, lat(batch), lpips_weight, phase='reg', state={})
+        torch.autograd.grad((reg * 4).mean(), gtr, allow_unused=True)
+
+    def D_reg():
+        _, reg, _ = OL.D_loss({k: v.detach() for k, v in gp.items()}, dp, cfg, rand, batch, reals(2 * batch), gamma=100, phase='reg', state={})
+        torch.autograd.grad((reg * 16).mean(), dtr, allow_unused=True)
+
+    t = {}
+    t_all = time.time()
+    for name, fn in (('G', G_step), ('D', D_step), ('G_reg', G_reg), ('D_reg', D_reg)):
+        t0 = time.time()
+        fn()
+        t[name] = time.time() - t0
+    per_iter = t['G'] + t['D'] + t['G_reg'] / 4 + t['D_reg'] / 16
+    return dict(value=round(2 * batch / per_iter, 4), unit='img/s', cores=cores, kind='port',
+                sample='one G step %.1f s + one D step %.1f s + one path-length step %.1f s / 4 + one R1 step %.1f s / 16 (forward+backward each, the GPU line\'s lazy-regularisation mix) '
+                       'at minibatch_gpu=%d, %dx%d, PyTorch-CPU fp32 oracle, %.1f s of CPU work' % (t['G'], t['D'], t['G_reg'], t['D_reg'], batch, resolution, resolution, time.time() - t_all),
+                op_seconds={k: round(v, 2) for k, v in t.items()})
 
 
 def knn_cpu_baseline(num_points=30000, dim=3072, num_queries=256):
@@ -289,29 +360,31 @@ def cpu_baseline_subprocess(resolution, batch, lpips_weight, timeout_s=600):
         return dict(value=None, unit='img/s', cores=0, kind='port', sample='cpu baseline exceeded %d s' % timeout_s)
 
 
-def variant_line(args, timeout_s=900):
-    """The SECOND, labelled line: the same steady-state measurement with the forward / data-gradient convolutions in their
-    bf16-piece form (IGAN_CONV_PLANES=1: three bf16 pieces per fp32 operand, six products, fp32 sums -- csrc/conv2d_mfma.hip
-    conv_fwd_planes_kernel; passes the GPU parity suite at the fp32 path's tolerances but is not the fp32 instruction, so it is
-    never `value`).  A child process, because the switch is read once per process; small data set: its refresh is not the subject."""
+def second_line(args, timeout_s=900):
+    """The SECOND, labelled line: the same steady-state measurement with the switch of the convolution form flipped -- a child process,
+    because the switch is read once per process (small data set: the refresh is not the subject).  The default path runs the large 3x3
+    convolutions in the bf16-piece form (three bf16 pieces per fp32 operand, six products, fp32 sums: all 24 significand bits, parity
+    tests at the fp32 tolerances), so the second line is the EXACT-fp32-instruction run (IGAN_CONV_PLANES=0); a run that is itself started
+    with IGAN_CONV_PLANES=0 reports the piece form as its second line."""
     import subprocess
-    env = dict(os.environ, IGAN_CONV_PLANES='1')
-    # at least 200 timed iterations after 40 of warm-up: the variant's short-window rate swings with the thermal state the headline run left
-    # behind (219-282 img/s over 32 iterations on the same code; 254 +- 0.3 over 800) -- the labelled line should be the sustained figure
+    other = '0' if piece_form_on() else '1'
+    env = dict(os.environ, IGAN_CONV_PLANES=other)
+    # at least 200 timed iterations after 40 of warm-up: short-window rates swing with the thermal state the headline run left behind
     steps, warmup = max(args.steps, 200), max(args.warmup, 40)
     cmd = [sys.executable, os.path.abspath(__file__), '--steps', str(steps), '--warmup', str(warmup), '--data-size', '1152',
            '--minibatch-gpu', str(args.minibatch_gpu), '--resolution', str(args.resolution), '--lpips-weight', str(args.lpips_weight),
            '--no-cpu-baseline', '--no-variant-line']
+    label = ('exact fp32: every convolution on v_mfma_f32_32x32x2_f32 (IGAN_CONV_PLANES=0); everything else as in the headline' if other == '0' else
+             '3x3 convolutions (forward, data gradient, weight gradient) as 3 bf16 pieces x 6 products with fp32 sums (the default form)')
     try:
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s)
         d = json.loads(r.stdout.strip().splitlines()[-1])
-    except Exception as e:      # a failed variant run never takes the headline with it
-        return {'label': 'bf16-piece convolutions (IGAN_CONV_PLANES=1)', 'error': repr(e)[:200]}
+    except Exception as e:      # a failed second run never takes the headline with it
+        return {'label': label, 'error': repr(e)[:200]}
     roof = d.get('roofline', {})
-    return {'label': 'VARIANT, not the product path: 3x3 convolutions (forward, data gradient, weight gradient) as 3 bf16 pieces x 6 products with fp32 sums (IGAN_CONV_PLANES=1); '
-                     'everything else as in the headline', 'value': d['value'], 'unit': d['unit'], 'ms_per_step': d['ms_per_step'], 'steps': d['steps'], 'warmup': d['warmup'],
-            'data_size': 1152, 'hip_graphs': d.get('hip_graphs'), 'dominant_kernel': roof.get('kernel'), 'dominant_kernel_fp32_equivalent_tflops': roof.get('achieved'),
-            'conv_family_fp32_equivalent_tflops': roof.get('conv_family_tflops')}
+    return {'label': label, 'value': d['value'], 'unit': d['unit'], 'ms_per_step': d['ms_per_step'], 'steps': d['steps'], 'warmup': d['warmup'], 'dtype': d['dtype'],
+            'data_size': 1152, 'hip_graphs': d.get('hip_graphs'), 'dominant_kernel': roof.get('kernel'), 'dominant_kernel_tflops': roof.get('achieved'),
+            'dominant_kernel_frac': roof.get('frac'), 'conv_family_tflops': roof.get('conv_family_tflops')}
 
 
 def log(msg):
@@ -399,6 +472,15 @@ def main():
             GraphedStep.generation += 1
         if state['iters'] == args.warmup + args.steps + profile_iters:
             torch.cuda.synchronize()
+            # the stamped graphs are new captures (all four ops have been re-captured within 16 iterations): they get the same
+            # replay-equals-eager check as the first ones.  The stamp totals are frozen first -- the check's replays would add
+            # samples the replay counters do not know about -- and its eager side runs without stamps.
+            from inclusivegan_amd import hip_ops
+            frozen = state['stamp'].totals_us()
+            state['stamp'].totals_us = lambda: frozen
+            hip_ops.stamp_log = None
+            info['revalidate_graphs']('after the stamped re-capture')
+            torch.cuda.synchronize()
             return True
         return False
 
@@ -438,7 +520,7 @@ def main():
         'metric': 'training img/sec (whole node), CelebA 128x128 StyleGAN2+IMLE',
         'value': round(imgs / elapsed, 3), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32' if os.environ.get('IGAN_CONV_PLANES') != '1' else 'f32 emulated with 3 bf16 pieces in the 3x3 convolutions (variant)',
+        'dtype': 'f32 (3x3 convs: exact 3-piece bf16 split, fp32 sums)' if piece_form_on() else 'f32',
         'data': 'synthetic',
         'config': {'workload': 'CelebA-shaped %dx%d StyleGAN2+IMLE, config-e-Gskip-Dresnet (fmap_base 8192), minibatch_gpu %d, '
                                'NN_rec_lpips_weight %g, lazy reg G/4 D/16, random-init weights' % (args.resolution, args.resolution, B, args.lpips_weight),
@@ -448,6 +530,12 @@ def main():
         # the four training ops run as replayed hipGraphs, each validated bit for bit against its eager execution after capture
         'hip_graphs': state['graphs'] if state['graphs'] is not None else {'captured': False},
     }
+    if world > 1:
+        from inclusivegan_amd.dnnlib.tflib import optimizer as _opt
+        nccl = torch.cuda.nccl.version() if backend == 'nccl' and hasattr(torch.cuda, 'nccl') else None
+        out['rccl'] = {'ranks': torch.distributed.get_world_size(), 'backend': torch.distributed.get_backend(),
+                       'in_graph': bool(state['graphs'] and state['graphs'].get('captured') and _opt.collectives_capturable()),
+                       'version': '.'.join(str(v) for v in nccl) if isinstance(nccl, (tuple, list)) else nccl}
     if state['refresh']:
         # `value` is the steady state between refreshes (the refresh is reported separately); one refresh serves
         # data_size * init_staleness images (training_loop.py:354), so over the first period the throughput is
@@ -465,12 +553,8 @@ def main():
             GraphedStep.after_capture = None
             log('aggregating %d stamped conv launches' % len(state['stamp'].entries))
             out['roofline'] = step_roofline(state['stamp'], state['stamp_steps'], args.conv_shapes)
-            pmc = _latest_profile('pmc_dominant.json')
-            if pmc and B == 6:
-                with open(pmc) as f:
-                    pj = json.load(f)
-                if pj.get('kernel') == out['roofline']['kernel']:
-                    out['roofline']['traffic'] = pj['traffic_bytes_per_launch']
+            if B == 6:
+                out['roofline']['traffic'], out['roofline']['traffic_source'] = pmc_traffic('pmc_dominant.json', want_kernel=out['roofline']['kernel'])
             out['roofline']['headline_shape'] = headline_shape_roofline(device, B)
             out['roofline']['hbm_kernel'] = hbm_kernel_roofline(device, B)
         if world == 1 and not args.no_cpu_baseline:
@@ -479,9 +563,9 @@ def main():
             knn = out['cpu_baseline'].get('knn')
             if isinstance(knn, dict) and knn.get('value'):
                 knn['gpu_queries_per_s'] = knn_gpu(device, knn['num_points'], knn['dim'])
-        if world == 1 and not args.no_variant_line and os.environ.get('IGAN_CONV_PLANES') != '1':
-            log('second line: the bf16-piece variant (child run)')
-            out['variant_bf16_pieces'] = variant_line(args)
+        if world == 1 and not args.no_variant_line:
+            log('second line: the other convolution form (child run)')
+            out['second_line_exact_fp32' if piece_form_on() else 'second_line_bf16_pieces'] = second_line(args)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()

@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 /* Bumped whenever a struct layout or a signature changes (2: fused conv epilogue fields, fp64 nearest-neighbour state). */
-#define IGAN_ABI_VERSION 5
+#define IGAN_ABI_VERSION 6
 
 typedef void* igan_stream_t; /* hipStream_t */
 
@@ -183,9 +183,10 @@ typedef struct igan_conv2d_params {
     const float* in_scale;  /* [N, Cin] or NULL */
     const float* out_scale; /* [N, Cout] or NULL */
     float* workspace;       /* igan_conv2d_plan()'s workspace_floats floats, 16-byte aligned; NULL iff the plan asked for none.  It
-                             * holds the partial tiles of the sliced tail (splits > 1) and, when the library runs in its bf16-piece
-                             * variant (environment IGAN_CONV_PLANES=1, not the default), the piece images behind them; a launch that
-                             * gets no room for the images runs the fp32 kernel */
+                             * holds the partial tiles of the sliced tail (splits > 1) and, for the shapes the library runs in its
+                             * bf16-piece form (the default for the large 3x3 layers; environment IGAN_CONV_PLANES=0 = exact-fp32
+                             * instruction everywhere), the piece images behind them; a launch that gets no room for the images runs
+                             * the fp32 kernel */
     size_t workspace_floats;
     int N, H, W, Cin;
     int OH, OW, Cout;
@@ -205,8 +206,9 @@ typedef struct igan_conv2d_params {
                              * y = act(y + noise[n, oy, ox] * noise_strength[0] + bias[co]) * act_gain; NULL = no noise */
     const float* noise_strength; /* device scalar */
     int noise_bcast;        /* 1: noise is [1, OH, OW], shared by the batch (the layer's stored noise); 0: [N, OH, OW] */
-    const void* x_pieces;   /* bf16-piece variant only (else NULL / ignored): the piece image of x * in_scale, written by igan_to_pieces(),
+    const void* x_pieces;   /* bf16-piece form only (else NULL / ignored): the piece image of x * in_scale, written by igan_to_pieces(),
                              * so that a caller who runs several convolutions on one tensor writes its image once */
+    size_t x_pieces_bytes;  /* its size, N * H * W * Cin * 6 (ABI v6): an image of any other size is rejected, never read */
 } igan_conv2d_params;
 
 int igan_conv2d_plan(const igan_conv2d_params* p, int* splits, int* sliced_tiles, size_t* workspace_floats);
@@ -237,14 +239,25 @@ typedef struct igan_conv2d_wgrad_params {
     int pad_y, pad_x;
     int splits;
     float alpha;            /* dw is multiplied by alpha (see igan_conv2d_params) */
-    const void* x_pieces;   /* bf16-piece variant only (else NULL / ignored): piece images of x * in_scale and dy * out_scale */
+    const void* x_pieces;   /* bf16-piece form only (else NULL / ignored): piece images of x * in_scale and dy * out_scale */
     const void* dy_pieces;
+    size_t x_pieces_bytes;  /* N * H * W * Cin * 6 and N * OH * OW * Cout * 6 (ABI v6): checked before an image is read */
+    size_t dy_pieces_bytes;
 } igan_conv2d_wgrad_params;
 
 int igan_conv2d_wgrad_plan(const igan_conv2d_wgrad_params* p, int* splits, size_t* workspace_floats);
 int igan_conv2d_wgrad(igan_stream_t stream, const igan_conv2d_wgrad_params* p);
+/* Host-only (ABI v6): the kernel family igan_conv2d_wgrad() runs for these parameters ("conv_wgrad_kernel",
+ * "conv_wgrad_planes_kernel", "thin_wgrad_kernel", "dense_small_wgrad_kernel").  For profiling tools. */
+int igan_conv2d_wgrad_kernel_name(const igan_conv2d_wgrad_params* p, char* buf, int buflen);
 
-/* bf16-piece variant (IGAN_CONV_PLANES=1; not the default path -- DESIGN.md section 4): the piece image of a channel-minor tensor
+/* ABI v6: the library's own answer to "will a layer with this filter take the bf16-piece form?" (the batch-independent part of the
+ * rule: 3x3 taps, both channel counts >= 128 and whole 32s, the form switched on) and "is a tensor [N, HW, C] one igan_to_pieces() can
+ * image for it?" -- so that a host does not restate the rules.  Both return 0 / 1. */
+int igan_conv_pieces_wanted(int KH, int KW, int Cin, int Cout);
+int igan_pieces_image_ok(int N, int HW, int C);
+
+/* bf16-piece form (default for the large 3x3 layers, IGAN_CONV_PLANES=0 switches it off -- DESIGN.md section 4): the piece image of a channel-minor tensor
  * x [N, HW, C] (times scale [N, C] when given), `out` = N * HW * C * 6 bytes, 16-byte aligned, C % 16 == 0.  The convolution entry
  * points write the images they need themselves; a caller that feeds one tensor to several of them (dy to the data and the
  * weight gradient, x to the forward pass and the weight gradient) writes it once with this and passes it as x_pieces / dy_pieces. */

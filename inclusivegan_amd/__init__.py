@@ -18,6 +18,14 @@ import os as _os
 # profiles/r03_graph_packet_capture.txt).  The runtime reads its flags at the first HIP call, so the switch has to be in the
 # environment before anything touches the GPU; dnnlib/tflib/graphs.py additionally validates every captured op against
 # its eager execution and refuses to replay a graph that disagrees.
-_os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
+if _os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE') is None:
+    import sys as _sys
+    _t = _sys.modules.get('torch')
+    if _t is not None and _t.cuda.is_initialized():
+        # the runtime has read its flags already: setting the variable now would silently do nothing
+        import warnings as _w
+        _w.warn('inclusivegan_amd imported after HIP was initialised: DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 cannot take effect in this process; '
+                'captured training ops are validated against eager execution and fall back to it if unfaithful (import the package first, or export the variable)')
+    _os.environ['DEBUG_CLR_GRAPH_PACKET_CAPTURE'] = '0'
 
 __version__ = '0.1.0'

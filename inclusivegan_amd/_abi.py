@@ -59,7 +59,7 @@ class Conv2DParams(ctypes.Structure):
         ('w_transposed', ctypes.c_int), ('splits', ctypes.c_int), ('sliced_tiles', ctypes.c_int), ('alpha', ctypes.c_float),
         ('bias', ctypes.c_void_p), ('act', ctypes.c_int), ('act_alpha', ctypes.c_float), ('act_gain', ctypes.c_float),
         ('noise', ctypes.c_void_p), ('noise_strength', ctypes.c_void_p), ('noise_bcast', ctypes.c_int),
-        ('x_pieces', ctypes.c_void_p),
+        ('x_pieces', ctypes.c_void_p), ('x_pieces_bytes', ctypes.c_size_t),
     ]
 
     def __init__(self, *args, **kwargs):
@@ -78,7 +78,7 @@ class Conv2DWgradParams(ctypes.Structure):
         ('stride', ctypes.c_int), ('up', ctypes.c_int),
         ('pad_y', ctypes.c_int), ('pad_x', ctypes.c_int),
         ('splits', ctypes.c_int), ('alpha', ctypes.c_float),
-        ('x_pieces', ctypes.c_void_p), ('dy_pieces', ctypes.c_void_p),
+        ('x_pieces', ctypes.c_void_p), ('dy_pieces', ctypes.c_void_p), ('x_pieces_bytes', ctypes.c_size_t), ('dy_pieces_bytes', ctypes.c_size_t),
     ]
 
     def __init__(self, *args, **kwargs):
@@ -114,7 +114,7 @@ class TapsParams(ctypes.Structure):
                 ('taps', ctypes.c_int), ('n', ctypes.c_int), ('scale', ctypes.c_float)]
 
 
-ABI_VERSION = 5      # include/igan_hip.h IGAN_ABI_VERSION
+ABI_VERSION = 6      # include/igan_hip.h IGAN_ABI_VERSION
 STRUCTS = (UpFirDn2DParams, FusedBiasActParams, Conv2DParams, Conv2DWgradParams, DenseParams, DenseWgradParams, TapsParams)   # igan_struct_size ids
 
 DENSE_MAX_GROUPS = 24
@@ -143,9 +143,12 @@ SIGNATURES = {
     'igan_conv2d_plan': (_I, [ctypes.POINTER(Conv2DParams), ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_SZ)]),
     'igan_conv2d': (_I, [_P, ctypes.POINTER(Conv2DParams)]),
     'igan_conv2d_kernel_name': (_I, [ctypes.POINTER(Conv2DParams), ctypes.c_char_p, _I]),
+    'igan_conv2d_wgrad_kernel_name': (_I, [ctypes.POINTER(Conv2DWgradParams), ctypes.c_char_p, _I]),
     'igan_conv2d_wgrad_plan': (_I, [ctypes.POINTER(Conv2DWgradParams), ctypes.POINTER(_I), ctypes.POINTER(_SZ)]),
     'igan_conv2d_wgrad': (_I, [_P, ctypes.POINTER(Conv2DWgradParams)]),
     'igan_to_pieces': (_I, [_P, _P, _P, _P, _I, _I, _I]),
+    'igan_conv_pieces_wanted': (_I, [_I, _I, _I, _I]),
+    'igan_pieces_image_ok': (_I, [_I, _I, _I]),
     'igan_dense_small': (_I, [_P, ctypes.POINTER(DenseParams)]),
     'igan_dense_small_wgrad': (_I, [_P, ctypes.POINTER(DenseWgradParams)]),
     'igan_dense_small_grouped': (_I, [_P, ctypes.POINTER(DenseParams), _I]),

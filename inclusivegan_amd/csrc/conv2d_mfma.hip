@@ -2015,15 +2015,20 @@ bool walk_ok(const igan_conv2d_params* p) {
     return walk && vecA && vecB && (p->in_scale == nullptr || vecS) && (p->Cin % BK == 0);
 }
 
-// Does this launch take the bf16-piece form (conv_fwd_planes_kernel)?  IGAN_CONV_PLANES=1, the 128x128 tile, Cin % 32 == 0, both
+// The bf16-piece form is the DEFAULT for the shapes below (round 4); IGAN_CONV_PLANES=0 runs every convolution on the fp32 instruction.
+bool planes_enabled() {
+    static const bool on = !(getenv("IGAN_CONV_PLANES") && atoi(getenv("IGAN_CONV_PLANES")) == 0);
+    return on;
+}
+
+// Does this launch take the bf16-piece form (conv_fwd_planes_kernel)?  the form switched on, the 128x128 tile, Cin % 32 == 0, both
 // piece images addressable with 32-bit offsets below the out-of-range marker -- and a reduction deep enough to pay for writing
 // the piece images: 3x3 taps on at least 128 channels (taps * Cin >= 1152) over at least 2048 output rows.  Measured per layer
 // (tools/conv_layers.py): the 1x1 Skip convolutions and the 4x4 / 8x8 layers lose (D 128 Skip 77 -> 220 us), everything from
 // 16x16 Conv1 up gains.  planes_shape_ok() is what the PLAN sizes the workspace by (shapes only: plans are cached per shape);
 // the launch also needs 16 B aligned operands.
 bool planes_shape_ok(const igan_conv2d_params* p, const FwdTile& t, int Mmax) {
-    static const bool planes = getenv("IGAN_CONV_PLANES") && atoi(getenv("IGAN_CONV_PLANES")) == 1;
-    if (!planes || t.BM != 128 || t.BN != 128 || p->Cin % BK != 0) return false;
+    if (!planes_enabled() || t.BM != 128 || t.BN != 128 || p->Cin % BK != 0) return false;
     if (p->KH * p->KW == 1 || (long long)p->KH * p->KW * p->Cin < 1152 || Mmax < 2048) return false;      // 1x1: the Skip layers and the nearest-neighbour distance GEMM stay on the fp32 instruction
     if ((long long)p->N * p->OH * p->OW >= (1LL << 24)) return false;
     if ((long long)p->N * p->H * p->W * p->Cin * 6 >= 0x7FFFFF00LL || (long long)p->KH * p->KW * p->Cin * p->Cout * 6 >= 0x7FFFFF00LL) return false;
@@ -2223,6 +2228,7 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
     const bool vec = a.vecA && a.vecB && (a.in_scale == nullptr || a.vecS);
     bool launched = false;
     if (planes) {       // bf16-piece form: write the two piece images, then the tile kernel
+        IGAN_REQUIRE(p->x_pieces == nullptr || p->x_pieces_bytes == planes_x_floats(p) * 4, "conv2d: x_pieces is not the image of this x (x_pieces_bytes != N*H*W*Cin*6)");
         const unsigned short* xp = reinterpret_cast<const unsigned short*>(p->x_pieces);
         unsigned short* wp = reinterpret_cast<unsigned short*>(p->workspace + partial_floats + planes_x_floats(p));
         const int cpp = p->Cin / PK;
@@ -2354,9 +2360,8 @@ int wgrad_splits(const igan_conv2d_wgrad_params* p) {
 // 3x3 filters between at least 128 channels on each side (the 128x128 tile), channel counts in whole 32s, a pixel axis of at least
 // 2048, both piece images below the out-of-range marker.
 bool wgrad_planes_shape_ok(const igan_conv2d_wgrad_params* p) {
-    static const bool planes = getenv("IGAN_CONV_PLANES") && atoi(getenv("IGAN_CONV_PLANES")) == 1;
-    static const bool wg = !(getenv("IGAN_WGRAD_PLANES") && atoi(getenv("IGAN_WGRAD_PLANES")) == 0);      // A/B switch inside the variant
-    if (!planes || !wg || p->KH * p->KW == 1 || p->Cin < 128 || p->Cout < 128 || p->Cin % 32 != 0 || p->Cout % 32 != 0) return false;
+    static const bool wg = !(getenv("IGAN_WGRAD_PLANES") && atoi(getenv("IGAN_WGRAD_PLANES")) == 0);      // A/B switch inside the piece form
+    if (!planes_enabled() || !wg || p->KH * p->KW == 1 || p->Cin < 128 || p->Cout < 128 || p->Cin % 32 != 0 || p->Cout % 32 != 0) return false;
     if ((long long)p->N * p->OH * p->OW < 2048 * (long long)p->up * p->up) return false;
     if ((long long)p->N * p->H * p->W * p->Cin * 6 >= 0x7FFFFF00LL || (long long)p->N * p->OH * p->OW * p->Cout * 6 >= 0x7FFFFF00LL) return false;
     return true;
@@ -2380,6 +2385,20 @@ extern "C" int igan_conv2d_wgrad_plan(const igan_conv2d_wgrad_params* p, int* sp
     *workspace_floats = (s > 1) ? (size_t)s * p->KH * p->KW * p->Cin * p->Cout : 0;
     if (wgrad_planes_shape_ok(p))       // the piece images of x and dy follow the partial filters
         *workspace_floats += wgrad_planes_x_floats(p) + wgrad_planes_dy_floats(p);
+    return IGAN_OK;
+}
+
+// Which kernel family igan_conv2d_wgrad() runs for these parameters (host-only, for the profiling tools; ABI v6).
+extern "C" int igan_conv2d_wgrad_kernel_name(const igan_conv2d_wgrad_params* p, char* buf, int buflen) {
+    using namespace igan;
+    IGAN_REQUIRE(p && buf && buflen > 0, "conv2d_wgrad_kernel_name: null argument");
+    if (int rc = wgrad_geometry_check(p)) return rc;
+    const char* name = "conv_wgrad_kernel";
+    if (is_small_dense_wgrad(p)) name = "dense_small_wgrad_kernel";
+    else if (thin_wgrad_kind(p)) name = "thin_wgrad_kernel";
+    else if (wgrad_planes_shape_ok(p) && (((uintptr_t)p->x | (uintptr_t)p->dy | (uintptr_t)p->in_scale | (uintptr_t)p->out_scale | (uintptr_t)p->x_pieces | (uintptr_t)p->dy_pieces) & 15) == 0)
+        name = "conv_wgrad_planes_kernel";
+    snprintf(buf, (size_t)buflen, "%s", name);
     return IGAN_OK;
 }
 
@@ -2434,6 +2453,8 @@ extern "C" int igan_conv2d_wgrad(igan_stream_t stream_, const igan_conv2d_wgrad_
     const size_t partial_floats = (splits > 1) ? (size_t)splits * wsize : 0;
     if (wgrad_planes_shape_ok(p) && p->workspace != nullptr && (((uintptr_t)p->workspace | (uintptr_t)p->x | (uintptr_t)p->dy | (uintptr_t)p->in_scale | (uintptr_t)p->out_scale | (uintptr_t)p->x_pieces | (uintptr_t)p->dy_pieces) & 15) == 0 &&
         p->workspace_floats >= partial_floats + wgrad_planes_x_floats(p) + wgrad_planes_dy_floats(p)) {
+        IGAN_REQUIRE(p->x_pieces == nullptr || p->x_pieces_bytes == wgrad_planes_x_floats(p) * 4, "conv2d_wgrad: x_pieces is not the image of this x (x_pieces_bytes != N*H*W*Cin*6)");
+        IGAN_REQUIRE(p->dy_pieces == nullptr || p->dy_pieces_bytes == wgrad_planes_dy_floats(p) * 4, "conv2d_wgrad: dy_pieces is not the image of this dy (dy_pieces_bytes != N*OH*OW*Cout*6)");
         const unsigned short* xp = reinterpret_cast<const unsigned short*>(p->x_pieces);
         const unsigned short* dyp = reinterpret_cast<const unsigned short*>(p->dy_pieces);
         const int cpa = p->Cin / PK, cpb = p->Cout / PK;
@@ -2475,6 +2496,16 @@ extern "C" int igan_conv2d_wgrad(igan_stream_t stream_, const igan_conv2d_wgrad_
         IGAN_LAUNCH_CHECK("conv2d_wgrad reduce launch");
     }
     return IGAN_OK;
+}
+
+extern "C" int igan_conv_pieces_wanted(int KH, int KW, int Cin, int Cout) {
+    using namespace igan;
+    return (planes_enabled() && KH * KW > 1 && Cin >= 128 && Cout >= 128 && Cin % 32 == 0 && Cout % 32 == 0) ? 1 : 0;
+}
+
+extern "C" int igan_pieces_image_ok(int N, int HW, int C) {
+    using namespace igan;
+    return (planes_enabled() && C >= 128 && C % 32 == 0 && (long long)N * HW >= 2048 && (long long)N * HW * C * 6 < 0x7FFFFF00LL) ? 1 : 0;
 }
 
 extern "C" int igan_to_pieces(igan_stream_t stream_, const float* x, const float* scale, void* out, int N, int HW, int C) {

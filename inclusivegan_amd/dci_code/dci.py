@@ -37,6 +37,7 @@ class DCI(object):
         self._norms = None
         self.cand_chunk = 8192      # candidates folded per kernel pass
         self.query_chunk = 4096     # queries per kernel pass
+        self.rerank_bytes = 1 << 30 # largest fp64 block the exact re-rank of query_device_k gathers at once
 
     @property
     def dim(self):
@@ -127,15 +128,62 @@ class DCI(object):
                                        best_d2[q0:q0 + self.query_chunk], best_idx[q0:q0 + self.query_chunk], c0)
         return unpack_best(best_d2, best_idx)
 
-    def query_device_k(self, q, k, margin=8, rerank_chunk=64):
+    def _screen(self, qs, qn, keep):
+        """Top-`keep` candidates per query by the fp32 MFMA screening distance over all candidate batches -> (d2 [nq, keep] ascending, idx)."""
+        n = self.num_points
+        best_v = best_i = None
+        for c0 in range(0, n, self.cand_chunk):
+            cs = self._data[c0:c0 + self.cand_chunk]
+            dots = hip_ops.conv2d_raw(qs.reshape(qs.shape[0], self.dim, 1, 1), cs.reshape(1, 1, cs.shape[0], self.dim),
+                                      hip_ops.ConvGeom(1, 1, 1, 1, 0, 0), (1, 1), cs.shape[0], w_transposed=True).reshape(qs.shape[0], -1)
+            d2 = qn[:, None] + self._norms[c0:c0 + self.cand_chunk].double()[None, :] - 2.0 * dots.double()
+            d2 = torch.where(torch.isfinite(d2), d2, torch.full_like(d2, float('inf')))
+            ci = torch.arange(c0, c0 + cs.shape[0], device=self.device)[None, :].expand_as(d2)
+            if best_v is not None:
+                d2 = torch.cat([best_v, d2], dim=1)
+                ci = torch.cat([best_i, ci], dim=1)
+            v, j = torch.topk(d2, min(keep, d2.shape[1]), dim=1, largest=False)
+            best_v, best_i = v, torch.gather(ci, 1, j)
+        return best_v, best_i
+
+    def _rerank(self, qs, cand_i, k, rerank_chunk):
+        """Exact fp64 squared distances (direct differences, compute_dist of dci_code/src/util.c:62-69) of the listed candidates,
+        ordered by (distance, index) -> (e [nq, k], idx [nq, k]).  The query rows per pass are sized so that the gathered
+        [rows, keep, dim] fp64 block stays inside `self.rerank_bytes`."""
+        keep = int(cand_i.shape[1])
+        rows = max(1, min(rerank_chunk, self.rerank_bytes // max(1, keep * self.dim * 8)))
+        es, iis = [], []
+        for r0 in range(0, qs.shape[0], rows):
+            qq = qs[r0:r0 + rows].double()
+            ii = cand_i[r0:r0 + rows]
+            if keep * self.dim * 8 > self.rerank_bytes:          # one row does not fit either: walk the candidates in slabs
+                step = max(1, self.rerank_bytes // (self.dim * 8))
+                e = torch.cat([((self._data[ii[0, c0:c0 + step]].double() - qq[0][None, :]) ** 2).sum(dim=1) for c0 in range(0, keep, step)])[None, :]
+            else:
+                diff = self._data[ii.reshape(-1)].double().reshape(ii.shape[0], ii.shape[1], self.dim) - qq[:, None, :]
+                e = (diff * diff).sum(dim=2)
+            e = torch.where(torch.isfinite(e), e, torch.full_like(e, float('inf')))
+            order = torch.argsort(ii, dim=1, stable=True)                       # lower index first among equal distances
+            e, ii = torch.gather(e, 1, order), torch.gather(ii, 1, order)
+            order = torch.argsort(e, dim=1, stable=True)
+            es.append(torch.gather(e, 1, order)[:, :k]); iis.append(torch.gather(ii, 1, order)[:, :k])
+        return torch.cat(es), torch.cat(iis)
+
+    def query_device_k(self, q, k, margin=8, rerank_chunk=64, max_keep=1024):
         """k > 1 neighbours (the exclusive IMLE assignment asks for num_samples_factor of them, training_loop.py:386):
         (int64 idx [nq, k], fp64 Euclidean dist [nq, k]), ascending, ties to the lower index.  Screening on the fp32 MFMA
         products keeps the k + margin best candidates per query over all candidate batches; those are then measured exactly
-        (direct differences in fp64, compute_dist of dci_code/src/util.c:62-69) and re-ranked by torch ops (a non-default path: the
-        reference's default is k = 1).  The short list is PROVEN sufficient before it is trusted: every candidate that was
-        screened out has an approximate squared distance of at least the worst kept one, hence an exact one of at least that
-        minus the screening error bound tol * (|q|^2 + max |c|^2) (the 1-NN kernel's nn1_tol); if that does not exceed the exact
-        k-th distance found, the margin is quadrupled and the chunk is searched again (up to keeping every candidate)."""
+        (direct differences in fp64) and re-ranked by torch ops (a non-default path: the reference's default is k = 1).
+
+        The short list is CHECKED before it is trusted: every candidate that was screened out has a screening distance of at
+        least the worst kept one, hence an exact one of at least that minus the screening error tol * (|q|^2 + max |c|^2).  `tol`
+        is the 1-NN kernel's nn1_tol = 2^-22 sqrt(dim): a STATISTICAL bound on the rounding error of a dim-long fp32 dot product
+        (random-walk growth, ~4 standard deviations), not the worst case dim * 2^-24 -- the same assumption the 1-NN screening
+        makes.  Queries whose check fails are searched again with four times the margin (only those queries; the margin always
+        grows).  Past `max_keep` kept candidates -- near-tied candidates, e.g. a collapsed generator -- the list is no longer
+        widened: the exact k-th distance already found bounds the true one from above, so only candidates whose screening
+        distance lies within the slack of it can matter; they are selected by threshold and measured exactly in slabs, which
+        terminates for any input and keeps the fp64 blocks inside `rerank_bytes`."""
         nq = int(q.shape[0])
         n = self.num_points
         out_i = torch.empty((nq, k), device=self.device, dtype=torch.int64)
@@ -143,48 +191,57 @@ class DCI(object):
         tol = max(2.0 ** -22 * float(np.sqrt(self.dim)), 1e-6)
         cmax = float(self._norms.max()) if n else 0.0
         self.last_margins = []
+        self.last_threshold_queries = 0
         for q0 in range(0, nq, self.query_chunk):
-            qs = q[q0:q0 + self.query_chunk]
-            qn = hip_ops.row_sqnorm_raw(qs).double()
-            m = margin
-            while True:
+            qs_all = q[q0:q0 + self.query_chunk]
+            todo = torch.arange(qs_all.shape[0], device=self.device)
+            m = max(int(margin), 0)
+            while todo.numel():
+                qs = qs_all[todo]
+                qn = hip_ops.row_sqnorm_raw(qs).double()
                 keep = min(n, k + m)
-                best_v = None
-                best_i = None
-                for c0 in range(0, n, self.cand_chunk):
-                    cs = self._data[c0:c0 + self.cand_chunk]
-                    dots = hip_ops.conv2d_raw(qs.reshape(qs.shape[0], self.dim, 1, 1), cs.reshape(1, 1, cs.shape[0], self.dim),
-                                              hip_ops.ConvGeom(1, 1, 1, 1, 0, 0), (1, 1), cs.shape[0], w_transposed=True).reshape(qs.shape[0], -1)
-                    d2 = qn[:, None] + self._norms[c0:c0 + self.cand_chunk].double()[None, :] - 2.0 * dots.double()
-                    d2 = torch.where(torch.isfinite(d2), d2, torch.full_like(d2, float('inf')))
-                    ci = torch.arange(c0, c0 + cs.shape[0], device=self.device)[None, :].expand_as(d2)
-                    if best_v is not None:
-                        d2 = torch.cat([best_v, d2], dim=1)
-                        ci = torch.cat([best_i, ci], dim=1)
-                    v, j = torch.topk(d2, min(keep, d2.shape[1]), dim=1, largest=False)
-                    best_v, best_i = v, torch.gather(ci, 1, j)
-                # exact fp64 distances of the survivors, re-ranked by (distance, index)
-                es, iis = [], []
-                for r0 in range(0, qs.shape[0], rerank_chunk):
-                    qq = qs[r0:r0 + rerank_chunk].double()
-                    ii = best_i[r0:r0 + rerank_chunk]
-                    diff = self._data[ii.reshape(-1)].double().reshape(ii.shape[0], ii.shape[1], self.dim) - qq[:, None, :]
-                    e = (diff * diff).sum(dim=2)
-                    e = torch.where(torch.isfinite(e), e, torch.full_like(e, float('inf')))
-                    order = torch.argsort(ii, dim=1, stable=True)                       # lower index first among equal distances
-                    e, ii = torch.gather(e, 1, order), torch.gather(ii, 1, order)
-                    order = torch.argsort(e, dim=1, stable=True)
-                    es.append(torch.gather(e, 1, order)[:, :k]); iis.append(torch.gather(ii, 1, order)[:, :k])
-                e_k, i_k = torch.cat(es), torch.cat(iis)
+                best_v, best_i = self._screen(qs, qn, keep)
+                e_k, i_k = self._rerank(qs, best_i, k, rerank_chunk)
                 # sufficiency: no screened-out candidate can be closer than the k-th exact distance
-                floor = best_v[:, -1] - tol * (qn + cmax)
-                if keep >= n or bool((floor > e_k[:, -1]).all()):
+                slack = tol * (qn + cmax)
+                ok = (best_v[:, -1] - slack > e_k[:, -1]) if keep < n else torch.ones_like(qn, dtype=torch.bool)
+                done = todo[ok]
+                out_i[q0 + done] = i_k[ok]
+                out_d[q0 + done] = torch.sqrt(e_k[ok])
+                self.last_margins.append(m)
+                bad = ~ok
+                if not bool(bad.any()):
                     break
-                m *= 4
-            self.last_margins.append(m)
-            out_i[q0:q0 + qs.shape[0]] = i_k
-            out_d[q0:q0 + qs.shape[0]] = torch.sqrt(e_k)
+                todo = todo[bad]
+                m = max(4 * m, 8)
+                if k + m > max_keep:         # stop widening: threshold selection against the exact k-th distance found so far
+                    self._threshold_rerank(qs_all, todo, q0, e_k[bad][:, -1] + slack[bad], k, out_i, out_d)
+                    self.last_threshold_queries += int(todo.numel())
+                    break
         return out_i, out_d
+
+    def _threshold_rerank(self, qs_all, todo, q0, limit, k, out_i, out_d):
+        """For each listed query: every candidate whose screening distance is <= limit (the exact k-th distance of a valid short
+        list plus the screening slack -- the true k nearest are among them), measured exactly slab by slab, best k kept."""
+        n = self.num_points
+        step = max(1, self.rerank_bytes // (self.dim * 8))
+        for t, lim in zip(todo.tolist(), limit.tolist()):
+            qrow = qs_all[t:t + 1]
+            qn = hip_ops.row_sqnorm_raw(qrow).double()
+            sel = []
+            for c0 in range(0, n, self.cand_chunk):
+                cs = self._data[c0:c0 + self.cand_chunk]
+                dots = hip_ops.conv2d_raw(qrow.reshape(1, self.dim, 1, 1), cs.reshape(1, 1, cs.shape[0], self.dim),
+                                          hip_ops.ConvGeom(1, 1, 1, 1, 0, 0), (1, 1), cs.shape[0], w_transposed=True).reshape(-1)
+                d2 = qn[0] + self._norms[c0:c0 + self.cand_chunk].double() - 2.0 * dots.double()
+                sel.append(torch.nonzero(~(d2 > lim)).reshape(-1) + c0)        # NaN / inf screening values stay in (measured exactly below)
+            ii = torch.cat(sel)
+            qq = qrow[0].double()
+            e = torch.cat([((self._data[ii[c0:c0 + step]].double() - qq[None, :]) ** 2).sum(dim=1) for c0 in range(0, ii.numel(), step)])
+            e = torch.where(torch.isfinite(e), e, torch.full_like(e, float('inf')))
+            order = torch.argsort(e, stable=True)[:k]                          # ii ascending already: ties go to the lower index
+            out_i[q0 + t] = ii[order]
+            out_d[q0 + t] = torch.sqrt(e[order])
 
     def clear(self):
         self._data = None

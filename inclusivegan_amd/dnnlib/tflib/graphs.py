@@ -31,6 +31,20 @@ def validation_enabled():
     return os.environ.get('IGAN_GRAPH_VALIDATE', '1') != '0'
 
 
+def runtime_info():
+    """What the replay check ran against (recorded in the bench line's `hip_graphs`): the HIP build PyTorch was made for, the ROCm
+    release installed on the box, and the runtime's graph-packet-capture setting (inclusivegan_amd/__init__.py)."""
+    rel = None
+    for path in ('/opt/rocm/.info/version', '/opt/rocm/.info/version-dev'):
+        try:
+            with open(path) as f:
+                rel = f.read().strip()
+            break
+        except OSError:
+            pass
+    return dict(torch_hip=getattr(torch.version, 'hip', None), rocm_release=rel, packet_capture=os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE'))
+
+
 def _one_stream():
     return os.environ.get('IGAN_GRAPH_ONE_STREAM', '1') != '0'      # A/B switch (0 = warm up on the default stream, capture on torch's own side stream)
 
@@ -103,7 +117,14 @@ class GraphedStep:
         reset()
         src = tfutil.random_source()
         tapped = src.by_op.get(self.name) if hasattr(src, 'by_op') else None     # a TapRandom must keep pointing at the GRAPH's draws
-        b = snapshot(self._run_fn())
+        if _one_stream():       # the eager side runs where the warm-up calls and the capture ran (see side_stream)
+            side, cur = GraphedStep.side_stream(), torch.cuda.current_stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                b = snapshot(self._run_fn())
+            cur.wait_stream(side)
+        else:
+            b = snapshot(self._run_fn())
         if tapped is not None:
             src.by_op[self.name] = tapped
         reset()

@@ -513,26 +513,46 @@ def conv_flops(n, h, w, cin, oh, ow, cout, geom):
     return 2.0 * n * pairs * cin * cout
 
 
-PIECES = os.environ.get('IGAN_CONV_PLANES') == '1' and os.environ.get('IGAN_PIECES_SHARE', '1') != '0'
-# ^ the bf16-piece variant of the large 3x3 convolutions (csrc/conv2d_mfma.hip; off by default) with its piece images shared between the calls of
-#   a layer (IGAN_PIECES_SHARE=0: every convolution call writes its own images, A/B switch)
+PIECES_SHARE = os.environ.get('IGAN_PIECES_SHARE', '1') != '0'
+# ^ the bf16-piece form of the large 3x3 convolutions (csrc/conv2d_mfma.hip; the default since round 4, IGAN_CONV_PLANES=0 switches it off inside
+#   the library) keeps its piece images shared between the calls of a layer (IGAN_PIECES_SHARE=0: every convolution call writes its own, A/B switch)
+
+_pieces_rule = {}
 
 
 def pieces_wanted(geom, cin, cout):
-    """Will the convolution calls of a layer with this filter take the piece form (so that writing ONE shared image pays)?  The shape
-    rules of csrc/conv2d_mfma.hip (planes_shape_ok / wgrad_planes_shape_ok) that do not depend on the batch: 3x3 taps, both channel
-    counts at least 128 and whole 32s.  (A call the library then runs in fp32 after all simply ignores the image.)"""
-    return PIECES and geom.kh * geom.kw > 1 and cin >= 128 and cout >= 128 and cin % 32 == 0 and cout % 32 == 0
+    """Will the convolution calls of a layer with this filter take the piece form (so that writing ONE shared image pays)?  The LIBRARY answers
+    (igan_conv_pieces_wanted: the batch-independent part of planes_shape_ok / wgrad_planes_shape_ok), cached per filter shape -- the rules are
+    not restated here.  (A call the library then runs in fp32 after all simply ignores the image.)"""
+    if not PIECES_SHARE:
+        return False
+    key = (geom.kh, geom.kw, int(cin), int(cout))
+    hit = _pieces_rule.get(key)
+    if hit is None:
+        hit = _pieces_rule[key] = bool(_abi.get_plugin().igan_conv_pieces_wanted(*key))
+    return hit
+
+
+class PieceImage:
+    """A piece image with its byte size: the library checks the size against the tensor it is claimed to be the image of (ABI v6)."""
+    __slots__ = ('buf', 'nbytes')
+
+    def __init__(self, buf, nbytes):
+        self.buf, self.nbytes = buf, nbytes
+
+    def data_ptr(self):
+        return self.buf.data_ptr()
 
 
 def to_pieces(x, scale=None):
-    """Piece image of a channels-last tensor (times scale[n, c]) for the bf16-piece variant: written once when several convolution
+    """Piece image of a channels-last tensor (times scale[n, c]) for the bf16-piece form: written once when several convolution
     calls consume the same tensor (dy in the data and the weight gradient, x in the forward pass and the weight gradient).
-    Returns None when the variant is off or the tensor is not of a kind the piece kernels take (they then make their own, or run fp32)."""
-    if not PIECES or _is_meta(x) or x.dim() != 4:
+    Returns None when the form is off or the tensor is not of a kind the piece kernels take (igan_pieces_image_ok; they then make their
+    own image, or run fp32)."""
+    if not PIECES_SHARE or _is_meta(x) or x.dim() != 4:
         return None
     n, c, h, w = x.shape
-    if c < 128 or c % 32 != 0 or n * h * w < 2048 or n * h * w * c * 6 >= 0x7FFFFF00:
+    if not _abi.get_plugin().igan_pieces_image_ok(int(n), int(h * w), int(c)):
         return None
     x = nhwc(x)
     if scale is not None:
@@ -540,8 +560,12 @@ def to_pieces(x, scale=None):
     out = torch.empty((n * h * w * c * 6 // 4,), device=x.device, dtype=torch.float32)
     if (x.data_ptr() | out.data_ptr() | (scale.data_ptr() if scale is not None else 0)) & 15:
         return None
-    _abi.check(_abi.get_plugin().igan_to_pieces(_stream(), _ptr(x), (_ptr(scale) if scale is not None else None), _ptr(out), n, h * w, c))
-    return out
+    launch = lambda: _abi.check(_abi.get_plugin().igan_to_pieces(_stream(), _ptr(x), (_ptr(scale) if scale is not None else None), _ptr(out), n, h * w, c))
+    if stamp_log is not None:       # part of the piece form's cost: counted in the conv family's time (no FLOPs of its own)
+        stamp_log.bracket('to_planes_kernel (shared image)', 0.0, launch, shape='%-12s N%-3d %3dx%-3d C%-4d' % ('pieces', n, h, w, c))
+    else:
+        launch()
+    return PieceImage(out, n * h * w * c * 6)
 
 
 def conv2d_raw(x, w, geom, out_hw, cout, w_transposed=False, in_scale=None, out_scale=None, bias=None, act=None, noise=None, strength=None, x_pieces=None):
@@ -574,8 +598,9 @@ def conv2d_raw(x, w, geom, out_hw, cout, w_transposed=False, in_scale=None, out_
         w_transposed=1 if w_transposed else 0, splits=1, alpha=float(geom.alpha),
         bias=(bias.data_ptr() if bias is not None else None), act=(int(act[0]) if act is not None else 0),
         act_alpha=(float(act[1]) if act is not None else 0.0), act_gain=(float(act[2]) if act is not None else 1.0))
-    if x_pieces is not None:    # bf16-piece variant: the image of x * in_scale, written once by to_pieces() for several consumers
+    if x_pieces is not None:    # bf16-piece form: the image of x * in_scale, written once by to_pieces() for several consumers
         p.x_pieces = x_pieces.data_ptr()
+        p.x_pieces_bytes = x_pieces.nbytes
     if noise is not None:       # epilogue noise: [N or 1, 1, OH, OW] contiguous + device scalar strength (needs act)
         noise = noise.contiguous()
         _require_cuda_f32(noise, strength)
@@ -651,8 +676,10 @@ def conv2d_wgrad_raw(x, dy, geom, in_scale=None, out_scale=None, x_pieces=None, 
         pad_y=geom.pad_y, pad_x=geom.pad_x, splits=1, alpha=float(geom.alpha))
     if x_pieces is not None:
         p.x_pieces = x_pieces.data_ptr()
+        p.x_pieces_bytes = x_pieces.nbytes
     if dy_pieces is not None:
         p.dy_pieces = dy_pieces.data_ptr()
+        p.dy_pieces_bytes = dy_pieces.nbytes
     key = (n, h, wd, cin, oh, ow, cout, geom, in_scale is not None, out_scale is not None)
     plan = _wplan_cache.get(key)
     if plan is None:
@@ -669,7 +696,9 @@ def conv2d_wgrad_raw(x, dy, geom, in_scale=None, out_scale=None, x_pieces=None, 
     if plan[0] > 1:
         p.splits = plan[0]
     if stamp_log is not None:
-        stamp_log.bracket('conv_wgrad_kernel (+ reduce)', conv_flops(n, h, wd, cin, oh, ow, cout, geom),
+        buf = ctypes.create_string_buffer(128)
+        _abi.check(lib.igan_conv2d_wgrad_kernel_name(ctypes.byref(p), buf, 128))
+        stamp_log.bracket(buf.value.decode() + ' (+ reduce)', conv_flops(n, h, wd, cin, oh, ow, cout, geom),
                           lambda: _abi.check(lib.igan_conv2d_wgrad(_stream(), ctypes.byref(p))),
                           shape='%-12s N%-3d %3dx%-3d C%-4d -> %3dx%-3d C%-4d k%d s%d u%d splits %d' % (
                               'wgrad' + ('+scale' if (in_scale is not None or out_scale is not None) else ''), n, h, wd, cin, oh, ow, cout, geom.kh, geom.stride, geom.up, plan[0]))

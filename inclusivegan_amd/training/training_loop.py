@@ -489,6 +489,33 @@ def training_loop(
     D_grad_step = graphs.GraphedStep(D_grad, use_graphs, eager_calls=1, name='D')
     D_reg_step = graphs.GraphedStep(D_reg_grad, use_graphs, eager_calls=1, name='D_reg')
 
+    graph_checks = []
+
+    def validate_graphs(reason):
+        """check_replay() of every captured op (the others replayed in front): after capture, after any re-capture (GraphedStep.generation)
+        and on every network-snapshot tick of a long run -- the fault this guards against depended on what else had run
+        (profiles/r03_graph_packet_capture.txt).  An op whose graph disagrees runs eagerly from then on.  State, gradients and the
+        generator are left as found; the summary accumulators the extra executions touched are the caller's to flush."""
+        if not use_graphs or not graphs.validation_enabled():
+            return True
+        ok = True
+        state = [G.vars['dlatent_avg']] + ([G.pl_mean_var] if hasattr(G, 'pl_mean_var') else [])
+        all_steps = (G_grad_step, G_reg_step, D_grad_step, D_reg_step)
+        for step, net in zip(all_steps, (G, G, D, D)):
+            if step.graph is None or not step.enabled:
+                continue
+            bad = step.check_replay(state, lambda out, net=net: [out, net.flat_grads], context=[s for s in all_steps if s is not step] if os.environ.get('IGAN_GRAPH_VALIDATE_CONTEXT', '1') != '0' else [])
+            flag = torch.tensor([1.0 if bad else 0.0], device=device)
+            if world > 1:       # every rank takes the same decision (the ops contain collectives)
+                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+            if bool(flag.item()):
+                ok = False
+                print('WARNING: hipGraph of training op %r does not reproduce its eager execution (%s; tensor index, max |diff|: %s); '
+                      'running this op eagerly' % (step.name, reason, bad), flush=True)
+                step.enabled = False
+        graph_checks.append(dict(when=reason, faithful=ok))
+        return ok
+
     if use_graphs:
         # Build all four graphs before the first iteration: one eager dry run of each op's device work
         # (creates every lazily allocated piece of state), then capture.  No optimizer update is applied;
@@ -501,24 +528,9 @@ def training_loop(
             step()      # capture + first replay
         # Every captured op must reproduce its own eager execution bit for bit (same inputs, same state, same generator
         # state) before the run is allowed to depend on it; a graph that does not is not replayed -- its op runs eagerly.
-        graphs_ok = True
-        if graphs.validation_enabled():
-            state = [G.vars['dlatent_avg']] + ([G.pl_mean_var] if hasattr(G, 'pl_mean_var') else [])
-            all_steps = (G_grad_step, G_reg_step, D_grad_step, D_reg_step)
-            for step, net in zip(all_steps, (G, G, D, D)):
-                if step.graph is None:
-                    continue
-                bad = step.check_replay(state, lambda out, net=net: [out, net.flat_grads], context=[s for s in all_steps if s is not step] if os.environ.get('IGAN_GRAPH_VALIDATE_CONTEXT', '1') != '0' else [])
-                flag = torch.tensor([1.0 if bad else 0.0], device=device)
-                if world > 1:       # every rank takes the same decision (the ops contain collectives)
-                    torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
-                if bool(flag.item()):
-                    graphs_ok = False
-                    print('WARNING: hipGraph of training op %r does not reproduce its eager execution (tensor index, max |diff|: %s); '
-                          'running this op eagerly' % (step.name, bad), flush=True)
-                    step.enabled = False
+        graphs_ok = validate_graphs('after capture')
         if 'on_graphs' in hooks:
-            hooks['on_graphs'](dict(captured=True, validated=graphs.validation_enabled(), faithful=graphs_ok))
+            hooks['on_graphs'](dict(captured=True, validated=graphs.validation_enabled(), faithful=graphs_ok, checks=graph_checks, runtime=graphs.runtime_info()))
         with torch.no_grad():
             for n, v in saved.items():
                 G.vars[n].copy_(v)
@@ -656,7 +668,7 @@ def training_loop(
             cur_nimg += mb * 2
             running_mb_counter += 1
             if 'on_iteration' in hooks:
-                if hooks['on_iteration'](dict(cur_nimg=cur_nimg, iteration=running_mb_counter, G=G, D=D, Gs=Gs)):
+                if hooks['on_iteration'](dict(cur_nimg=cur_nimg, iteration=running_mb_counter, G=G, D=D, Gs=Gs, revalidate_graphs=validate_graphs)):
                     stop = True
                     break
 
@@ -701,6 +713,9 @@ def training_loop(
                     misc.save_pkl((G, D, Gs), pkl, reference_layout=True, build_module_src=module_src)
                     metrics.run(pkl, run_dir=run_dir, data_dir=data_dir, dataset_args=ds_args, mirror_augment=mirror_augment,
                                 num_gpus=min([2, num_gpus]), tf_config=tf_config, device=device)                   # :519
+            if network_snapshot_ticks is not None and cur_tick > 0 and cur_tick % max(network_snapshot_ticks, 1) == 0 and use_graphs:
+                validate_graphs('tick %d' % cur_tick)      # long runs: the replays are re-checked at the network-snapshot cadence
+                autosummary_mod.flush()                    # the check's extra executions do not reach the next tick's statistics
             metrics.update_autosummaries()                                                                        # :522
             torch.cuda.synchronize()
             tick_start_time = time.time()

@@ -107,6 +107,14 @@ def mode_record(rank, world, outdir):
     torch.save(log, os.path.join(outdir, 'rank%d.pt' % rank))
 
 
+def mode_record5(rank, world, outdir):
+    """Two iterations of the real loop at BASELINE config 5's own size (128x128, fmap_base 8192, minibatch_gpu 3, attribute mask) with every
+    op recorded, for tests/test_gpu_loop_parity.py::test_config5_two_ranks_at_its_own_size_match_oracle_towers."""
+    from tests.test_gpu_loop_parity import record_loop, config5_kwargs
+    log = record_loop(2, config5_kwargs(world), keep_state=(rank == 0))
+    torch.save(log, os.path.join(outdir, 'rank%d.pt' % rank))
+
+
 def mode_config5(rank, world, outdir):
     """BASELINE config 5's shape at any world size: minibatch_gpu 3, CelebA-style 40 attribute labels, attribute AND-mask
     (one attribute here: the synthetic labels are Bernoulli(0.2), and an epoch must hold 2 * minibatch matches), a data_size
@@ -126,13 +134,14 @@ def mode_config5(rank, world, outdir):
             rec['slices'].append(dict(lat=feed['latents_rec_1'].cpu().numpy().copy(), lab=feed['labels_rec_1'].cpu().numpy().copy()))
 
     mb_gpu = int(os.environ.get('IGAN_TEST_MB_GPU', '3'))
+    res5, fmap5 = int(os.environ.get('IGAN_TEST_RES', RES)), int(os.environ.get('IGAN_TEST_FMAP', '256'))     # 128 / 8192 = config 5's own size
     res = TL.training_loop(
-        G_args=EasyDict(func_name='training.networks_stylegan2.G_main', fmap_base=256, architecture='skip'),
-        D_args=EasyDict(func_name='training.networks_stylegan2.D_stylegan2_feature', fmap_base=256, architecture='resnet'),
+        G_args=EasyDict(func_name='training.networks_stylegan2.G_main', fmap_base=fmap5, architecture='skip'),
+        D_args=EasyDict(func_name='training.networks_stylegan2.D_stylegan2_feature', fmap_base=fmap5, architecture='resnet'),
         G_opt_args=EasyDict(beta1=0.0, beta2=0.99, epsilon=1e-8), D_opt_args=EasyDict(beta1=0.0, beta2=0.99, epsilon=1e-8),
         G_loss_args=EasyDict(func_name='training.loss.G_logistic_ns_rec_interp_arb_pathreg', NN_rec_lpips_weight=2.5),
         D_loss_args=EasyDict(func_name='training.loss.D_logistic_r1', gamma=100),
-        dataset_args=EasyDict(resolution=RES, num_channels=3, label_size=40, label_kind='attributes'),
+        dataset_args=EasyDict(resolution=res5, num_channels=3, label_size=40, label_kind='attributes'),
         sched_args=EasyDict(minibatch_gpu_base=mb_gpu, minibatch_size_base=mb_gpu * world),
         tf_config={'rnd.np_random_seed': 1000}, total_kimg=1, data_size=480, init_staleness=10, num_samples_factor=2,
         knn_perturb_factor=0.05, candidate_batch_size=16, attr_interesting='Smiling', attr_names=list(imle.CELEBA_ATTRIBUTES),
@@ -149,7 +158,7 @@ def main():
     torch.cuda.set_device(0)
     if world > 1:
         torch.distributed.init_process_group('gloo', rank=rank, world_size=world)
-    {'exchange': mode_exchange, 'loop': mode_loop, 'record': mode_record, 'config5': mode_config5}[mode](rank, world, outdir)
+    {'exchange': mode_exchange, 'loop': mode_loop, 'record': mode_record, 'record5': mode_record5, 'config5': mode_config5}[mode](rank, world, outdir)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -89,15 +89,19 @@ def test_plans_are_host_only():
     big = _abi.Conv2DParams(x=16, w=16, y=16, N=6, H=128, W=128, Cin=128, OH=128, OW=128, Cout=128, KH=3, KW=3, stride=1, up=1, pad_y=1, pad_x=1)
     mid = _abi.Conv2DParams(x=16, w=16, y=16, N=18, H=32, W=32, Cin=256, OH=32, OW=32, Cout=256, KH=3, KW=3, stride=1, up=1, pad_y=1, pad_x=1)
     s, sl, ws = ctypes.c_int(), ctypes.c_int(), ctypes.c_size_t()
+    # the large 3x3 layers run in the bf16-piece form by default: their plans add the piece images of x and of the filter (6 B per element)
+    on = lib.igan_conv_pieces_wanted(3, 3, 128, 128)
+    assert on == (0 if os.environ.get('IGAN_CONV_PLANES') == '0' else 1)
+    img = lambda p: on * (p.N * p.H * p.W * p.Cin * 6 // 4 + p.KH * p.KW * p.Cin * p.Cout * 6 // 4)
     assert lib.igan_conv2d_plan(ctypes.byref(small), ctypes.byref(s), ctypes.byref(sl), ctypes.byref(ws)) == 0
     assert s.value > 1 and sl.value == 4 and ws.value == 4 * s.value * 128 * 128
     assert lib.igan_conv2d_plan(ctypes.byref(big), ctypes.byref(s), ctypes.byref(sl), ctypes.byref(ws)) == 0
-    assert s.value == 1 and sl.value == 0 and ws.value == 0
+    assert s.value == 1 and sl.value == 0 and ws.value == img(big)
     assert lib.igan_conv2d_plan(ctypes.byref(mid), ctypes.byref(s), ctypes.byref(sl), ctypes.byref(ws)) == 0
-    assert s.value > 1 and sl.value in (32, 288) and ws.value == sl.value * s.value * 128 * 128
+    assert s.value > 1 and sl.value in (32, 288) and ws.value == sl.value * s.value * 128 * 128 + img(mid)
     wg = _abi.Conv2DWgradParams(x=16, dy=16, dw=16, N=6, H=128, W=128, Cin=128, OH=128, OW=128, Cout=128, KH=3, KW=3, stride=1, up=1, pad_y=1, pad_x=1)
     assert lib.igan_conv2d_wgrad_plan(ctypes.byref(wg), ctypes.byref(s), ctypes.byref(ws)) == 0
-    assert s.value > 1 and ws.value == s.value * 9 * 128 * 128
+    assert s.value > 1 and ws.value == s.value * 9 * 128 * 128 + on * 2 * (6 * 128 * 128 * 128 * 6 // 4)
 
 
 def test_no_cpu_fallback():

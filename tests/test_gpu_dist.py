@@ -110,19 +110,23 @@ def test_bench_launches_its_own_ranks(cuda_device):
     assert d['value'] > 0 and abs(d['value'] - 12 / (d['ms_per_step'] * 1e-3)) < 1e-2 * d['value']
 
 
-def test_eight_rank_loop_at_config5_shape(cuda_device, tmp_path):
+@pytest.mark.parametrize('size', ['32x32_fmap256', '128x128_fmap8192'])
+def test_eight_rank_loop_at_config5_shape(cuda_device, tmp_path, size):
     """BASELINE config 5 (8 GPUs, minibatch_gpu 3, attribute-masked selection) as far as one GPU allows: EIGHT ranks on GPU 0 over
-    gloo run two iterations of the real loop.  Replicas end bit-identical; the ranks' slices tile the global minibatch (reals picked by
+    gloo run two iterations of the real loop -- at a reduced size and at config 5's own (128x128, fmap_base 8192: eight replicas of the
+    full networks and their captured graphs in one device's memory; the oracle comparison at that size is tests/test_gpu_loop_parity.py's).  Replicas end bit-identical; the ranks' slices tile the global minibatch (reals picked by
     the attribute mask, latents, labels); the refresh sharded over eight ranks + the two min-exchanges assign every real the same
     candidate as ONE process searching all candidates (same seeds; noise strengths are zero at initialisation, so the candidate
     images do not depend on the ranks' device generators)."""
     import numpy as np
     import torch
     world = 8
+    full = size.startswith('128')
+    env8 = dict(os.environ, IGAN_TEST_RES='128' if full else '32', IGAN_TEST_FMAP='8192' if full else '256')
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'dist_worker.py'), 'config5', str(r), str(world), str(port), str(tmp_path)],
-                              cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
-    outs = [p.communicate(timeout=1500) for p in procs]
+                              cwd=ROOT, env=env8, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=2400) for p in procs]
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, se[-3000:]
     recs = [torch.load(os.path.join(str(tmp_path), 'rank%d.pt' % r), weights_only=False) for r in range(world)]
@@ -142,7 +146,7 @@ def test_eight_rank_loop_at_config5_shape(cuda_device, tmp_path):
     # one process, the whole minibatch of 24: the same host stream, hence the same candidates -- and the same assignment
     single = tmp_path / 'single'
     single.mkdir()
-    env = dict(os.environ, IGAN_TEST_MB_GPU='24')
+    env = dict(env8, IGAN_TEST_MB_GPU='24')
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'dist_worker.py'), 'config5', '0', '1', str(port), str(single)], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]

@@ -249,6 +249,34 @@ def test_knn_short_list_is_widened_when_many_candidates_nearly_coincide(cuda_dev
     assert np.abs(dist.cpu().numpy() - np.take_along_axis(d, want, 1)).max() <= 1e-12 * d.max()
 
 
+def test_knn_collapsed_candidates_terminate_inside_the_memory_budget(cuda_device):
+    """a collapsed candidate set (every candidate within rounding of every other -- a mode-collapsed generator) makes the
+    sufficiency check fail however wide the short list is.  The search must still terminate, must not gather blocks beyond
+    `rerank_bytes`, must grow from margin 0, and must return the fp64 brute-force neighbours: past `max_keep` it selects by threshold
+    against the exact k-th distance found so far instead of keeping every candidate."""
+    from inclusivegan_amd.dci_code.dci import DCI
+    dev = cuda_device
+    rng = np.random.RandomState(11)
+    dim, nq, n, k = 3072, 5, 700, 4
+    base = rng.uniform(-1, 1, size=(1, dim)).astype(np.float32)
+    c = np.repeat(base, n, axis=0)
+    for i in range(n):                                            # differences of a few ulps: far inside the screening error
+        c[i, rng.randint(dim)] += np.float32(2.0 ** -20 * (1 + i % 7))
+    q = (base + rng.uniform(-1, 1, size=(nq, dim)).astype(np.float32) * np.float32(0.05)).astype(np.float32)
+    d = np.sqrt(((q[:, None, :].astype(np.float64) - c[None, :, :].astype(np.float64)) ** 2).sum(-1))
+    want = np.lexsort((np.broadcast_to(np.arange(n), d.shape), d), axis=1)[:, :k]
+    db = DCI(dim, device=dev)
+    db.rerank_bytes = 64 * dim * 8                                # 64 candidate rows per fp64 block
+    db.add(torch.from_numpy(c).to(dev))
+    torch.cuda.reset_peak_memory_stats(dev)
+    before = torch.cuda.memory_allocated(dev)
+    idx, dist = db.query_device_k(torch.from_numpy(q).to(dev), k, margin=0, max_keep=64)
+    assert db.last_margins[:3] == [0, 8, 32] and db.last_threshold_queries > 0
+    assert torch.cuda.max_memory_allocated(dev) - before < 64 << 20
+    assert np.array_equal(idx.cpu().numpy(), want)
+    assert np.abs(dist.cpu().numpy() - np.take_along_axis(d, want, 1)).max() <= 1e-12 * d.max()
+
+
 @pytest.mark.parametrize('case', [('G 128 Conv1', 6, 128, 128, 128, True), ('G 32 Conv1 (4 calls)', 24, 512, 32, 512, True), ('G 8 Conv1', 24, 512, 8, 512, False)],
                          ids=lambda c: c[0])
 def test_fused_synthesis_layer_against_fp64_samples_full_size(case, cuda_device):

@@ -36,7 +36,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RES = 32
 
 
-def loop_kwargs(fmap, B, world=1, data_size=48, label=None, **extra):
+def loop_kwargs(fmap, B, world=1, data_size=48, label=None, res=RES, **extra):
     from inclusivegan_amd.dnnlib import EasyDict
     label = label or dict(label_size=0)
     kw = dict(
@@ -45,7 +45,7 @@ def loop_kwargs(fmap, B, world=1, data_size=48, label=None, **extra):
         G_opt_args=EasyDict(beta1=0.0, beta2=0.99, epsilon=1e-8), D_opt_args=EasyDict(beta1=0.0, beta2=0.99, epsilon=1e-8),
         G_loss_args=EasyDict(func_name='training.loss.G_logistic_ns_rec_interp_arb_pathreg', NN_rec_lpips_weight=2.5),
         D_loss_args=EasyDict(func_name='training.loss.D_logistic_r1', gamma=100),
-        dataset_args=EasyDict(resolution=RES, num_channels=3, **label),
+        dataset_args=EasyDict(resolution=res, num_channels=3, **label),
         sched_args=EasyDict(minibatch_gpu_base=B, minibatch_size_base=B * world), tf_config={'rnd.np_random_seed': 1000},
         total_kimg=1, data_size=data_size, num_samples_factor=4, init_staleness=10, knn_perturb_factor=0.05, candidate_batch_size=64)
     kw.update(extra)
@@ -136,8 +136,8 @@ class TeacherForcedOracle:
     pre-op state.  `select(index, name, it)` chooses the ops that get the (expensive) oracle evaluation; the optimizer, moving
     average and state bookkeeping is checked on every op."""
 
-    def __init__(self, fmap, B, world=1, select=None, dtype=torch.float64):
-        self.fmap, self.B, self.world, self.dtype = fmap, B, world, dtype
+    def __init__(self, fmap, B, world=1, select=None, dtype=torch.float64, res=RES):
+        self.fmap, self.B, self.world, self.dtype, self.res = fmap, B, world, dtype, res
         self.select = select or (lambda j, name, it: True)
         self.ops = None
         self.j = 0
@@ -146,7 +146,7 @@ class TeacherForcedOracle:
 
     def start(self, init):
         from oracle.train_ops import TrainOps
-        cfg = dict(resolution=RES, num_channels=3, fmap_base=self.fmap, G_arch='skip', D_arch='resnet')
+        cfg = dict(resolution=self.res, num_channels=3, fmap_base=self.fmap, G_arch='skip', D_arch='resnet')
         self.init = init
         self.ops = TrainOps(init['G'], init['D'], init['G_layout'], init['D_layout'], init['lpips'], cfg, world=self.world, minibatch_gpu=self.B, dtype=self.dtype)
         self.pre = dict(G=self.ops.w['G'].copy(), D=self.ops.w['D'].copy(), Gs=self.ops.w['G'].copy())
@@ -329,6 +329,80 @@ def test_two_rank_graphed_loop_matches_oracle_towers(cuda_device, tmp_path):
         oracle.consume([r0, r1])
     oracle.finish(logs[0]['final'])
     print('worst deviations', oracle.worst)
+
+
+CONFIG5 = dict(res=128, fmap=8192, B=3, data_size=240, attr='Smiling', col=31)      # BASELINE config 5 at its own size (minibatch_gpu 3, attribute mask)
+
+
+def config5_kwargs(world, **extra):
+    from inclusivegan_amd.training import imle
+    c = CONFIG5
+    return loop_kwargs(c['fmap'], c['B'], world=world, data_size=c['data_size'], res=c['res'], label=dict(label_size=40, label_kind='attributes'),
+                       attr_interesting=c['attr'], attr_names=list(imle.CELEBA_ATTRIBUTES), num_samples_factor=2, candidate_batch_size=16, **extra)
+
+
+def test_config5_at_its_own_size_matches_oracle(cuda_device):
+    """BASELINE config 5 on one rank at ITS OWN size: 128x128, config-e width (fmap_base 8192), minibatch_gpu 3,
+    40 attribute labels with the attribute AND-mask (training_loop.py:416-424) choosing the reals, data_size divisible by
+    2 * minibatch (:338-340), the four training ops captured as hipGraphs.  Two iterations of training_loop(); every op kind
+    (G, G_reg, D, D_reg: iteration 1 runs all four) is evaluated by the fp64 oracle from the HIP path's pre-op state -- loss value,
+    gradient of every trainable, Adam update, pl_mean, dlatent_avg, Gs -- and the fed reals all carry the attribute."""
+    c = CONFIG5
+    fed = []
+
+    class Consumer(TeacherForcedOracle):
+        def __call__(self, rec):
+            super().__call__(rec)
+
+    oracle = Consumer(c['fmap'], c['B'], select=lambda j, name, it: it == 0, res=c['res'])
+    kw = config5_kwargs(1)
+    assert kw['data_size'] % (2 * c['B']) == 0
+    from inclusivegan_amd.dnnlib.tflib import tfutil
+    from inclusivegan_amd.training import training_loop as TL
+    orig = TL.imle.ImleSampler.next_batch
+
+    def next_batch(self, mb):
+        b = orig(self, mb)
+        fed.append({k: np.array(v) for k, v in b.items() if isinstance(v, np.ndarray)})
+        return b
+    TL.imle.ImleSampler.next_batch = next_batch
+    try:
+        log = record_loop(2, kw, consumer=oracle)
+    finally:
+        TL.imle.ImleSampler.next_batch = orig
+    oracle.finish(log['final'])
+    assert log['graphs']['captured'] and log['graphs']['faithful'], log['graphs']
+    assert [e[1] for e in oracle.evaluated] == ['G', 'G_reg', 'D', 'D_reg'], oracle.evaluated
+    assert len(fed) == 2
+    for b in fed:
+        assert b['reals_rec_1'].shape == (c['B'], 3, c['res'], c['res']) and b['labels_rec_1'].shape == (c['B'], 40)
+        assert bool((b['labels_rec_1'][:, c['col']] == 1).all()) and bool((b['labels_rec_2'][:, c['col']] == 1).all())      # the AND-mask selection
+    print('config 5 @128 world 1: worst deviations', oracle.worst)
+
+
+def test_config5_two_ranks_at_its_own_size_match_oracle_towers(cuda_device, tmp_path):
+    """Config 5's shape on TWO ranks (GPU 0, gloo) at 128x128 / fmap_base 8192 / minibatch_gpu 3 / attribute mask: two iterations,
+    replicas bit-identical, the ranks' slices tile the masked global minibatch, and the G and D ops of iteration 1 equal the oracle's
+    two towers with 1 / 2-scaled summed gradients (optimizer.py:186,199).  The RCCL leg itself needs more than one device."""
+    c = CONFIG5
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'dist_worker.py'), 'record5', str(r), '2', str(port), str(tmp_path)],
+                              cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=2400) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    logs = [torch.load(os.path.join(str(tmp_path), 'rank%d.pt' % r), weights_only=False) for r in range(2)]
+    for k in ('G', 'D', 'Gs', 'G_pow', 'D_pow'):
+        assert np.array_equal(logs[0]['final'][k], logs[1]['final'][k]), k
+    for a, b in zip([o for o in logs[0]['ops'] if o['name'] == 'G'], [o for o in logs[1]['ops'] if o['name'] == 'G']):
+        assert np.array_equal(np.concatenate([a['latents_rec_1'], b['latents_rec_1']]), a['global_latents_rec_1'].astype(np.float32))
+    oracle = TeacherForcedOracle(c['fmap'], c['B'], world=2, select=lambda j, name, it: it == 0 and name in ('G', 'D'), res=c['res'])
+    oracle.start(logs[0]['init'])
+    for r0, r1 in zip(logs[0]['ops'], logs[1]['ops']):
+        oracle.consume([r0, r1])
+    oracle.finish(logs[0]['final'])
+    assert [e[1] for e in oracle.evaluated] == ['G', 'D']
+    print('config 5 @128 world 2: worst deviations', oracle.worst)
 
 
 def test_packet_capture_fault_is_detected_by_the_replay_check(cuda_device):

@@ -1,6 +1,7 @@
-"""GPU: the bf16-piece form of the forward / data-gradient convolution (IGAN_CONV_PLANES=1, csrc/conv2d_mfma.hip
-conv_fwd_planes_kernel) against fp64.  It is a labelled VARIANT, not the product path: the switch is read
-once per process, so the checks run in a child process.  Tolerances are those of the exact-fp32 path's own full-size tests
+"""GPU: the bf16-piece form of the forward / data-gradient / weight-gradient convolution (csrc/conv2d_mfma.hip conv_fwd_planes_kernel,
+conv_wgrad_planes_kernel) against fp64.  Since round 4 it is the DEFAULT form of the large 3x3 layers (IGAN_CONV_PLANES=0 restores the
+fp32 instruction everywhere): the switch is read once per process, so the checks run in child processes with the
+switch stated explicitly either way.  Tolerances are those of the exact-fp32 path's own full-size tests
 (3e-6 relative to the output rms per element, tests/test_gpu_fullsize.py), plus the property that made the variant acceptable at
 all: no coherent shift of the outputs (|mean error| below 5e-8 rms; profiles/r03_bf16_split_rounding.txt)."""
 import os
@@ -176,3 +177,67 @@ def test_shared_piece_images_change_nothing(cuda_device):
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
         digs.append([l for l in r.stdout.splitlines() if l.startswith('DIGESTS ')][-1])
     assert digs[0] == digs[1], digs
+
+
+FP32_CHILD = r'''
+import ctypes, sys
+import torch
+sys.path.insert(0, %r)
+from inclusivegan_amd import hip_ops, _abi
+dev = torch.device('cuda', 0)
+lib = _abi.get_plugin()
+assert lib.igan_conv_pieces_wanted(3, 3, 256, 256) == int(sys.argv[1]) and lib.igan_conv_pieces_wanted(1, 1, 256, 256) == 0 and lib.igan_conv_pieces_wanted(3, 3, 64, 256) == 0
+assert lib.igan_pieces_image_ok(4, 1024, 256) == int(sys.argv[1]) and lib.igan_pieces_image_ok(1, 1024, 256) == 0 and lib.igan_pieces_image_ok(4, 1024, 144) == 0
+p = _abi.Conv2DParams(x=1 << 20, w=1 << 20, y=1 << 20, in_scale=None, out_scale=None, workspace=None, workspace_floats=0, N=4, H=32, W=32, Cin=256, OH=32, OW=32,
+                      Cout=256, KH=3, KW=3, stride=1, up=1, pad_y=1, pad_x=1, w_transposed=0, splits=1, alpha=1.0, bias=None, act=0, act_alpha=0.0, act_gain=1.0)
+buf = ctypes.create_string_buffer(128)
+_abi.check(lib.igan_conv2d_kernel_name(ctypes.byref(p), buf, 128))
+print('KERNEL ' + buf.value.decode())
+g = torch.Generator().manual_seed(3)
+x = torch.randn(4, 256, 32, 32, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+w = (torch.randn(3, 3, 256, 256, generator=g) / 48.0).to(dev)
+geom = hip_ops.ConvGeom(3, 3, 1, 1, 1, 1)
+y = hip_ops.conv2d_raw(x, w, geom, (32, 32), 256)
+want = torch.nn.functional.conv2d(x.double().cpu(), w.double().cpu().permute(3, 2, 0, 1), padding=1)
+err = float((y.double().cpu() - want).abs().max() / want.abs().max())
+assert err < 3e-6, err
+# an image that is not the image of this tensor is refused, never read (ABI v6)
+xp = hip_ops.to_pieces(x)
+if int(sys.argv[1]):
+    assert xp is not None and xp.nbytes == x.numel() * 6
+    y2 = hip_ops.conv2d_raw(x, w, geom, (32, 32), 256, x_pieces=xp)
+    assert torch.equal(y, y2)
+    xp.nbytes -= 96
+    try:
+        hip_ops.conv2d_raw(x, w, geom, (32, 32), 256, x_pieces=xp)
+    except Exception as e:
+        assert 'x_pieces' in str(e), e
+    else:
+        raise AssertionError('a piece image of the wrong size was accepted')
+    dy = torch.randn(4, 256, 32, 32, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    dyp = hip_ops.to_pieces(dy)
+    dyp.nbytes += 6
+    try:
+        hip_ops.conv2d_wgrad_raw(x, dy, geom, dy_pieces=dyp)
+    except Exception as e:
+        assert 'dy_pieces' in str(e), e
+    else:
+        raise AssertionError('a dy piece image of the wrong size was accepted')
+else:
+    assert xp is None
+print('SWITCH-OK')
+'''
+
+
+@pytest.mark.parametrize('on', ['1', '0'], ids=['default_piece_form', 'exact_fp32'])
+def test_switch_selects_the_form_and_piece_images_are_size_checked(cuda_device, on):
+    """Default (nothing in the environment) = the piece form for the large 3x3 layers; IGAN_CONV_PLANES=0 = the fp32 instruction
+    everywhere (the labelled second bench line).  The library, not the host, decides which tensors get an image
+    (igan_conv_pieces_wanted / igan_pieces_image_ok), and it refuses an image whose byte size is not that of the tensor (ADVICE r03)."""
+    env = {k: v for k, v in os.environ.items() if k != 'IGAN_CONV_PLANES'}
+    if on == '0':
+        env['IGAN_CONV_PLANES'] = '0'
+    r = subprocess.run([sys.executable, '-c', FP32_CHILD % ROOT, on], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'SWITCH-OK' in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+    kernel = [l for l in r.stdout.splitlines() if l.startswith('KERNEL ')][-1]
+    assert ('planes' in kernel) == (on == '1'), kernel

@@ -3,7 +3,7 @@
 #   bench line (default flags), rocprofv3 kernel stats + steady-state kernel breakdown of the same command, the stamped per-shape
 #   conv table, per-layer sustained microbenchmark, single-kernel microbenchmarks, full-size IMLE refresh.
 # Everything lands in gpurun_out/prof_<tag>/; copy what should be judged into profiles/.
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$PWD/gpurun_out/prof_$TAG
 R=$PWD
 mkdir -p $OUT
@@ -21,12 +21,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rf_$TAG -o rf -- py
 cd $R
 python tools/prof_summary.py $(find /tmp/rf_$TAG -name "*kernel_stats.csv" | head -1) 14 > $OUT/refresh_kernel_stats_tenth.txt
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb_$TAG -o bench -- python3 $R/bench.py --no-cpu-baseline --data-size 1152 > $OUT/bench_profiled.log 2>&1      # small data set: the trace is about the training step, not the refresh
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb_$TAG -o bench -- python3 $R/bench.py --no-cpu-baseline --no-variant-line --data-size 1152 > $OUT/bench_profiled.log 2>&1      # small data set: the trace is about the training step, not the refresh
 cp $(find /tmp/pb_$TAG -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv
 cd $R
 python tools/prof_summary.py $OUT/bench_kernel_stats.csv 45 > $OUT/bench_kernel_stats_summary.txt
 cd /tmp
-rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_$TAG -o kt -- python3 $R/bench.py --no-cpu-baseline --no-roofline --steps 24 --data-size 1152 > $OUT/bench_traced.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_$TAG -o kt -- python3 $R/bench.py --no-cpu-baseline --no-roofline --no-variant-line --steps 24 --data-size 1152 > $OUT/bench_traced.log 2>&1
 cd $R
 python tools/gpu_idle.py $(find /tmp/kt_$TAG -name "*kernel_trace.csv" | head -1) 0.3 12 > $OUT/bench_steady_state.txt 2>&1
 ls -la $OUT
