@@ -51,9 +51,25 @@ __device__ __forceinline__ float io_load(const __half* p) { return __half2float(
 __device__ __forceinline__ void io_store(float* p, float v) { *p = v; }
 __device__ __forceinline__ void io_store(__half* p, float v) { *p = __float2half(v); }
 
-// General path: one thread per output element, channel index fastest.
-// Same receptive-field arithmetic as upfirdn_2d.cu:76-90.  T = float or half (the reference registers both, upfirdn_2d.cu:323-324;
-// loads are widened to float, the accumulation is float, the store rounds to T: :101,114).
+// General path: one thread per output element, channel index fastest.  Written from the op's definition (upfirdn_2d.py:19-60):
+//     y[m, oy, ox, c] = sum_{jy, jx} Z[m, oy * downy + jy - pady0, ox * downx + jx - padx0, c] * taps[jy][jx]
+// where Z is x with (up - 1) zeros inserted after every sample (Z[u] = x[u / up] when u >= 0, u % up == 0 and u / up < in; else 0:
+// negative pads crop, positive pads add zeros) and `taps` is the filter in correlation order (the host flips it once).  Per axis only
+// every up-th tap meets a sample: the first one is the smallest j >= 0 whose Z coordinate is a non-negative multiple of `up`, and
+// from there tap j += up walks sample i += 1.  Same terms in the same order (input rows, then columns, ascending) as the reference's
+// kernels (upfirdn_2d.cu:64-207), so the float accumulation gives the same value.  T = float or half (the reference registers both,
+// upfirdn_2d.cu:323-324; loads are widened to float, the accumulation is float, the store rounds to T: :101,114).
+struct TapWalk { int j0, i0, n; };      // first tap that lands on a sample, that sample, how many (tap, sample) pairs follow
+
+__device__ __forceinline__ TapWalk tap_walk(int o, int down, int up, int pad0, int taps, int in) {
+    const int u0 = o * down - pad0;                                 // Z coordinate under tap 0
+    const int j0 = (u0 >= 0) ? (up - u0 % up) % up : -u0;           // u0 + j0 is the first non-negative multiple of up
+    const int i0 = (u0 + j0) / up;
+    const int by_taps = (j0 < taps) ? (taps - j0 + up - 1) / up : 0;
+    const int by_samples = (i0 < in) ? in - i0 : 0;
+    return TapWalk{j0, i0, min(by_taps, by_samples)};
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void upfirdn2d_generic_kernel(UpfirdnArgs a, FirTaps taps) {
     const T* xin = reinterpret_cast<const T*>(a.x);
@@ -66,28 +82,14 @@ __global__ __launch_bounds__(256) void upfirdn2d_generic_kernel(UpfirdnArgs a, F
         const int ox = (int)(t % a.outW);    t /= a.outW;
         const int oy = (int)(t % a.outH);    t /= a.outH;
         const int m = (int)t;
-
-        const int midY = oy * a.downy + a.upy - 1 - a.pady0;
-        const int inY = min(max(floor_div(midY, a.upy), 0), a.inH);
-        const int h = min(max(floor_div(midY + a.kernelH, a.upy), 0), a.inH) - inY;
-        const int kernelY = midY + a.kernelH - (inY + 1) * a.upy;
-
-        const int midX = ox * a.downx + a.upx - 1 - a.padx0;
-        const int inX = min(max(floor_div(midX, a.upx), 0), a.inW);
-        const int w = min(max(floor_div(midX + a.kernelW, a.upx), 0), a.inW) - inX;
-        const int kernelX = midX + a.kernelW - (inX + 1) * a.upx;
-
-        // taps.k holds the FLIPPED filter; the reference walks the unflipped one
-        // backwards (kp += -upx), i.e. k[kernelY - y*upy][kernelX - x*upx].
+        const TapWalk wy = tap_walk(oy, a.downy, a.upy, a.pady0, a.kernelH, a.inH);
+        const TapWalk wx = tap_walk(ox, a.downx, a.upx, a.padx0, a.kernelW, a.inW);
         float v = 0.0f;
-        for (int yy = 0; yy < h; yy++) {
-            const int ky = kernelY - yy * a.upy;  // index into the unflipped filter
-            const T* xrow = xin + (((long long)m * a.inH + inY + yy) * a.inW + inX) * a.minorDim + c;
-            for (int xx = 0; xx < w; xx++) {
-                const int kx = kernelX - xx * a.upx;
-                const float kv = taps.k[(a.kernelH - 1 - ky) * a.kernelW + (a.kernelW - 1 - kx)];
-                v += io_load(xrow + (long long)xx * a.minorDim) * kv;
-            }
+        for (int sy = 0; sy < wy.n; sy++) {
+            const T* xrow = xin + (((long long)m * a.inH + wy.i0 + sy) * a.inW + wx.i0) * a.minorDim + c;
+            const float* krow = taps.k + (wy.j0 + sy * a.upy) * a.kernelW + wx.j0;
+            for (int sx = 0; sx < wx.n; sx++)
+                v += io_load(xrow + (long long)sx * a.minorDim) * krow[sx * a.upx];
         }
         io_store(yout + idx, v);
     }

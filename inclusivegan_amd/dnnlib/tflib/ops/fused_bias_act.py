@@ -25,9 +25,9 @@ activation_funcs = {
 
 
 def fused_bias_act(x, b=None, axis=1, act='linear', alpha=None, gain=None, impl='hip'):
-    """y = act(x + b) * gain with `b` broadcast along `axis`.  First-order gradients for every
-    activation; second-order gradients for the piecewise-linear ones (linear / relu / lrelu), which
-    is what R1 and path-length regularisation need."""
+    """y = act(x + b) * gain with `b` broadcast along `axis`.  Twice differentiable for all nine activations, like the
+    reference's op (fused_bias_act.py:149-189): the piecewise-linear ones (linear / relu / lrelu -- what R1 and the path-length
+    regulariser need) through the closed grad = 1 kernel, the smooth ones through the grad = 2 kernel (hip_ops.FusedBiasActSmoothFn)."""
     if impl not in ('hip', 'cuda'):     # 'cuda' = the reference's name for the device kernel (fused_bias_act.py:34,61-64)
         raise ValueError("impl must be 'hip' (or the reference's 'cuda'; got %r); the CPU reference lives in oracle/ and is not a product path" % (impl,))
     spec = activation_funcs[act]
@@ -49,5 +49,7 @@ def fused_bias_act(x, b=None, axis=1, act='linear', alpha=None, gain=None, impl=
     # (dx and db together) -- csrc/bias_act_noise.hip
     if axis == 1 and spec.hip_idx in (1, 2, 3) and gain > 0 and x.dim() in (2, 4) and x.shape[1] % 4 == 0 and x.dtype == torch.float32:
         return hip_ops.bias_act_noise(x, b, None, None, spec.hip_idx, 0.0 if alpha is None else float(alpha), float(gain))
+    if not spec.zero_2nd_grad:      # func_nonzero_2nd_grad (:174-189)
+        return hip_ops.FusedBiasActSmoothFn.apply(x, b, axis, spec.hip_idx, 0.0 if alpha is None else float(alpha), float(gain), spec.ref)
     return hip_ops.FusedBiasActFn.apply(x, b, axis, spec.hip_idx, 0.0 if alpha is None else float(alpha), float(gain),
                                         spec.ref, spec.zero_2nd_grad)

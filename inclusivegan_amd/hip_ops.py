@@ -273,27 +273,43 @@ def _match_layout(t, ref):
 
 
 class _FbaGradFn(torch.autograd.Function):
-    """dx = kernel(grad=1)(dy [+ d_db], ref).  Closed under differentiation for activations
-    with zero second derivative (fused_bias_act.py:161-172)."""
+    """dx = kernel(grad=1)(dy [+ d_db], ref): the first-order gradient as a differentiable op (fused_bias_act.py:161-189).
+    Piecewise-linear activations (zero second derivative): closed under differentiation, nothing depends on x.  Smooth activations
+    (tanh, sigmoid, elu, selu, softplus, swish): dx also depends on x through f'(x), and its gradient w.r.t. x is
+    kernel(grad=2)(d_dx, ref) * dy -- the grad=2 table entry is gain * f''(x) (expressed through x or y, whichever `ref` is), as in
+    fused_bias_act.cu.  `xrecv` is the forward input (graph-connected): it only RECEIVES that gradient; `ref` stays a constant, like
+    the closed-over y of the reference's grad_impl(dy, x) (:176-188).  Deviation from the reference, on purpose: its grad2_d_x (:165-168)
+    hands only d_dx to the grad=2 kernel, so its second-order term lacks the factor dy (its PyTorch successor passes dy); the two
+    agree for dy = 1, and what is computed here is the derivative (checked against fp64 autograd in tests/test_gpu_ops.py)."""
 
     @staticmethod
-    def forward(ctx, dy, bias_term, ref, axis, act_idx, alpha, gain, size_b, step_b, zero_2nd):
-        ctx.save_for_backward(ref)
+    def forward(ctx, dy, bias_term, ref, axis, act_idx, alpha, gain, size_b, step_b, zero_2nd, xrecv=None):
         ctx.cfg = (axis, act_idx, alpha, gain, size_b, step_b, zero_2nd)
         ctx.has_bias_term = bias_term is not None
-        return fused_bias_act_raw(_match_layout(dy, ref), bias_term, ref, 1, act_idx, alpha, gain, size_b, step_b)
+        dyl = _match_layout(dy, ref)
+        ctx.save_for_backward(ref, *(() if zero_2nd else (dyl, bias_term) if bias_term is not None else (dyl,)))
+        return fused_bias_act_raw(dyl, bias_term, ref, 1, act_idx, alpha, gain, size_b, step_b)
 
     @staticmethod
     def backward(ctx, d_dx):
-        (ref,) = ctx.saved_tensors
+        ref = ctx.saved_tensors[0]
         axis, act_idx, alpha, gain, size_b, step_b, zero_2nd = ctx.cfg
+        d_dy = _FbaGradFn.apply(d_dx, None, ref, axis, act_idx, alpha, gain, size_b, step_b, True) if zero_2nd else None
+        d_x = None
         if not zero_2nd:
-            raise NotImplementedError('fused_bias_act: second-order gradients of this activation are not supported on the hip path')
-        d_dy = _FbaGradFn.apply(d_dx, None, ref, axis, act_idx, alpha, gain, size_b, step_b, zero_2nd)
+            with torch.no_grad():       # third order is not offered
+                g = _match_layout(d_dx, ref)
+                d_dy = fused_bias_act_raw(g, None, ref, 1, act_idx, alpha, gain, size_b, step_b)
+                if ctx.needs_input_grad[10]:
+                    dy = ctx.saved_tensors[1]
+                    if ctx.has_bias_term:
+                        view = [1] * dy.dim(); view[axis] = -1
+                        dy = dy + ctx.saved_tensors[2].view(*view)
+                    d_x = fused_bias_act_raw(g, None, ref, 2, act_idx, alpha, gain, size_b, step_b) * dy
         d_bias_term = None
         if ctx.has_bias_term:
             d_bias_term = _BiasGradFn.apply(d_dy, axis, size_b, step_b)
-        return (d_dy, d_bias_term) + (None,) * 8
+        return (d_dy, d_bias_term) + (None,) * 8 + (d_x,)
 
 
 class _BiasGradFn(torch.autograd.Function):
@@ -329,6 +345,40 @@ class FusedBiasActFn(torch.autograd.Function):
         dx = _FbaGradFn.apply(dy, None, ref, axis, act_idx, alpha, gain, size_b, step_b, zero_2nd)
         db = _BiasGradFn.apply(dx, axis, size_b, step_b) if (ctx.has_b and _needed(ctx, 1)) else None
         return (dx, db) + (None,) * 6
+
+
+class FusedBiasActSmoothFn(torch.autograd.Function):
+    """FusedBiasActFn for the activations with a non-zero second derivative (the reference's func_nonzero_2nd_grad,
+    fused_bias_act.py:174-189): under create_graph the first-order gradient is taken by `_FbaGradFn` with a receiver for the
+    second-order term, so the op is twice differentiable w.r.t. x, b and dy.  The receiver is what `ref` is a function of: the
+    pre-activation x + b for the activations whose ref is y (tanh, sigmoid, elu, selu, softplus), and the op input x alone for swish --
+    the reference hands its kernel ref = x WITHOUT the bias there (fused_bias_act.py:135, fused_bias_act.cu:57-58), and the first-order
+    gradient here is that literal value, so its derivative is taken literally too."""
+
+    @staticmethod
+    def forward(ctx, x, b, axis, act_idx, alpha, gain, ref_kind):
+        xd, size_b, step_b = _bias_layout(x, axis)
+        y = fused_bias_act_raw(xd, b, None, 0, act_idx, alpha, gain, size_b, step_b)
+        ctx.cfg = (axis, act_idx, alpha, gain, size_b, step_b, ref_kind)
+        ctx.has_b = b is not None
+        ctx.save_for_backward(xd, y, b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xd, y, b = ctx.saved_tensors
+        axis, act_idx, alpha, gain, size_b, step_b, ref_kind = ctx.cfg
+        ref = (xd if ref_kind == 'x' else y).detach()
+        if torch.is_grad_enabled():
+            recv = xd
+            if ref_kind != 'x' and b is not None:
+                view = [1] * xd.dim(); view[axis] = -1
+                recv = xd + b.view(*view)
+            dx = _FbaGradFn.apply(dy, None, ref, axis, act_idx, alpha, gain, size_b, step_b, False, recv)
+        else:
+            dx = fused_bias_act_raw(_match_layout(dy, ref), None, ref, 1, act_idx, alpha, gain, size_b, step_b)
+        db = _BiasGradFn.apply(dx, axis, size_b, step_b) if (ctx.has_b and _needed(ctx, 1)) else None
+        return (dx, db) + (None,) * 5
 
 
 # ----------------------------------------------------------------------------

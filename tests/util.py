@@ -72,3 +72,36 @@ def gloss_tape_in_product_order(entries, B, lpips_weight, calls=4):
     for j in range(3, per):
         out.append(('normal', np.concatenate([np.asarray(k[j][1]) for k in c], axis=0)))
     return out
+
+
+def synthetic_mnist(directory, seed=5):
+    """A stand-in for the MNIST training files (same names, idx headers, 60000 x 28 x 28 uint8 + 60000 labels) from a seed: digits are
+    random bytes (with 0 and 255 present), labels mostly 0 and 9 so that a few hundred stacked images already span 000..999."""
+    import gzip
+    import os
+    rng = np.random.RandomState(seed)
+    imgs = rng.randint(0, 256, size=(60000, 28, 28)).astype(np.uint8)
+    labels = rng.choice(10, size=60000, p=[0.41, .0225, .0225, .0225, .0225, .0225, .0225, .0225, .0225, 0.41]).astype(np.uint8)
+    os.makedirs(directory, exist_ok=True)
+    with gzip.open(os.path.join(directory, 'train-images-idx3-ubyte.gz'), 'wb', compresslevel=1) as f:
+        f.write(b'\x00\x00\x08\x03' + (60000).to_bytes(4, 'big') + (28).to_bytes(4, 'big') + (28).to_bytes(4, 'big') + imgs.tobytes())
+    with gzip.open(os.path.join(directory, 'train-labels-idx1-ubyte.gz'), 'wb', compresslevel=1) as f:
+        f.write(b'\x00\x00\x08\x01' + (60000).to_bytes(4, 'big') + labels.tobytes())
+
+
+def synthetic_celeba(root, n=7, seed=6):
+    """n aligned-CelebA-shaped PNGs (218 x 178 RGB, names 000001.png ...) under <root>/img and the attribute file at
+    <root>/celeba/Anno/list_attr_celeba.txt (count line, 40 names, '<name>.jpg' + 40 values in {-1, 1})."""
+    import os
+    import PIL.Image
+    from inclusivegan_amd.training.imle import CELEBA_ATTRIBUTES
+    rng = np.random.RandomState(seed)
+    os.makedirs(os.path.join(root, 'img'), exist_ok=True)
+    os.makedirs(os.path.join(root, 'celeba', 'Anno'), exist_ok=True)
+    lines = ['%d' % n, ' '.join(CELEBA_ATTRIBUTES)]
+    for i in range(n):
+        PIL.Image.fromarray(rng.randint(0, 256, size=(218, 178, 3)).astype(np.uint8)).save(os.path.join(root, 'img', '%06d.png' % (i + 1)))
+        lines.append('%06d.jpg  ' % (i + 1) + ' '.join('%2d' % v for v in rng.choice([-1, 1], size=40)))
+    with open(os.path.join(root, 'celeba', 'Anno', 'list_attr_celeba.txt'), 'w') as f:
+        f.write('\n'.join(lines) + '\n')
+    return os.path.join(root, 'img')
