@@ -60,34 +60,43 @@ def _dist_world(group=None):
 _capture_probe = {}
 
 
-def collectives_capturable(group=None):
+def _rccl_capture_probe(group):
+    """Capture and replay a tiny all-reduce on this process group; True when the replayed result is right."""
+    import os
+    if os.environ.get('IGAN_GRAPH_COLLECTIVES', '1') == '0' or torch.distributed.get_backend(group) != 'nccl':
+        return False
+    try:
+        t = torch.ones(1024, device=torch.device('cuda', torch.cuda.current_device()))
+        torch.distributed.all_reduce(t, group=group)            # communicator set up outside the capture
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode='thread_local'):
+            w = torch.distributed.all_reduce(t, group=group, async_op=True)
+            w.wait()
+        t.fill_(1.0)
+        g.replay()
+        torch.cuda.synchronize()
+        return bool((t == float(_dist_world(group))).all())
+    except Exception:   # noqa: BLE001 -- any failure means: keep collectives outside the graphs
+        return False
+
+
+def collectives_capturable(group=None, probe=None):
     """Can this process group's all-reduce be captured into a hipGraph?  RCCL: yes, verified once per group by capturing
     and replaying a tiny all-reduce (a failure here is cheap and leaves nothing behind; a failure in the middle of a
-    training op's capture would not be).  gloo stages through the host: never.  IGAN_GRAPH_COLLECTIVES=0 forces 'no'."""
-    import os
+    training op's capture would not be).  gloo stages through the host: never.  IGAN_GRAPH_COLLECTIVES=0 forces 'no'.
+    EVERY rank takes the same path: the ranks' answers are combined with an all-reduce(MIN), so one rank whose probe fails
+    (`probe`: the per-rank check, injectable for the tests) takes every rank to the exchange-after-replay form."""
     if _dist_world(group) == 1:
         return True
     key = id(group)
-    if key not in _capture_probe:
-        ok = False
-        if os.environ.get('IGAN_GRAPH_COLLECTIVES', '1') != '0' and torch.distributed.get_backend(group) == 'nccl':
-            try:
-                t = torch.ones(1024, device=torch.device('cuda', torch.cuda.current_device()))
-                torch.distributed.all_reduce(t, group=group)            # communicator set up outside the capture
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode='thread_local'):
-                    w = torch.distributed.all_reduce(t, group=group, async_op=True)
-                    w.wait()
-                t.fill_(1.0)
-                g.replay()
-                torch.cuda.synchronize()
-                ok = bool((t == float(_dist_world(group))).all())
-            except Exception:   # noqa: BLE001 -- any failure means: keep collectives outside the graphs
-                ok = False
-        # every rank must take the same path
-        flag = torch.tensor([1 if ok else 0], device=torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() and torch.distributed.get_backend(group) == 'nccl' else 'cpu')
+    if key not in _capture_probe or probe is not None:
+        ok = bool((probe or _rccl_capture_probe)(group))
+        on_device = torch.cuda.is_available() and torch.distributed.get_backend(group) == 'nccl'
+        flag = torch.tensor([1 if ok else 0], device=torch.device('cuda', torch.cuda.current_device()) if on_device else 'cpu')
         torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN, group=group)
+        if probe is not None:
+            return bool(flag.item())
         _capture_probe[key] = bool(flag.item())
     return _capture_probe[key]
 

@@ -19,7 +19,7 @@ from .dnnlib import EasyDict
 _CONFIGS_E = ['config-e-G%s-D%s' % (g, d) for g in ('orig', 'resnet', 'skip') for d in ('orig', 'resnet', 'skip')]
 _valid_configs = ['config-a', 'config-b', 'config-c', 'config-d', 'config-e', 'config-f'] + _CONFIGS_E
 
-metric_defaults = {}    # snapshot-time metrics are out of scope
+from .metrics.metric_defaults import metric_defaults      # the metrics built here: mode_counts_24k, KL24k, fid30k (run_training.py:21 of the reference)
 
 
 def build_kwargs(dataset, data_dir, result_dir, config_id, num_gpus, gamma, mirror_augment, metrics, resume_pkl,
@@ -161,7 +161,9 @@ def main():
     torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.distributed.init_process_group('nccl')
+        import datetime
+        # generous timeout: rank 0 evaluates the snapshot metrics alone while the other ranks wait at the next collective
+        torch.distributed.init_process_group('nccl', timeout=datetime.timedelta(hours=4))
     assert world == args.num_gpus, 'one process per GPU: launch %d ranks' % args.num_gpus
     run(**vars(args))
 

@@ -711,8 +711,10 @@ def training_loop(
                 if network_snapshot_ticks is not None and (cur_tick % max(network_snapshot_ticks, 1) == 0 or done):
                     pkl = snap('network-snapshot-%06d.pkl' % (cur_nimg // 1000))
                     misc.save_pkl((G, D, Gs), pkl, reference_layout=True, build_module_src=module_src)
+                    rng_state = torch.cuda.get_rng_state(device)    # the reference's metric ops carry their own seeds: evaluating a metric must not
                     metrics.run(pkl, run_dir=run_dir, data_dir=data_dir, dataset_args=ds_args, mirror_augment=mirror_augment,
                                 num_gpus=min([2, num_gpus]), tf_config=tf_config, device=device)                   # :519
+                    torch.cuda.set_rng_state(rng_state, device)     # shift this rank's training draws (a run with metrics == a run without)
             if network_snapshot_ticks is not None and cur_tick > 0 and cur_tick % max(network_snapshot_ticks, 1) == 0 and use_graphs:
                 validate_graphs('tick %d' % cur_tick)      # long runs: the replays are re-checked at the network-snapshot cadence
                 autosummary_mod.flush()                    # the check's extra executions do not reach the next tick's statistics

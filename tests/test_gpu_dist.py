@@ -110,6 +110,27 @@ def test_bench_launches_its_own_ranks(cuda_device):
     assert d['value'] > 0 and abs(d['value'] - 12 / (d['ms_per_step'] * 1e-3)) < 1e-2 * d['value']
 
 
+def test_bench_eight_ranks_at_the_bench_size(cuda_device):
+    """The driver's multi-GPU command at the bench configuration itself (128x128 config-e, minibatch_gpu 6), eight ranks on this one
+    GPU over gloo, 2 timed steps: the self-launch path, the data_size rounding to a multiple of 2 * minibatch_gpu * ranks, the
+    barrier-bracketed max-over-ranks timing and the whole-job rate -- everything of an 8-GPU run but RCCL and the other seven devices."""
+    import json
+    env = dict(os.environ)
+    env.pop('RANK', None); env.pop('WORLD_SIZE', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--one-gpu', '--backend', 'gloo', '--steps', '2', '--warmup', '1', '--no-roofline',
+                        '--no-cpu-baseline', '--data-size', '1000', '--num-samples-factor', '1'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=2400)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 8 and d['steps'] == 2 and d['scaling'] == 'weak' and d['config']['parallelism'] == 'dp8'
+    assert d['config']['data_size'] == 960 and d['config']['data_size'] % (2 * 6 * 8) == 0          # 1000 rounded down
+    assert d['config']['global_batch'] == 48 and d['config']['images_per_step'] == 96
+    assert abs(d['value'] - 96 / (d['ms_per_step'] * 1e-3)) < 1e-2 * d['value']
+    assert d['rccl'] == {'ranks': 8, 'backend': 'gloo', 'in_graph': False, 'version': None}
+    assert d['hip_graphs']['captured'] and d['hip_graphs']['faithful']
+
+
 @pytest.mark.parametrize('size', ['32x32_fmap256', '128x128_fmap8192'])
 def test_eight_rank_loop_at_config5_shape(cuda_device, tmp_path, size):
     """BASELINE config 5 (8 GPUs, minibatch_gpu 3, attribute-masked selection) as far as one GPU allows: EIGHT ranks on GPU 0 over

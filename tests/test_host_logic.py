@@ -227,6 +227,37 @@ def test_data_parallel_exchange_gloo_world2():
         assert nchunks >= 2 and covers and averaged and flagged and same_as_blocking
 
 
+def _probe_worker(rank, world, port, out):
+    import os
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.distributed.init_process_group('gloo', rank=rank, world_size=world)
+    from inclusivegan_amd.dnnlib.tflib.optimizer import collectives_capturable
+    res = [collectives_capturable(probe=lambda g: True),                  # every rank's probe passes
+           collectives_capturable(probe=lambda g: rank != 1),             # rank 1's probe fails: NOBODY may capture the collectives
+           collectives_capturable()]                                      # gloo itself: never (host staging)
+    out[rank] = res
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_capture_decision_is_the_same_on_every_rank():
+    """the ranks must agree on whether the gradient exchange rides inside the captured graphs -- a rank that
+    captured it next to one that did not would deadlock.  The per-rank probe results are combined with all-reduce(MIN)."""
+    ctx = mp.get_context('spawn')
+    with ctx.Manager() as m:
+        out = m.dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_probe_worker, args=(r, 3, port, out)) for r in range(3)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0
+        res = [out[r] for r in range(3)]
+    assert res[0] == res[1] == res[2] == [True, False, False]
+
+
 def test_mbstd_preserving_interleave_is_exact():
     """One D pass over interleaved (fakes, reals) gives every sample the minibatch-stddev statistic of its own
     separate pass (loss.D_logistic_r1 relies on this)."""
