@@ -453,9 +453,11 @@ def main():
         state['iters'] += 1
         log('iteration %d done' % state['iters'])
         if state['iters'] == args.warmup and args.warmup > 0:
-            barrier_sync()
+            info['drain']()         # the loop hands its device work to a submission thread: everything up to here has been issued ...
+            barrier_sync()          # ... and has run
             state['t_start'] = time.perf_counter()
         if state['iters'] == args.warmup + args.steps:
+            info['drain']()
             barrier_sync()
             state['t_end'] = time.perf_counter()
             if profile_iters == 0:
@@ -471,6 +473,7 @@ def main():
             GraphedStep.after_capture = lambda step: state['stamp_steps'].__setitem__(step, state['stamp'].fold())
             GraphedStep.generation += 1
         if state['iters'] == args.warmup + args.steps + profile_iters:
+            info['drain']()
             torch.cuda.synchronize()
             # the stamped graphs are new captures (all four ops have been re-captured within 16 iterations): they get the same
             # replay-equals-eager check as the first ones.  The stamp totals are frozen first -- the check's replays would add
@@ -502,7 +505,7 @@ def main():
         tf_config={'rnd.np_random_seed': 1000},
         total_kimg=10 ** 6, data_size=data_size, num_epochs=10000,
         init_staleness=10, num_samples_factor=args.num_samples_factor, knn_perturb_factor=0.05, candidate_batch_size=256,
-        hooks=dict(on_iteration=on_iteration, on_refresh=on_refresh, on_graphs=lambda g: state.__setitem__('graphs', g),
+        hooks=dict(on_iteration=on_iteration, on_refresh=on_refresh, on_graphs=lambda g: state.__setitem__('graphs', g), async_ok=True,
                    **({'op_times': state.setdefault('op_times', {})} if args.op_times else {})),
     )
     log('starting training loop')
@@ -529,6 +532,7 @@ def main():
         'imle_refresh_s': round(state['refresh'][0], 3) if state['refresh'] else None,
         # the four training ops run as replayed hipGraphs, each validated bit for bit against its eager execution after capture
         'hip_graphs': state['graphs'] if state['graphs'] is not None else {'captured': False},
+        'host': {'async_submit': os.environ.get('IGAN_ASYNC_SUBMIT', '1') != '0' and not args.op_times},
     }
     if world > 1:
         from inclusivegan_amd.dnnlib.tflib import optimizer as _opt

@@ -1274,6 +1274,11 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
     typedef __attribute__((address_space(3))) void lds_void;
     unsigned char* dA = nullptr;
     auto dma_prep = [&](int stage) {        // addresses of the next chunk, then one step forward in (slice, tap) order
+#ifdef IGAN_PLANES_NO_PREP      // TIMING EXPERIMENT ONLY (wrong results): how much of the step is the scalar address work?
+        dA = smem + stage * P_STAGE + (wave & 3) * 1024;
+        offA = baseA; soffB = 0u;
+        return;
+#endif
         const unsigned disp = (unsigned)(ld_ta * a.W + ld_tb) * pixA + (unsigned)ld_cc * 96u;                      // scalar
         const unsigned bit = 1u << (ld_ta * nkx + ld_tb);                                                           // scalar
         offA = (maskA & bit) ? baseA + disp : OOB;
@@ -1349,9 +1354,20 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
     // cycles against 4 (same guide), and the compiler packs them when left alone.  Same products, same order within a tile, same
     // sums: bit-identical to the interleaved form (-DIGAN_PLANES_INTERLEAVED, kept for A/B).
     f32x16 t0, t1 = zero;
+    // The adds are inline assembly, so the compiler's hazard recogniser does not see them: a vector read of an MFMA result needs
+    // 11 wait states behind the 8-pass write (it put `s_nop 9` there itself in the interleaved form), and nothing in the hardware
+    // interlocks it.  Both call sites sit far behind the chain they read (three MFMAs of the other tile / a barrier and nine LDS
+    // reads); the explicit s_nop keeps that true whatever the scheduler does around the fences.
     auto fold = [](f32x16& acc_, const f32x16& t_) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) asm("v_add_f32 %0, %1, %0" : "+v"(acc_[r]) : "v"(t_[r]));
+        asm volatile("s_nop 7\n\ts_nop 3\n\t"
+                     "v_add_f32 %0, %8, %0\n\tv_add_f32 %1, %9, %1\n\tv_add_f32 %2, %10, %2\n\tv_add_f32 %3, %11, %3\n\t"
+                     "v_add_f32 %4, %12, %4\n\tv_add_f32 %5, %13, %5\n\tv_add_f32 %6, %14, %6\n\tv_add_f32 %7, %15, %7"
+                     : "+v"(acc_[0]), "+v"(acc_[1]), "+v"(acc_[2]), "+v"(acc_[3]), "+v"(acc_[4]), "+v"(acc_[5]), "+v"(acc_[6]), "+v"(acc_[7])
+                     : "v"(t_[0]), "v"(t_[1]), "v"(t_[2]), "v"(t_[3]), "v"(t_[4]), "v"(t_[5]), "v"(t_[6]), "v"(t_[7]));
+        asm volatile("v_add_f32 %0, %8, %0\n\tv_add_f32 %1, %9, %1\n\tv_add_f32 %2, %10, %2\n\tv_add_f32 %3, %11, %3\n\t"
+                     "v_add_f32 %4, %12, %4\n\tv_add_f32 %5, %13, %5\n\tv_add_f32 %6, %14, %6\n\tv_add_f32 %7, %15, %7"
+                     : "+v"(acc_[8]), "+v"(acc_[9]), "+v"(acc_[10]), "+v"(acc_[11]), "+v"(acc_[12]), "+v"(acc_[13]), "+v"(acc_[14]), "+v"(acc_[15])
+                     : "v"(t_[8]), "v"(t_[9]), "v"(t_[10]), "v"(t_[11]), "v"(t_[12]), "v"(t_[13]), "v"(t_[14]), "v"(t_[15]));
     };
     for (int c = c_begin; c < c_end; c++) {
         asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
@@ -1378,6 +1394,7 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
         t0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][0], bfr[2], t0, 0, 0, 0);
         t0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][1], bfr[1], t0, 0, 0, 0);
         t0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][2], bfr[0], t0, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);      // tile 0's chain ends here: the fold below must stay three products behind it
         t1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][0], bfr[0], zero, 0, 0, 0);
         t1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][0], bfr[1], t1, 0, 0, 0);
         t1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][1], bfr[0], t1, 0, 0, 0);
@@ -1878,9 +1895,20 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_planes_kernel(WgradArgs a) 
 #ifndef IGAN_PLANES_INTERLEAVED
     // step schedule of conv_fwd_planes_kernel (tile after tile, tile 0 folded beside tile 1's products, tile 1 under the next step's reads)
     f32x16 t0, t1 = zero;
+    // The adds are inline assembly, so the compiler's hazard recogniser does not see them: a vector read of an MFMA result needs
+    // 11 wait states behind the 8-pass write (it put `s_nop 9` there itself in the interleaved form), and nothing in the hardware
+    // interlocks it.  Both call sites sit far behind the chain they read (three MFMAs of the other tile / a barrier and nine LDS
+    // reads); the explicit s_nop keeps that true whatever the scheduler does around the fences.
     auto fold = [](f32x16& acc_, const f32x16& t_) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) asm("v_add_f32 %0, %1, %0" : "+v"(acc_[r]) : "v"(t_[r]));
+        asm volatile("s_nop 7\n\ts_nop 3\n\t"
+                     "v_add_f32 %0, %8, %0\n\tv_add_f32 %1, %9, %1\n\tv_add_f32 %2, %10, %2\n\tv_add_f32 %3, %11, %3\n\t"
+                     "v_add_f32 %4, %12, %4\n\tv_add_f32 %5, %13, %5\n\tv_add_f32 %6, %14, %6\n\tv_add_f32 %7, %15, %7"
+                     : "+v"(acc_[0]), "+v"(acc_[1]), "+v"(acc_[2]), "+v"(acc_[3]), "+v"(acc_[4]), "+v"(acc_[5]), "+v"(acc_[6]), "+v"(acc_[7])
+                     : "v"(t_[0]), "v"(t_[1]), "v"(t_[2]), "v"(t_[3]), "v"(t_[4]), "v"(t_[5]), "v"(t_[6]), "v"(t_[7]));
+        asm volatile("v_add_f32 %0, %8, %0\n\tv_add_f32 %1, %9, %1\n\tv_add_f32 %2, %10, %2\n\tv_add_f32 %3, %11, %3\n\t"
+                     "v_add_f32 %4, %12, %4\n\tv_add_f32 %5, %13, %5\n\tv_add_f32 %6, %14, %6\n\tv_add_f32 %7, %15, %7"
+                     : "+v"(acc_[8]), "+v"(acc_[9]), "+v"(acc_[10]), "+v"(acc_[11]), "+v"(acc_[12]), "+v"(acc_[13]), "+v"(acc_[14]), "+v"(acc_[15])
+                     : "v"(t_[8]), "v"(t_[9]), "v"(t_[10]), "v"(t_[11]), "v"(t_[12]), "v"(t_[13]), "v"(t_[14]), "v"(t_[15]));
     };
     for (int c = c_begin; c < c_end; c++) {
         asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
@@ -1907,6 +1935,7 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_planes_kernel(WgradArgs a) 
         t0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][0], bfr[2], t0, 0, 0, 0);
         t0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][1], bfr[1], t0, 0, 0, 0);
         t0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][2], bfr[0], t0, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);      // tile 0's chain ends here: the fold below must stay three products behind it
         t1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][0], bfr[0], zero, 0, 0, 0);
         t1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][0], bfr[1], t1, 0, 0, 0);
         t1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][1], bfr[0], t1, 0, 0, 0);

@@ -276,6 +276,73 @@ def _with_random_source(fn):
 
 
 @_with_random_source
+class SubmitThread:
+    """A second host thread that owns the per-iteration device submissions (input copies, graph replays, optimizer updates), fed in
+    order through a queue.  With the HIP runtime's graph packet capture off (inclusivegan_amd/__init__.py) `CUDAGraph.replay()` blocks its
+    caller for about as long as the device executes the graph (the runtime hands over the kernel nodes as the queue drains), so a single
+    host thread alternates between "inside replay()" and "preparing the next iteration" -- and the device idles during the second
+    (profiles/r03_bench_steady_state_bf16_pieces_variant.txt: 94 % busy; host profile: 12.2 of 13.4 s inside replay()).  replay() releases
+    the GIL, so the main thread assembles iteration i + 1 (NumPy sampler, pinned staging) while this thread submits iteration i.
+    Everything device-side stays on ONE stream in program order: the arithmetic and every buffer hand-over are those of the single-thread
+    loop (tests/test_gpu_loop_parity.py::test_async_submission_equals_synchronous_loop).  IGAN_ASYNC_SUBMIT=0 switches it off."""
+
+    def __init__(self, device):
+        import queue
+        import threading
+        self.q = queue.Queue(maxsize=64)
+        self.error = None
+        self.device = device
+        self.cond = threading.Condition()
+        self.submitted = 0
+        self.completed = 0
+        self.thread = threading.Thread(target=self._run, name='igan-submit', daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        torch.cuda.set_device(self.device)
+        while True:
+            fn = self.q.get()
+            try:
+                if fn is None:
+                    return
+                if self.error is None:
+                    fn()
+            except BaseException as e:      # noqa: BLE001 -- handed to the main thread at its next submit() / drain()
+                self.error = e
+            finally:
+                self.q.task_done()
+                with self.cond:
+                    self.completed += 1
+                    self.cond.notify_all()
+
+    def _check(self):
+        if self.error is not None:
+            e, self.error = self.error, None
+            raise e
+
+    def submit(self, fn):
+        self._check()
+        with self.cond:
+            self.submitted += 1
+        self.q.put(fn)
+
+    def wait_backlog(self, n):
+        """Returns when at most n submitted items have not been run yet (bounds how far the main thread runs ahead)."""
+        with self.cond:
+            self.cond.wait_for(lambda: self.submitted - self.completed <= n or self.error is not None)
+        self._check()
+
+    def drain(self):
+        """Returns when everything submitted so far has been HANDED to the device (not: executed)."""
+        self.q.join()
+        self._check()
+
+    def close(self):
+        self.q.put(None)
+        self.thread.join()
+        self._check()
+
+
 def training_loop(
     G_args                  = {},
     D_args                  = {},
@@ -607,6 +674,14 @@ def training_loop(
     if 'on_start' in hooks:
         hooks['on_start'](dict(G=G, D=D, Gs=Gs, lpips=lpips, feed=feed, training_set=training_set, G_opt=G_opt, D_opt=D_opt))
     stop = False
+    # Submission thread (SubmitThread): on unless switched off, or a hook wants to look at device state after every op / time the ops
+    # (those hooks are synchronous by contract: the parity tests).  A hook set may carry 'async_ok': True to say that its on_iteration
+    # does not read device state without calling info['drain']() first (bench.py); otherwise the queue is drained before on_iteration.
+    use_async = (os.environ.get('IGAN_ASYNC_SUBMIT', '1') != '0' and use_graphs and not any(k in hooks for k in ('on_op', 'op_times', 'on_batch')))
+    submitter = SubmitThread(device) if use_async else None
+    submit = submitter.submit if use_async else (lambda fn: fn())
+    drain = submitter.drain if use_async else (lambda: None)
+    backlog = submitter.wait_backlog if use_async else (lambda n: None)
     while cur_nimg < total_kimg * 1000 and not stop:
         # Choose training parameters (:336-340).
         sched = training_schedule(cur_nimg=cur_nimg, training_set=training_set, **sched_args)
@@ -625,6 +700,7 @@ def training_loop(
 
             # IMLE refresh (:354-406) and this iteration's (real, label, latent) triples (:409-464).
             if sampler.refresh_due(cur_nimg, mb):
+                drain()                 # the refresh runs the generator from this thread: every earlier update must have been handed over
                 sampler.refresh(mb)
             batch = sampler.next_batch(mb)
             if 'on_batch' in hooks:
@@ -636,16 +712,20 @@ def training_loop(
             # device while the host prepares the next iteration -- and an idle-prone device also runs at a lower clock).
             assert sched.minibatch_gpu == B, 'minibatch_gpu must stay constant (static buffers / captured graphs)'
             rs = slice(rank * B, (rank + 1) * B)
-            stage = staging[running_mb_counter % len(staging)]
-            stage['event'].synchronize()            # the copy that last read this staging set has run
+            backlog(1)                              # at most one iteration waits behind the one being submitted: the upload that last read the
+            stage = staging[running_mb_counter % len(staging)]      # staging set below (three sets: three iterations ago) has been issued ...
+            stage['event'].synchronize()            # ... and has run
             for h, (r_, l_, z_) in enumerate(halves):
                 for key, arr in (('reals_rec_%d', r_), ('labels_rec_%d', l_), ('latents_rec_%d', z_)):
-                    key = key % (h + 1)
-                    stage[key].copy_(torch.from_numpy(np.ascontiguousarray(arr[rs], dtype=np.float32)))
-                    feed[key].copy_(stage[key], non_blocking=True)
-            stage['event'].record()
+                    stage[key % (h + 1)].copy_(torch.from_numpy(np.ascontiguousarray(arr[rs], dtype=np.float32)))
 
-            # Run training ops (:474-479).
+            def upload(stage=stage):
+                for key in stage:
+                    if key != 'event':
+                        feed[key].copy_(stage[key], non_blocking=True)
+                stage['event'].record()
+
+            # Run training ops (:474-479) -- handed to the submission thread in program order (or executed here when it is off).
             timed = hooks.get('op_times')          # optional: dict name -> list of (start, end) HIP events
             on_op = hooks.get('on_op')
             def run(name, op):
@@ -657,18 +737,27 @@ def training_loop(
                     timed.setdefault(name, []).append((e0, e1))
                 if on_op is not None and res is not None:
                     on_op(res[0], res[1], feed)
-            run('G_train', G_train_op)
-            if run_G_reg:
-                run('G_reg', G_reg_op)
-            run('D_train', D_train_op)
-            run('Gs_update', Gs_update_op)
-            if run_D_reg:
-                run('D_reg', D_reg_op)
+
+            def iteration(run_G_reg=run_G_reg, run_D_reg=run_D_reg, upload=upload):
+                upload()
+                run('G_train', G_train_op)
+                if run_G_reg:
+                    run('G_reg', G_reg_op)
+                run('D_train', D_train_op)
+                run('Gs_update', Gs_update_op)
+                if run_D_reg:
+                    run('D_reg', D_reg_op)
+            submit(iteration)
 
             cur_nimg += mb * 2
             running_mb_counter += 1
             if 'on_iteration' in hooks:
-                if hooks['on_iteration'](dict(cur_nimg=cur_nimg, iteration=running_mb_counter, G=G, D=D, Gs=Gs, revalidate_graphs=validate_graphs)):
+                if not hooks.get('async_ok'):
+                    drain()
+                def revalidate(reason):
+                    drain()
+                    return validate_graphs(reason)
+                if hooks['on_iteration'](dict(cur_nimg=cur_nimg, iteration=running_mb_counter, G=G, D=D, Gs=Gs, revalidate_graphs=revalidate, drain=drain)):
                     stop = True
                     break
 
@@ -676,6 +765,7 @@ def training_loop(
         done = (cur_nimg >= total_kimg * 1000) or stop
         if cur_tick < 0 or cur_nimg >= tick_start_nimg + sched.tick_kimg * 1000 or done:
             cur_tick += 1
+            drain()
             torch.cuda.synchronize()
             now = time.time()
             tick_kimg = max((cur_nimg - tick_start_nimg) / 1000.0, 1e-9)
@@ -723,6 +813,8 @@ def training_loop(
             tick_start_time = time.time()
             maintenance_time = tick_start_time - now
 
+    if submitter is not None:
+        submitter.close()
     # Save final snapshot (:527-530).
     if run_dir is not None and rank == 0:
         if final_grids is not None:

@@ -331,6 +331,37 @@ def test_two_rank_graphed_loop_matches_oracle_towers(cuda_device, tmp_path):
     print('worst deviations', oracle.worst)
 
 
+def test_async_submission_equals_synchronous_loop(cuda_device):
+    """The submission thread (training_loop.SubmitThread: the main thread assembles iteration i + 1 while a second thread hands iteration
+    i's copies, graph replays and updates to the device) against the single-thread loop: same stream, same order, so after 9 iterations
+    (refresh, lazy regularisers, three staging sets reused three times) G, D, Gs, pl_mean, dlatent_avg and the Adam powers are bit-identical."""
+    import hashlib
+    from inclusivegan_amd.training import training_loop as TL
+
+    def final(flag):
+        os.environ['IGAN_ASYNC_SUBMIT'] = flag
+        seen = dict(n=0, threads=set())
+        import threading
+
+        def on_it(info):
+            seen['n'] += 1
+            seen['threads'] = {t.name for t in threading.enumerate()}
+            return info['iteration'] >= 9
+        try:
+            out = TL.training_loop(hooks=dict(on_iteration=on_it, async_ok=True), **loop_kwargs(1024, 6, data_size=48))
+        finally:
+            os.environ.pop('IGAN_ASYNC_SUBMIT', None)
+        torch.cuda.synchronize()
+        G, D, Gs = out['G'], out['D'], out['Gs']
+        dig = [hashlib.sha1(t.detach().cpu().numpy().tobytes()).hexdigest() for t in (G.flat_params, D.flat_params, Gs.flat_params, G.vars['dlatent_avg'], G.pl_mean_var)]
+        return dig, seen
+    a, sa = final('1')
+    b, sb = final('0')
+    assert 'igan-submit' in sa['threads'] and 'igan-submit' not in sb['threads']
+    assert sa['n'] == sb['n'] == 9
+    assert a == b
+
+
 CONFIG5 = dict(res=128, fmap=8192, B=3, data_size=240, attr='Smiling', col=31)      # BASELINE config 5 at its own size (minibatch_gpu 3, attribute mask)
 
 
