@@ -1298,12 +1298,19 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
         unsigned char* B = dA + P_IMG;
         // an out-of-range offset stays out of range with the piece offset added
         // (the piece displacement rides in the scalar offset: the instruction's immediate offset would also move the LDS address)
+#ifdef IGAN_PLANES_NO_DMA_A       // TIMING EXPERIMENT ONLY (wrong results): the A operand's three DMA instructions become B re-fetches of the same size
+#define IGAN_A_RSRC rw
+#define IGAN_A_OFF voffB
+#else
+#define IGAN_A_RSRC rx
+#define IGAN_A_OFF offA
+#endif
         if (lowave) {
-            if (j == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)A, 16, offA, 0, 0, 0);
-            if (j == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(A + 2 * 4096), 16, offA, 64, 0, 0);
+            if (j == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(IGAN_A_RSRC, (lds_void*)A, 16, IGAN_A_OFF, 0, 0, 0);
+            if (j == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(IGAN_A_RSRC, (lds_void*)(A + 2 * 4096), 16, IGAN_A_OFF, 64, 0, 0);
             if (j == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(B + 4096), 16, voffB, soffB + 32u, 0, 0);
         } else {
-            if (j == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(A + 4096), 16, offA, 32, 0, 0);
+            if (j == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(IGAN_A_RSRC, (lds_void*)(A + 4096), 16, IGAN_A_OFF, 32, 0, 0);
             if (j == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)B, 16, voffB, soffB, 0, 0);
             if (j == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(B + 2 * 4096), 16, voffB, soffB + 64u, 0, 0);
         }
@@ -1345,14 +1352,16 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
 
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int st = 0;
-#ifndef IGAN_PLANES_INTERLEAVED
-    // Step schedule (round 4).  The two 32x32 tiles of a wave run ONE AFTER THE OTHER (six dependent products each: a chain on one
+#ifdef IGAN_PLANES_TILE_SEQUENTIAL
+    // MEASURED AND NOT KEPT (round 4; -DIGAN_PLANES_TILE_SEQUENTIAL builds it): bit-identical to the default form below and
+    // 1.5 % slower forward, 4 % slower in the weight gradient (tools/planes_sched_ab.sh) -- the vector adds were not what the step waits for.
+    // The two 32x32 tiles of a wave run ONE AFTER THE OTHER (six dependent products each: a chain on one
     // accumulator issues back to back, MI355X_MICROARCH.md), so the vector adds that fold a tile's step sum into its running sum no
     // longer wait behind the whole cluster: tile 0's sixteen adds issue while tile 1's products execute, and tile 1's are deferred
     // to the top of the NEXT step, where they fill the latency of the fragment reads behind the barrier (t1 stays live across the
     // back edge; its next chain starts six products later).  The adds are plain v_add_f32: beside MFMAs a packed add costs 13 issue
     // cycles against 4 (same guide), and the compiler packs them when left alone.  Same products, same order within a tile, same
-    // sums: bit-identical to the interleaved form (-DIGAN_PLANES_INTERLEAVED, kept for A/B).
+    // sums: bit-identical to the interleaved form.
     f32x16 t0, t1 = zero;
     // The adds are inline assembly, so the compiler's hazard recogniser does not see them: a vector read of an MFMA result needs
     // 11 wait states behind the 8-pass write (it put `s_nop 9` there itself in the interleaved form), and nothing in the hardware
@@ -1409,6 +1418,9 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
     }
     fold(acc[1], t1);
 #else
+#ifdef IGAN_PLANES_NO_LDSREAD
+    bf16x8 keep_a[TM][3], keep_b[3];
+#endif
     for (int c = c_begin; c < c_end; c++) {
         // chunk c: issued two iterations ago (three instructions of this wave are younger: chunk c+1)
         asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
@@ -1416,11 +1428,23 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
         const int nst = st >= 1 ? st - 1 : P_NSTAGE - 1;
         const unsigned char* S = smem + st * P_STAGE;
         bf16x8 af[TM][3], bfr[3];
+#ifdef IGAN_PLANES_NO_LDSREAD     // TIMING EXPERIMENT ONLY (wrong results): fragments read once, from the first stage
+        const unsigned char* S0 = (c == c_begin) ? S : smem;
+#else
+        const unsigned char* S0 = S;
+#endif
 #pragma unroll
         for (int q = 0; q < 3; q++) {
-            bfr[q] = *reinterpret_cast<const bf16x8*>(S + fb + q * 4096);
+#ifdef IGAN_PLANES_NO_LDSREAD
+            if (c == c_begin) {
+#endif
+            bfr[q] = *reinterpret_cast<const bf16x8*>(S0 + fb + q * 4096);
 #pragma unroll
-            for (int tm = 0; tm < TM; tm++) af[tm][q] = *reinterpret_cast<const bf16x8*>(S + fa[tm] + q * 4096);
+            for (int tm = 0; tm < TM; tm++) af[tm][q] = *reinterpret_cast<const bf16x8*>(S0 + fa[tm] + q * 4096);
+#ifdef IGAN_PLANES_NO_LDSREAD
+            } else { bfr[q] = keep_b[q]; af[0][q] = keep_a[0][q]; af[1][q] = keep_a[1][q]; }
+            keep_b[q] = bfr[q]; keep_a[0][q] = af[0][q]; keep_a[1][q] = af[1][q];
+#endif
         }
         dma_prep(nst);
         f32x16 t[TM];
@@ -1440,6 +1464,9 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
                 for (int tm = 0; tm < TM; tm++) t[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][i], bfr[o - i], t[tm], 0, 0, 0);
                 ++g;
             }
+#ifdef IGAN_PLANES_NO_FOLD        // TIMING EXPERIMENT ONLY (wrong results): what do the 32 vector adds of a step cost?
+        if (c + 1 == c_end)
+#endif
 #pragma unroll
         for (int tm = 0; tm < TM; tm++) acc[tm] += t[tm];
         st = (st + 1 == P_NSTAGE) ? 0 : st + 1;
@@ -1892,7 +1919,7 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_planes_kernel(WgradArgs a) 
     }
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int st = 0;
-#ifndef IGAN_PLANES_INTERLEAVED
+#ifdef IGAN_PLANES_TILE_SEQUENTIAL
     // step schedule of conv_fwd_planes_kernel (tile after tile, tile 0 folded beside tile 1's products, tile 1 under the next step's reads)
     f32x16 t0, t1 = zero;
     // The adds are inline assembly, so the compiler's hazard recogniser does not see them: a vector read of an MFMA result needs

@@ -275,7 +275,6 @@ def _with_random_source(fn):
     return wrapper
 
 
-@_with_random_source
 class SubmitThread:
     """A second host thread that owns the per-iteration device submissions (input copies, graph replays, optimizer updates), fed in
     order through a queue.  With the HIP runtime's graph packet capture off (inclusivegan_amd/__init__.py) `CUDAGraph.replay()` blocks its
@@ -295,6 +294,11 @@ class SubmitThread:
         self.cond = threading.Condition()
         self.submitted = 0
         self.completed = 0
+        # the submission thread re-takes the GIL after every replay(): with CPython's default 5 ms switch interval the main thread's
+        # NumPy work would hold it off for longer than the work it is meant to hide
+        import sys
+        self._switch = sys.getswitchinterval()
+        sys.setswitchinterval(float(os.environ.get('IGAN_ASYNC_SWITCH_S', '1e-4')))
         self.thread = threading.Thread(target=self._run, name='igan-submit', daemon=True)
         self.thread.start()
 
@@ -338,11 +342,14 @@ class SubmitThread:
         self._check()
 
     def close(self):
+        import sys
         self.q.put(None)
         self.thread.join()
+        sys.setswitchinterval(self._switch)
         self._check()
 
 
+@_with_random_source
 def training_loop(
     G_args                  = {},
     D_args                  = {},

@@ -123,12 +123,13 @@ def test_bench_eight_ranks_at_the_bench_size(cuda_device):
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d['n_gpus'] == 8 and d['steps'] == 2 and d['scaling'] == 'weak' and d['config']['parallelism'] == 'dp8'
+    print(lines[0])
+    assert d['n_gpus'] == 8 and d['steps'] == 2 and d['scaling'] == 'weak' and d['config']['parallelism'] == 'dp8', d
     assert d['config']['data_size'] == 960 and d['config']['data_size'] % (2 * 6 * 8) == 0          # 1000 rounded down
     assert d['config']['global_batch'] == 48 and d['config']['images_per_step'] == 96
     assert abs(d['value'] - 96 / (d['ms_per_step'] * 1e-3)) < 1e-2 * d['value']
-    assert d['rccl'] == {'ranks': 8, 'backend': 'gloo', 'in_graph': False, 'version': None}
-    assert d['hip_graphs']['captured'] and d['hip_graphs']['faithful']
+    assert d['rccl'] == {'ranks': 8, 'backend': 'gloo', 'in_graph': False, 'version': None}, d['rccl']
+    assert d['hip_graphs']['captured'] and d['hip_graphs']['faithful'], d['hip_graphs']
 
 
 @pytest.mark.parametrize('size', ['32x32_fmap256', '128x128_fmap8192'])
