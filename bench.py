@@ -532,7 +532,7 @@ def main():
         'imle_refresh_s': round(state['refresh'][0], 3) if state['refresh'] else None,
         # the four training ops run as replayed hipGraphs, each validated bit for bit against its eager execution after capture
         'hip_graphs': state['graphs'] if state['graphs'] is not None else {'captured': False},
-        'host': {'async_submit': os.environ.get('IGAN_ASYNC_SUBMIT', '1') != '0' and not args.op_times},
+        'host': {'async_submit': os.environ.get('IGAN_ASYNC_SUBMIT', '0') == '1' and not args.op_times},
     }
     if world > 1:
         from inclusivegan_amd.dnnlib.tflib import optimizer as _opt

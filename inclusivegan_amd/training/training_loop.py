@@ -283,7 +283,10 @@ class SubmitThread:
     (profiles/r03_bench_steady_state_bf16_pieces_variant.txt: 94 % busy; host profile: 12.2 of 13.4 s inside replay()).  replay() releases
     the GIL, so the main thread assembles iteration i + 1 (NumPy sampler, pinned staging) while this thread submits iteration i.
     Everything device-side stays on ONE stream in program order: the arithmetic and every buffer hand-over are those of the single-thread
-    loop (tests/test_gpu_loop_parity.py::test_async_submission_equals_synchronous_loop).  IGAN_ASYNC_SUBMIT=0 switches it off."""
+    loop (tests/test_gpu_loop_parity.py::test_async_submission_equals_synchronous_loop: bit-identical).
+    MEASURED AND NOT THE DEFAULT (round 4, same-box A/B over 96 iterations): 237 / 269 img/s against 262 / 291 with
+    CPython's 5 ms GIL switch interval, 273 / 279 against 279 / 287 with 0.1 ms -- the second thread's GIL hand-overs between replays cost
+    more than the ~3 ms of host work they hide.  IGAN_ASYNC_SUBMIT=1 switches it on."""
 
     def __init__(self, device):
         import queue
@@ -681,10 +684,10 @@ def training_loop(
     if 'on_start' in hooks:
         hooks['on_start'](dict(G=G, D=D, Gs=Gs, lpips=lpips, feed=feed, training_set=training_set, G_opt=G_opt, D_opt=D_opt))
     stop = False
-    # Submission thread (SubmitThread): on unless switched off, or a hook wants to look at device state after every op / time the ops
+    # Submission thread (SubmitThread; off by default: measured slower, see its docstring): never when a hook wants to look at device state after every op / time the ops
     # (those hooks are synchronous by contract: the parity tests).  A hook set may carry 'async_ok': True to say that its on_iteration
     # does not read device state without calling info['drain']() first (bench.py); otherwise the queue is drained before on_iteration.
-    use_async = (os.environ.get('IGAN_ASYNC_SUBMIT', '1') != '0' and use_graphs and not any(k in hooks for k in ('on_op', 'op_times', 'on_batch')))
+    use_async = (os.environ.get('IGAN_ASYNC_SUBMIT', '0') == '1' and use_graphs and not any(k in hooks for k in ('on_op', 'op_times', 'on_batch')))
     submitter = SubmitThread(device) if use_async else None
     submit = submitter.submit if use_async else (lambda fn: fn())
     drain = submitter.drain if use_async else (lambda: None)
