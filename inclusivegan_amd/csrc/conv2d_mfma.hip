@@ -1205,7 +1205,19 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
     if (a.xcd_remap && bid < a.full_tiles) {
         const int per_class = a.nx * a.ny;
         const int lo = (bid / per_class) * per_class;
-        bid = lo + remap_xcd(bid - lo, min(per_class, a.full_tiles - lo));
+        const int cnt = min(per_class, a.full_tiles - lo);
+        bid = lo + remap_xcd(bid - lo, cnt);
+        // Round 4, STRIDE-2 convolutions only: inside an XCD's contiguous range the tiles run N-TILE FASTEST (when the class is whole).
+        // The tile list is m-tile fastest, so an XCD's range is ~nx / 8 m-tiles of ONE filter column block: the ny column blocks of an
+        // m-tile run on ny different XCDs and each fetches the m-tile's rows into its own L2.  With the column blocks adjacent in the
+        // range they share one L2.  Measured (tools/planes_sched_ab.sh, profiles/r04_planes_experiments.txt): D 64 Conv1_down forward
+        // 384 -> 359 us, the data gradient of G 64 Conv0_up 385 -> 359 us (at stride 2 the taps of a slice share few rows, the x image
+        // is the traffic); stride-1 layers lose 0.5-1.3 % (their rows are re-read by the nine taps from L2 anyway, and the filter
+        // slices of ny column blocks compete for it), so they keep the m-major order.  Placement only: digests equal.
+        if (cnt == per_class && a.ny > 1 && a.stride > 1) {
+            const int j = bid - lo;
+            bid = lo + (j % a.ny) * a.nx + j / a.ny;
+        }
     }
     const bool sliced = bid >= a.full_tiles;
     const int tail = bid - a.full_tiles;
