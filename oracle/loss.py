@@ -2,7 +2,9 @@
 
 CPU restatement of training/loss.py: G_logistic_ns_rec_interp_arb_pathreg :19-91 and
 D_logistic_r1 :93-113, on the oracle networks.  Random draws from `rand` in the reference's order.
-Parity unpinned at the reference level (TF, no tests); the arithmetic follows the cited lines.
+PINNED (round 4): tests/golden/ref_train_golden.npz holds the outputs of the reference's own loss.py executed under tests/golden/np_tf.py
+(both functions, weights 2.5 and 0, every autosummary term, pl_mean update); tests/test_ref_train_golden.py requires this file to reproduce
+them to 1e-9.  `tf.gradients` is the one statement that cannot be executed (inherent).
 """
 import numpy as np
 import torch

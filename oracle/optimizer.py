@@ -4,6 +4,9 @@ The reference's own `SimpleAdam` arithmetic (dnnlib/tflib/optimizer.py:318-332: 
 identically" to tf.train.AdamOptimizer under tflib.Optimizer), the non-finite-gradient skip
 (:237-239) and the EMA of Network.setup_as_moving_average_of (dnnlib/tflib/network.py:341-351),
 restated in NumPy float32 on flat arrays.
+PINNED (round 4): tests/golden/ref_train_golden.npz holds the weights the reference's own Optimizer.apply_updates + SimpleAdam produce step
+by step (one / two devices, a non-finite step, the accumulation branch) and the results of setup_as_moving_average_of, executed under
+tests/golden/np_tf.py; tests/test_ref_train_golden.py requires this file to reproduce them.
 """
 import numpy as np
 

@@ -15,7 +15,8 @@ losses / Adam so that a recorded run of the HIP loop can be replayed op by op:
 
 Weights live as flat fp32 NumPy arrays in the HIP buckets' layout (`layout`: name -> (offset, count, shape)); every op builds
 `dtype` (fp64 by default) parameter tensors from them, evaluates oracle/loss.py, and applies oracle/optimizer.py.
-Parity unpinned at the reference level (TensorFlow), like the losses it drives.
+Round 4: the pieces it composes are pinned to the reference's executed code -- the losses (oracle/loss.py), the optimizer set-up, the
+registered objectives and Gs_beta (oracle/training_loop.py helpers), scaling / summation / gate / Adam (oracle/optimizer.py).
 """
 import numpy as np
 import torch

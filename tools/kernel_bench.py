@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Single-kernel microbenchmarks for roofline evidence (run bare, or under rocprofv3 --pmc ...).
-  python tools/kernel_bench.py conv     [batch] [reps]   modulated conv 128x128 (north-star GEMM shape) -> TFLOP/s vs 157.3
+  python tools/kernel_bench.py conv     [batch] [reps]   modulated conv 128x128 (north-star GEMM shape) -> TFLOP/s vs the form's peak (416.7 fp32-equivalent for the default bf16-piece form, 157.3 with IGAN_CONV_PLANES=0)
   python tools/kernel_bench.py upfirdn  [batch] [reps]   the three upfirdn2d call sites at 128x128     -> GB/s vs 8 TB/s
   python tools/kernel_bench.py epilogue [batch] [reps]   fused noise+bias+lrelu forward / backward      -> GB/s
 Algorithmic bytes = (numel_in + numel_out) * 4."""
@@ -11,6 +11,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
+
+PIECE_FORM = os.environ.get('IGAN_CONV_PLANES', '1') != '0'      # the large 3x3 layers run in the bf16-piece form by default
+PEAK = 2500.0 / 6 if PIECE_FORM else 157.3                       # fp32-equivalent TFLOP/s: bf16 dense peak / 6 piece products, or the f32 matrix peak
+PIECE_PEAK = PEAK
 
 from inclusivegan_amd import hip_ops  # noqa: E402
 
@@ -43,7 +47,7 @@ def main():
         g = hip_ops.ConvGeom(3, 3, 1, 1, 1, 1)
         ms = time_ms(lambda: hip_ops.conv2d_raw(x, w, g, (128, 128), 128, in_scale=s, out_scale=d), reps)
         fl = 2.0 * B * 128 * 128 * 128 * 128 * 9
-        print('modconv 128x128 B=%d: %.1f us  %.1f TFLOP/s  = %.1f %% of 157.3' % (B, ms * 1e3, fl / ms / 1e9, fl / ms / 1e9 / 157.3 * 100))
+        print('modconv 128x128 B=%d: %.1f us  %.1f TFLOP/s  = %.1f %% of %.1f' % (B, ms * 1e3, fl / ms / 1e9, fl / ms / 1e9 / PEAK * 100, PEAK))
     elif mode == 'upfirdn':
         k = np.outer([1, 3, 3, 1], [1, 3, 3, 1]).astype(np.float32) / 64
         sites = [('G Conv0_up post-filter  [B,129,129,128] pad 1/1 x4', (B, 129, 129, 128), k * 4, 1, 1),
