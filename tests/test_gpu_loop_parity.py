@@ -414,8 +414,10 @@ def test_config5_at_its_own_size_matches_oracle(cuda_device):
 
 def test_config5_two_ranks_at_its_own_size_match_oracle_towers(cuda_device, tmp_path):
     """Config 5's shape on TWO ranks (GPU 0, gloo) at 128x128 / fmap_base 8192 / minibatch_gpu 3 / attribute mask: two iterations,
-    replicas bit-identical, the ranks' slices tile the masked global minibatch, and the G and D ops of iteration 1 equal the oracle's
-    two towers with 1 / 2-scaled summed gradients (optimizer.py:186,199).  The RCCL leg itself needs more than one device."""
+    replicas bit-identical, the ranks' slices tile the masked global minibatch, and the G op of iteration 1 equals the oracle's two
+    towers with 1 / 2-scaled summed gradients (optimizer.py:186,199; the D, G_reg and D_reg ops at this size are the one-rank test's, the
+    two-tower D op at 32x32 test_two_rank_graphed_loop_matches_oracle_towers's); the optimizer / moving-average bookkeeping is checked on
+    every op of both iterations.  The RCCL leg itself needs more than one device."""
     c = CONFIG5
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'dist_worker.py'), 'record5', str(r), '2', str(port), str(tmp_path)],
@@ -428,12 +430,12 @@ def test_config5_two_ranks_at_its_own_size_match_oracle_towers(cuda_device, tmp_
         assert np.array_equal(logs[0]['final'][k], logs[1]['final'][k]), k
     for a, b in zip([o for o in logs[0]['ops'] if o['name'] == 'G'], [o for o in logs[1]['ops'] if o['name'] == 'G']):
         assert np.array_equal(np.concatenate([a['latents_rec_1'], b['latents_rec_1']]), a['global_latents_rec_1'].astype(np.float32))
-    oracle = TeacherForcedOracle(c['fmap'], c['B'], world=2, select=lambda j, name, it: it == 0 and name in ('G', 'D'), res=c['res'])
+    oracle = TeacherForcedOracle(c['fmap'], c['B'], world=2, select=lambda j, name, it: it == 0 and name == 'G', res=c['res'])
     oracle.start(logs[0]['init'])
     for r0, r1 in zip(logs[0]['ops'], logs[1]['ops']):
         oracle.consume([r0, r1])
     oracle.finish(logs[0]['final'])
-    assert [e[1] for e in oracle.evaluated] == ['G', 'D']
+    assert [e[1] for e in oracle.evaluated] == ['G']
     print('config 5 @128 world 2: worst deviations', oracle.worst)
 
 
