@@ -29,6 +29,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+_LAUNCH_AFFINITY = os.sched_getaffinity(0) if hasattr(os, 'sched_getaffinity') else None      # before this rank confines itself to its GPU's socket
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
@@ -351,7 +352,9 @@ def cpu_baseline_subprocess(resolution, batch, lpips_weight, timeout_s=600):
             'print("CPU_BASELINE " + json.dumps(b))' % (ROOT, resolution, batch, lpips_weight))
     env = dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
     try:
-        r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=timeout_s, env=env)
+        # the CPU baseline uses the host as the launcher gave it to us, not the one socket this rank pinned itself to
+        unpin = (lambda: os.sched_setaffinity(0, _LAUNCH_AFFINITY)) if _LAUNCH_AFFINITY else None
+        r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=timeout_s, env=env, preexec_fn=unpin)
         for line in r.stdout.splitlines():
             if line.startswith('CPU_BASELINE '):
                 return json.loads(line[len('CPU_BASELINE '):])
@@ -425,6 +428,10 @@ def main():
     backend = args.backend
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
+    from inclusivegan_amd import hostaffinity
+    host_threads = hostaffinity.limit_host_threads()         # a small CPU pool: graph replays are host submissions, and a 128-thread OpenMP pool starves them
+    pinned = hostaffinity.pin_to_device_node(local_rank)      # IGAN_PIN_NUMA=1 only
+    log('host: %d intra-op CPU threads, NUMA pinning %s' % (host_threads, ('%d cpus' % len(pinned)) if pinned else 'off'))
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if backend == 'nccl':
@@ -532,7 +539,7 @@ def main():
         'imle_refresh_s': round(state['refresh'][0], 3) if state['refresh'] else None,
         # the four training ops run as replayed hipGraphs, each validated bit for bit against its eager execution after capture
         'hip_graphs': state['graphs'] if state['graphs'] is not None else {'captured': False},
-        'host': {'async_submit': os.environ.get('IGAN_ASYNC_SUBMIT', '0') == '1' and not args.op_times},
+        'host': {'async_submit': os.environ.get('IGAN_ASYNC_SUBMIT', '0') == '1' and not args.op_times, 'cpu_threads': host_threads, 'pinned_to_gpu_numa_node': None if pinned is None else '%d cpus' % len(pinned)},
     }
     if world > 1:
         from inclusivegan_amd.dnnlib.tflib import optimizer as _opt

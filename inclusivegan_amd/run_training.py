@@ -159,6 +159,9 @@ def main():
     import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
     torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+    from . import hostaffinity
+    hostaffinity.limit_host_threads()           # one process per GPU with a small CPU pool (hostaffinity.py: a 128-thread OpenMP pool starves the graph submissions)
+    hostaffinity.pin_to_device_node(int(os.environ.get('LOCAL_RANK', '0')))     # IGAN_PIN_NUMA=1 only
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         import datetime

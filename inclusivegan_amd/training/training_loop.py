@@ -510,6 +510,7 @@ def training_loop(
         reals=torch.zeros((2 * B, C, R, R), device=device, dtype=torch.uint8), labels=torch.zeros((2 * B, LS), device=device))
     staging = [dict({k: torch.empty(v.shape, dtype=torch.float32).pin_memory() for k, v in feed.items() if '_rec_' in k},
                     event=torch.cuda.Event()) for _ in range(3)]
+    stage_np = [{k: v.numpy() for k, v in st.items() if k != 'event'} for st in staging]       # views of the pinned buffers (same memory)
     use_graphs = graphs.graphs_enabled(hip_graphs)
     # Gradient exchange: chunk by chunk DURING backward (tflib/optimizer.py GradientExchange), inside the captured graph
     # when the process group's collectives can be captured (RCCL); otherwise (gloo) one all-reduce after each replay.
@@ -727,7 +728,9 @@ def training_loop(
             stage['event'].synchronize()            # ... and has run
             for h, (r_, l_, z_) in enumerate(halves):
                 for key, arr in (('reals_rec_%d', r_), ('labels_rec_%d', l_), ('latents_rec_%d', z_)):
-                    stage[key % (h + 1)].copy_(torch.from_numpy(np.ascontiguousarray(arr[rs], dtype=np.float32)))
+                    # filled through the pinned tensor's NumPy view: a torch CPU copy_ would open a parallel region over PyTorch's whole
+                    # intra-op pool (128 threads on this host) for 600 KB -- inclusivegan_amd/hostaffinity.py has the measurement
+                    np.copyto(stage_np[running_mb_counter % len(staging)][key % (h + 1)], arr[rs], casting='same_kind')
 
             def upload(stage=stage):
                 for key in stage:
