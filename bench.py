@@ -36,13 +36,38 @@ if ROOT not in sys.path:
 F32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (about 6.3 TB/s achievable)
 BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense" (v_mfma_f32_32x32x16_bf16, 1024 FLOP/clk/SIMD)
-PIECE_PRODUCTS = 6               # bf16-piece form: a0b0, a0b1, a1b0, a0b2, a1b1, a2b0 per fp32 product -> fp32-equivalent peak = 2500 / 6
-PIECE_FORM_PEAK_TFLOPS = BF16_DENSE_PEAK_TFLOPS / PIECE_PRODUCTS      # 416.7 fp32-equivalent TFLOP/s
+# matrix instructions per fp32 product in a piece form (csrc/conv2d_mfma.hip): 1 = three bf16 pieces: a0b0, a0b1, a1b0, a0b2, a1b1, a2b0;
+# 2 = two fp16 pieces with a per-tensor power-of-two scale: p0p0, p0p1, p1p0.  fp32-equivalent peak = 2500 / products (fp16 and bf16 MFMA run at the same rate)
+PIECE_PRODUCTS_BY_FORM = {1: 6, 2: 3}
+PIECE_DTYPE = {0: 'f32',
+               1: 'f32 (3x3 convs: exact 3-piece bf16 split, fp32 sums)',
+               2: 'f32 (3x3 convs: 2-piece fp16 split under a per-tensor power-of-two scale, fp32 sums)'}
+
+
+def piece_form():
+    """Which form the large 3x3 convolutions run in (csrc/conv2d_mfma.hip planes_mode; igan_conv_piece_form() is the library's own answer):
+    IGAN_CONV_PLANES=0 -> 0 (fp32 matrix instruction everywhere), unset / 1 -> 1 (three bf16 pieces), 2 -> 2 (two fp16 pieces)."""
+    v = os.environ.get('IGAN_CONV_PLANES')
+    try:
+        m = int(v) if v is not None else DEFAULT_PIECE_FORM
+    except ValueError:
+        m = 0
+    return 0 if m == 0 else (2 if m == 2 else 1)
+
+
+DEFAULT_PIECE_FORM = 1
 
 
 def piece_form_on():
-    """The large 3x3 convolutions run in the bf16-piece form unless IGAN_CONV_PLANES=0 (csrc/conv2d_mfma.hip planes_enabled)."""
-    return os.environ.get('IGAN_CONV_PLANES', '1') != '0'
+    return piece_form() != 0
+
+
+def piece_products():
+    return PIECE_PRODUCTS_BY_FORM[piece_form()]
+
+
+def piece_form_peak():
+    return BF16_DENSE_PEAK_TFLOPS / piece_products()
 
 
 def family_of(kernel_name):
@@ -52,7 +77,7 @@ def family_of(kernel_name):
 
 
 def family_peak(family):
-    return PIECE_FORM_PEAK_TFLOPS if 'planes' in family else F32_MATRIX_PEAK_TFLOPS
+    return piece_form_peak() if 'planes' in family else F32_MATRIX_PEAK_TFLOPS
 
 
 def file_sha16(path):
@@ -95,6 +120,7 @@ def parse_args():
     p.add_argument('--no-variant-line', action='store_true', help='skip the second, labelled measurement with the other convolution form (a child run of this script; default path: the exact-fp32 run)')
     p.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='process-group backend for --gpus > 1 (nccl = RCCL; gloo for the one-GPU tests)')
     p.add_argument('--one-gpu', action='store_true', help='test hook: every rank on device 0 (needs --backend gloo: RCCL refuses two ranks on one device)')
+    p.add_argument('--revalidate-every', type=int, default=0, help='stress check: every N iterations (untimed work inside the loop) replay each captured op against its eager execution again; the results land in hip_graphs.checks')
     p.add_argument('--op-times', action='store_true', help='also report the mean device time of each training op (HIP events)')
     p.add_argument('--conv-shapes', default=None, metavar='FILE', help='write the per-shape table of the conv family inside the replayed graphs (device stamps) to FILE')
     return p.parse_args()
@@ -129,7 +155,7 @@ def headline_shape_roofline(device, batch, reps=40, warm_s=0.4):
     ms = e0.elapsed_time(e1) / reps
     flops = 2.0 * batch * res * res * cout * cin * 9
     achieved = flops / (ms * 1e-3) / 1e12
-    peak = PIECE_FORM_PEAK_TFLOPS if piece_form_on() else F32_MATRIX_PEAK_TFLOPS
+    peak = piece_form_peak() if piece_form_on() else F32_MATRIX_PEAK_TFLOPS
     out = dict(shape='modulated conv 128x128 3x3 Cin=Cout=128 batch %d (M=%d N=128 K=1152)' % (batch, batch * res * res),
                kernel='conv_fwd_planes_kernel (whole call: x image + filter image + tile kernel)' if piece_form_on() else 'conv_fwd_dma_kernel<false, true>',
                achieved=round(achieved, 2), peak=round(peak, 1), frac=round(achieved / peak, 4),
@@ -231,7 +257,7 @@ def step_roofline(stamp, steps, shapes_file=None):
             f.write('# total %.1f ms, %.1f TFLOP/s\n' % (fam_secs * 1e3, fam_flops / max(fam_secs, 1e-12) / 1e12))
             f.write('# per family: ' + '; '.join('%s %.1f ms %.1f TFLOP/s' % (k, v[2] * 1e3, v[1] / v[2] / 1e12) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][2])) + '\n')
     out = dict(bound='mfma', **entry(name))
-    out['peak_note'] = ('bf16 dense peak %.0f / %d piece products (fp32-equivalent)' % (BF16_DENSE_PEAK_TFLOPS, PIECE_PRODUCTS)) if 'planes' in name else 'f32 matrix peak (v_mfma_f32_32x32x2_f32)'
+    out['peak_note'] = ('%s dense peak %.0f / %d piece products (fp32-equivalent)' % ('fp16' if piece_form() == 2 else 'bf16', BF16_DENSE_PEAK_TFLOPS, piece_products())) if 'planes' in name else 'f32 matrix peak (v_mfma_f32_32x32x2_f32)'
     out['conv_family_tflops'] = round(fam_flops / max(fam_secs, 1e-12) / 1e12, 2)
     out['conv_family_ms_per_iteration'] = round(fam_secs * 1e3 / max(replays.values()), 3)
     out['timing'] = 'device stamps inside the replayed hipGraphs'
@@ -363,22 +389,28 @@ def cpu_baseline_subprocess(resolution, batch, lpips_weight, timeout_s=600):
         return dict(value=None, unit='img/s', cores=0, kind='port', sample='cpu baseline exceeded %d s' % timeout_s)
 
 
-def second_line(args, timeout_s=900):
-    """The SECOND, labelled line: the same steady-state measurement with the switch of the convolution form flipped -- a child process,
-    because the switch is read once per process (small data set: the refresh is not the subject).  The default path runs the large 3x3
-    convolutions in the bf16-piece form (three bf16 pieces per fp32 operand, six products, fp32 sums: all 24 significand bits, parity
-    tests at the fp32 tolerances), so the second line is the EXACT-fp32-instruction run (IGAN_CONV_PLANES=0); a run that is itself started
-    with IGAN_CONV_PLANES=0 reports the piece form as its second line."""
+FORM_LABEL = {
+    0: 'exact fp32: every convolution on v_mfma_f32_32x32x2_f32 (IGAN_CONV_PLANES=0); everything else as in the headline',
+    1: '3x3 convolutions (forward, data gradient, weight gradient) as 3 bf16 pieces x 6 products with fp32 sums (IGAN_CONV_PLANES=1)',
+    2: '3x3 convolutions as 2 fp16 pieces x 3 products under a per-tensor power-of-two scale, fp32 sums (IGAN_CONV_PLANES=2)',
+}
+FORM_KEY = {0: 'second_line_exact_fp32', 1: 'line_bf16_pieces', 2: 'line_fp16_pairs'}
+
+
+def second_line(args, form, timeout_s=900):
+    """A labelled line next to the headline: the same steady-state measurement with the convolution form `form` -- a child process,
+    because the switch is read once per process (small data set: the refresh is not the subject).  The headline runs whichever form is the
+    default (or the environment asks for); the EXACT-fp32-instruction run (IGAN_CONV_PLANES=0) is always reported, and so is the other
+    piece form."""
     import subprocess
-    other = '0' if piece_form_on() else '1'
+    other = str(form)
     env = dict(os.environ, IGAN_CONV_PLANES=other)
     # at least 200 timed iterations after 40 of warm-up: short-window rates swing with the thermal state the headline run left behind
     steps, warmup = max(args.steps, 200), max(args.warmup, 40)
     cmd = [sys.executable, os.path.abspath(__file__), '--steps', str(steps), '--warmup', str(warmup), '--data-size', '1152',
            '--minibatch-gpu', str(args.minibatch_gpu), '--resolution', str(args.resolution), '--lpips-weight', str(args.lpips_weight),
            '--no-cpu-baseline', '--no-variant-line']
-    label = ('exact fp32: every convolution on v_mfma_f32_32x32x2_f32 (IGAN_CONV_PLANES=0); everything else as in the headline' if other == '0' else
-             '3x3 convolutions (forward, data gradient, weight gradient) as 3 bf16 pieces x 6 products with fp32 sums (the default form)')
+    label = FORM_LABEL[form]
     try:
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s)
         d = json.loads(r.stdout.strip().splitlines()[-1])
@@ -459,6 +491,8 @@ def main():
     def on_iteration(info):
         state['iters'] += 1
         log('iteration %d done' % state['iters'])
+        if args.revalidate_every and state['iters'] % args.revalidate_every == 0:
+            info['revalidate_graphs']('iteration %d' % state['iters'])
         if state['iters'] == args.warmup and args.warmup > 0:
             info['drain']()         # the loop hands its device work to a submission thread: everything up to here has been issued ...
             barrier_sync()          # ... and has run
@@ -513,7 +547,7 @@ def main():
         total_kimg=10 ** 6, data_size=data_size, num_epochs=10000,
         init_staleness=10, num_samples_factor=args.num_samples_factor, knn_perturb_factor=0.05, candidate_batch_size=256,
         hooks=dict(on_iteration=on_iteration, on_refresh=on_refresh, on_graphs=lambda g: state.__setitem__('graphs', g), async_ok=True,
-                   **({'op_times': state.setdefault('op_times', {})} if args.op_times else {})),
+                   **({'op_times': state.setdefault('op_times', {}), 'op_host_times': state.setdefault('op_host_times', {})} if args.op_times else {})),
     )
     log('starting training loop')
     import contextlib
@@ -530,7 +564,7 @@ def main():
         'metric': 'training img/sec (whole node), CelebA 128x128 StyleGAN2+IMLE',
         'value': round(imgs / elapsed, 3), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32 (3x3 convs: exact 3-piece bf16 split, fp32 sums)' if piece_form_on() else 'f32',
+        'dtype': PIECE_DTYPE[piece_form()],
         'data': 'synthetic',
         'config': {'workload': 'CelebA-shaped %dx%d StyleGAN2+IMLE, config-e-Gskip-Dresnet (fmap_base 8192), minibatch_gpu %d, '
                                'NN_rec_lpips_weight %g, lazy reg G/4 D/16, random-init weights' % (args.resolution, args.resolution, B, args.lpips_weight),
@@ -552,10 +586,18 @@ def main():
         # data_size * init_staleness images (training_loop.py:354), so over the first period the throughput is
         period = data_size * 10
         out['amortised_img_s'] = round(period / (period / out['value'] + state['refresh'][0]), 3)
+    if piece_form() == 2:
+        # how often the two-piece fp16 form met an element outside the window in which it is exact to 2^-24 (more than 2^26 below its tensor's largest)
+        import ctypes
+        below, imaged = ctypes.c_ulonglong(0), ctypes.c_ulonglong(0)
+        _abi.check(_abi.get_plugin().igan_debug_f16_window(ctypes.byref(below), ctypes.byref(imaged), 0))
+        out['fp16_pairs_window'] = {'elements_imaged': imaged.value, 'nonzero_elements_below_exact_window': below.value,
+                                    'fraction': (below.value / imaged.value) if imaged.value else 0.0}
     if args.op_times:
         torch.cuda.synchronize()
         out['op_ms'] = {k: round(sum(a.elapsed_time(b) for a, b in v[2:]) / max(len(v) - 2, 1), 3) for k, v in state['op_times'].items()}
         out['op_calls'] = {k: len(v) for k, v in state['op_times'].items()}
+        out['op_host_ms'] = {k: round(sum(v[2:]) / max(len(v) - 2, 1) * 1e3, 3) for k, v in state['op_host_times'].items()}     # host time inside the op's call
     if rank == 0:
         if not args.no_roofline:
             from inclusivegan_amd import hip_ops
@@ -575,8 +617,10 @@ def main():
             if isinstance(knn, dict) and knn.get('value'):
                 knn['gpu_queries_per_s'] = knn_gpu(device, knn['num_points'], knn['dim'])
         if world == 1 and not args.no_variant_line:
-            log('second line: the other convolution form (child run)')
-            out['second_line_exact_fp32' if piece_form_on() else 'second_line_bf16_pieces'] = second_line(args)
+            for form in (0, 1, 2):
+                if form != piece_form():
+                    log('labelled line: convolution form %d (child run)' % form)
+                    out[FORM_KEY[form]] = second_line(args, form)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()

@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 /* Bumped whenever a struct layout or a signature changes (2: fused conv epilogue fields, fp64 nearest-neighbour state). */
-#define IGAN_ABI_VERSION 6
+#define IGAN_ABI_VERSION 7
 
 typedef void* igan_stream_t; /* hipStream_t */
 
@@ -256,6 +256,15 @@ int igan_conv2d_wgrad_kernel_name(const igan_conv2d_wgrad_params* p, char* buf, 
  * image for it?" -- so that a host does not restate the rules.  Both return 0 / 1. */
 int igan_conv_pieces_wanted(int KH, int KW, int Cin, int Cout);
 int igan_pieces_image_ok(int N, int HW, int C);
+/* ABI v7: which piece form this process runs (read once from IGAN_CONV_PLANES): 0 = none (every convolution on the fp32 matrix instruction),
+ * 1 = three bf16 pieces / six products (the default), 2 = the two-piece fp16 VARIANT: per-tensor power-of-two scale, p0 = fp16(v S),
+ * p1 = fp16((v S - p0) 2^11), three products (main term folded per 16-deep step by the vector ALU, cross terms chained in the matrix pipe),
+ * exact to 2^-24 for every element within 2^26 of its tensor's largest magnitude.  Piece images of form 2 live in the
+ * SAME buffers (N * HW * C * 6 bytes): 4 bytes per element of image, then the tensor's block maxima and 1 / S -- callers need not know. */
+int igan_conv_piece_form(void);
+/* Diagnostic for form 2 (synchronises the device): non-zero elements imaged so far BELOW the exact window (|v S| < 2^-12) and elements imaged in
+ * all; reset != 0 zeroes both counters. */
+int igan_debug_f16_window(unsigned long long* below, unsigned long long* imaged, int reset);
 
 /* bf16-piece form (default for the large 3x3 layers, IGAN_CONV_PLANES=0 switches it off -- DESIGN.md section 4): the piece image of a channel-minor tensor
  * x [N, HW, C] (times scale [N, C] when given), `out` = N * HW * C * 6 bytes, 16-byte aligned, C % 16 == 0.  The convolution entry

@@ -114,7 +114,7 @@ class TapsParams(ctypes.Structure):
                 ('taps', ctypes.c_int), ('n', ctypes.c_int), ('scale', ctypes.c_float)]
 
 
-ABI_VERSION = 6      # include/igan_hip.h IGAN_ABI_VERSION
+ABI_VERSION = 7      # include/igan_hip.h IGAN_ABI_VERSION
 STRUCTS = (UpFirDn2DParams, FusedBiasActParams, Conv2DParams, Conv2DWgradParams, DenseParams, DenseWgradParams, TapsParams)   # igan_struct_size ids
 
 DENSE_MAX_GROUPS = 24
@@ -149,6 +149,8 @@ SIGNATURES = {
     'igan_to_pieces': (_I, [_P, _P, _P, _P, _I, _I, _I]),
     'igan_conv_pieces_wanted': (_I, [_I, _I, _I, _I]),
     'igan_pieces_image_ok': (_I, [_I, _I, _I]),
+    'igan_conv_piece_form': (_I, []),
+    'igan_debug_f16_window': (_I, [_P, _P, _I]),
     'igan_dense_small': (_I, [_P, ctypes.POINTER(DenseParams)]),
     'igan_dense_small_wgrad': (_I, [_P, ctypes.POINTER(DenseWgradParams)]),
     'igan_dense_small_grouped': (_I, [_P, ctypes.POINTER(DenseParams), _I]),

@@ -1181,10 +1181,199 @@ __global__ __launch_bounds__(256) void filter_planes_kernel(const float* __restr
         }
 }
 
+
+// ------------------------------------------------------------------------------
+// TWO-PIECE fp16 form of the piece kernels (IGAN_CONV_PLANES=2; a VARIANT, not the default: tools/piece_shape_probe.hip).
+//
+// Arithmetic.  fp16 carries 11 significand bits, so TWO pieces hold an fp32 value to 2^-24: with a per-tensor power-of-two scale S that brings
+// the tensor's largest magnitude into [2^14, 2^15) (exact: an exponent shift),  p0 = fp16(v S),  p1 = fp16((v S - p0) 2^11)  (|p1| <= |p0|: the
+// second piece is stored 2^11 up so that it lives in fp16's normal range too), and  v S = p0 + 2^-11 p1  to 2^-24 |v S| for every element within
+// 2^-26 of the tensor's largest (below that, one bit less per binade: fp16's subnormals; fp32 has the exponent range, this form does not -- which
+// is why it is a variant).  A product is three matrix instructions instead of six:
+//     a b = (Sa Sb)^-1 [ p0a p0b + 2^-11 (p0a p1b + p1a p0b) ]        (dropped: 2^-22 p1a p1b <= 2^-24 |a b|, typically 2^-26)
+// the main term exactly as in the bf16 form (each 16-deep step from an exact zero, folded into the running fp32 sum by the vector ALU), the two
+// cross terms chained in a second accumulator of the matrix pipe (they carry 2^-11 of the result: the instruction's own rounding of them is
+// 2^-35 of it).  Image layout [pixel][C/16][2][16] fp16 = 4 B per element -- the SAME buffers the bf16 form sizes at 6 B per element hold it and,
+// behind it (byte offset 4 * elements), a trailer of floats: partial[256] (block maxima of |v|, written by amax_partial_kernel), then 1 / S.
+// No host involvement, no atomics: the maxima are combined by every block that needs S (max is order-independent: bit-reproducible).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr int H_PARTIALS = 1024;     // block maxima per image (four per thread of a 256-thread consumer)
+// Diagnostic (igan_debug_f16_window): how many non-zero elements were imaged BELOW the window in which the two pieces are exact to 2^-24
+// (|v S| < 2^-12, i.e. more than 2^26 below the tensor's largest magnitude), and how many elements were imaged in all.
+__device__ unsigned long long g_f16_below_window = 0ull, g_f16_imaged = 0ull;
+
+__device__ __forceinline__ float image_amax(const float* trailer, float* red);
+__device__ __forceinline__ float block_max_256(float v, float* red) {      // all 256 threads receive the maximum
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// S = 2^(14 - floor(log2 amax)) as a float (amax = 0, subnormal or below 2^-112: the largest shift that keeps 1 / S normal; inf / nan: 2^-113)
+__device__ __forceinline__ float scale_from_amax(float amax) {
+    int e = (int)((__float_as_uint(amax) >> 23) & 0xFFu);
+    e = max(15, min(e, 254));
+    return __uint_as_float((unsigned)(268 - e) << 23);
+}
+__device__ __forceinline__ float inv_scale_from_amax(float amax) {
+    int e = (int)((__float_as_uint(amax) >> 23) & 0xFFu);
+    e = max(15, min(e, 254));
+    return __uint_as_float((unsigned)(e - 14) << 23);
+}
+
+__device__ __forceinline__ float image_amax(const float* trailer, float* red) {       // the tensor's largest magnitude from its H_PARTIALS block maxima
+    // The trailer is a few KiB at a fixed address that one kernel writes from every XCD and the next reads from every XCD, replay after replay:
+    // it is read and written at DEVICE scope (past the XCDs' L2s), so that its coherence does not rest on the kernel-boundary cache maintenance.
+    float m = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) m = fmaxf(m, __hip_atomic_load(trailer + 4 * threadIdx.x + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    return block_max_256(m, red);
+}
+__device__ __forceinline__ void count_window(int below, float* red) {      // per block: one atomic when anything is to be counted (diagnostic)
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) below += __shfl_xor(below, o);
+    if ((threadIdx.x & 63) == 0 && below != 0) atomicAdd(&g_f16_below_window, (unsigned long long)below);
+}
+
+// block maxima of |x * scale| over a flat fp32 array of n4 float4s (scale [N][C] per (sample, channel) or NULL; C % 4 == 0)
+__global__ __launch_bounds__(256) void amax_partial_kernel(const float* __restrict__ x, const float* __restrict__ scale, float* __restrict__ partial,
+                                                            int n4, int C4, int HWC4) {
+    __shared__ float red[4];
+    float m = 0.0f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += 2 * H_PARTIALS * 256) {      // two loads in flight per lane
+        const int j = i + H_PARTIALS * 256;
+        float4 v = reinterpret_cast<const float4*>(x)[i];
+        float4 q = (j < n4) ? reinterpret_cast<const float4*>(x)[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (scale != nullptr) {
+            const float4 f = reinterpret_cast<const float4*>(scale)[(i / HWC4) * C4 + i % C4];
+            v.x *= f.x; v.y *= f.y; v.z *= f.z; v.w *= f.w;
+            if (j < n4) {
+                const float4 g = reinterpret_cast<const float4*>(scale)[(j / HWC4) * C4 + j % C4];
+                q.x *= g.x; q.y *= g.y; q.z *= g.z; q.w *= g.w;
+            }
+        }
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fmaxf(fabsf(q.z), fabsf(q.w))));
+    }
+    m = block_max_256(m, red);
+    if (threadIdx.x == 0) __hip_atomic_store(partial + blockIdx.x, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void split2(float vs, unsigned short (&o)[2]) {        // vs = v * S
+    const _Float16 p0 = (_Float16)vs;                   // round to nearest even
+    const _Float16 p1 = (_Float16)((vs - (float)p0) * 2048.0f);
+    o[0] = __builtin_bit_cast(unsigned short, p0);
+    o[1] = __builtin_bit_cast(unsigned short, p1);
+}
+
+// x [P][C] fp32 (times scale[p / HW][C] when given) -> [P][C/16][2][16] fp16 with the tensor's scale; trailer = out + 4 * P * C bytes.
+__global__ __launch_bounds__(256) void to_planes_f16_kernel(const float* __restrict__ x, const float* __restrict__ scale, unsigned short* __restrict__ out,
+                                                             float* __restrict__ trailer, int total, int cpp, int C, int HW) {
+    __shared__ float red[4];
+    __shared__ uint4 stage[256 * 4];
+    const float amax = image_amax(trailer, red);
+    const float S = scale_from_amax(amax);
+    if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(trailer + H_PARTIALS, inv_scale_from_amax(amax), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int idx = min((int)(blockIdx.x * 256 + threadIdx.x), total - 1);
+    const int p = idx / cpp, c = idx - p * cpp;
+    const float4* src = reinterpret_cast<const float4*>(x + (size_t)p * C + 16 * c);
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const float4 f = src[i]; v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w; }
+    if (scale != nullptr) {
+        const float4* sc = reinterpret_cast<const float4*>(scale + (size_t)(p / HW) * C + 16 * c);
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const float4 f = sc[i]; v[4 * i] *= f.x; v[4 * i + 1] *= f.y; v[4 * i + 2] *= f.z; v[4 * i + 3] *= f.w; }
+    }
+    unsigned short pc[2][16];
+    int below = 0;
+    const bool mine = (int)(blockIdx.x * 256 + threadIdx.x) < total;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        unsigned short o[2];
+        const float vs = v[i] * S;
+        split2(vs, o);
+        pc[0][i] = o[0]; pc[1][i] = o[1];
+        below += (mine && vs != 0.0f && fabsf(vs) < 0x1p-12f) ? 1 : 0;
+    }
+    count_window(below, red);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_f16_imaged, (unsigned long long)total * 16ull);
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++) {
+            uint4 u;
+            u.x = pc[q][8 * hh + 0] | ((unsigned)pc[q][8 * hh + 1] << 16); u.y = pc[q][8 * hh + 2] | ((unsigned)pc[q][8 * hh + 3] << 16);
+            u.z = pc[q][8 * hh + 4] | ((unsigned)pc[q][8 * hh + 5] << 16); u.w = pc[q][8 * hh + 6] | ((unsigned)pc[q][8 * hh + 7] << 16);
+            stage[threadIdx.x * 4 + 2 * q + hh] = u;
+        }
+    __syncthreads();
+    const int units = min(256, total - (int)blockIdx.x * 256);
+    uint4* dst = reinterpret_cast<uint4*>(out + (size_t)blockIdx.x * 256 * 32);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int j = k * 256 + threadIdx.x;
+        if (j < units * 4) dst[j] = stage[j];
+    }
+}
+
+// filter -> [K/16][tap][n][2][16] fp16 with the filter's scale (trailer as above; orientation as filter_planes_kernel)
+template <bool WT>
+__global__ __launch_bounds__(256) void filter_planes_f16_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, float* __restrict__ trailer,
+                                                                 int taps, int KW_, int Nn, int K) {
+    __shared__ float red[4];
+    const float amax = image_amax(trailer, red);
+    const float S = scale_from_amax(amax);
+    if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(trailer + H_PARTIALS, inv_scale_from_amax(amax), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int cpk = K >> 4;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= taps * Nn * cpk) return;
+    int tap, n, c;
+    if constexpr (WT) { c = idx % cpk; const int r = idx / cpk; n = r % Nn; tap = r / Nn; }
+    else { n = idx % Nn; const int r = idx / Nn; c = r % cpk; tap = r / cpk; }
+    float v[16];
+    if constexpr (WT) {
+        const float4* src = reinterpret_cast<const float4*>(w + ((size_t)(taps - 1 - tap) * Nn + n) * K + 16 * c);
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const float4 f = src[i]; v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; i++) v[i] = w[((size_t)tap * K + 16 * c + i) * Nn + n];
+    }
+    unsigned short pc[2][16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        unsigned short o[2];
+        split2(v[i] * S, o);
+        pc[0][i] = o[0]; pc[1][i] = o[1];
+    }
+    uint4* dst = reinterpret_cast<uint4*>(out + (((size_t)c * taps + tap) * Nn + n) * 32);
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++) {
+            uint4 u;
+            u.x = pc[q][8 * hh + 0] | ((unsigned)pc[q][8 * hh + 1] << 16); u.y = pc[q][8 * hh + 2] | ((unsigned)pc[q][8 * hh + 3] << 16);
+            u.z = pc[q][8 * hh + 4] | ((unsigned)pc[q][8 * hh + 5] << 16); u.w = pc[q][8 * hh + 6] | ((unsigned)pc[q][8 * hh + 7] << 16);
+            dst[2 * q + hh] = u;
+        }
+}
+
+// 1 / S of the image of `elems` elements at `img` (read by the tile kernels' epilogues)
+__device__ __forceinline__ float image_inv_scale(const unsigned short* img, size_t elems) {
+    return __hip_atomic_load(reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(img) + elems * 4) + H_PARTIALS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int NP>
 __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
     constexpr int BM = 128, BN = 128, WN = 4, TM = 2;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[P_NSTAGE * P_STAGE + 3 * BM * 4];
-    int* row_pix = reinterpret_cast<int*>(smem + P_NSTAGE * P_STAGE);
+    static_assert(NP == 3 || NP == 2, "three bf16 pieces (six products) or two fp16 pieces (three products)");
+    constexpr int IMG = NP * 128 * 32, STAGE = 2 * IMG;       // one operand's LDS image [NP pieces][128 rows][32 B]; a stage = A + B
+    constexpr unsigned PB = NP * 32u;                          // bytes of one (pixel, 16-channel slice) in a piece image
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[P_NSTAGE * STAGE + 3 * BM * 4];
+    int* row_pix = reinterpret_cast<int*>(smem + P_NSTAGE * STAGE);
     int* row_n = row_pix + BM;
     float* row_nz = reinterpret_cast<float*>(row_n + BM);
 
@@ -1254,10 +1443,10 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
     int ld_t0 = (c_begin < c_end) ? c_begin - ld_cc * ntap : 0;
     int ld_ta = (c_begin < c_end) ? ld_t0 / nkx : 0;
     int ld_tb = (c_begin < c_end) ? ld_t0 - ld_ta * nkx : 0;
-    const unsigned xbytes = (unsigned)a.N * a.H * a.W * a.Cin * 6u, wbytes = (unsigned)a.KH * a.KW * a.Cin * a.Cout * 6u;   // host: both < OOB
+    const unsigned xbytes = (unsigned)a.N * a.H * a.W * a.Cin * (2u * NP), wbytes = (unsigned)a.KH * a.KW * a.Cin * a.Cout * (2u * NP);   // host: both < OOB
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.xp), 0, (int)xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.wp), 0, (int)wbytes, 0x00020000);
-    const unsigned pixA = (unsigned)a.Cin * 6u;           // bytes per pixel
+    const unsigned pixA = (unsigned)a.Cin * (2u * NP);           // bytes per pixel
     // Per lane, once per tile: the byte offset of its A row under tap (0, 0) of the class and one validity bit per tap (tap (ta, tb)
     // reads input pixel (iy0 + ta, ix0 + tb): the class's taps are `up` apart and the parity makes the shift exact), and the
     // offset of its B row inside a (slice, tap) block.  A step then costs four vector instructions of address work: add the
@@ -1280,23 +1469,23 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
                 maskA |= ok ? (1u << (ta * nkx + tb)) : 0u;
             }
         const int co = n0 + drow;
-        voffB = (co < a.Cout) ? (unsigned)co * 96u + (unsigned)dhalf * 16u : OOB;
+        voffB = (co < a.Cout) ? (unsigned)co * PB + (unsigned)dhalf * 16u : OOB;
     }
     unsigned offA = OOB, soffB = 0u;
     typedef __attribute__((address_space(3))) void lds_void;
     unsigned char* dA = nullptr;
     auto dma_prep = [&](int stage) {        // addresses of the next chunk, then one step forward in (slice, tap) order
 #ifdef IGAN_PLANES_NO_PREP      // TIMING EXPERIMENT ONLY (wrong results): how much of the step is the scalar address work?
-        dA = smem + stage * P_STAGE + (wave & 3) * 1024;
+        dA = smem + stage * STAGE + (wave & 3) * 1024;
         offA = baseA; soffB = 0u;
         return;
 #endif
-        const unsigned disp = (unsigned)(ld_ta * a.W + ld_tb) * pixA + (unsigned)ld_cc * 96u;                      // scalar
+        const unsigned disp = (unsigned)(ld_ta * a.W + ld_tb) * pixA + (unsigned)ld_cc * PB;                      // scalar
         const unsigned bit = 1u << (ld_ta * nkx + ld_tb);                                                           // scalar
         offA = (maskA & bit) ? baseA + disp : OOB;
         const int ky = ky0 + (ld_ta << a.up_shift), kx = kx0 + (ld_tb << a.up_shift);
-        soffB = (unsigned)((ld_cc * (a.KH * a.KW) + ky * a.KW + kx) * a.Cout) * 96u;                               // scalar
-        dA = smem + stage * P_STAGE + (wave & 3) * 1024;
+        soffB = (unsigned)((ld_cc * (a.KH * a.KW) + ky * a.KW + kx) * a.Cout) * PB;                               // scalar
+        dA = smem + stage * STAGE + (wave & 3) * 1024;
         ++ld_tb;
         const int w1 = (ld_tb == nkx) ? 1 : 0;
         ld_tb = w1 ? 0 : ld_tb;
@@ -1307,7 +1496,7 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
     };
     auto dma_piece = [&](int j) {           // one of this wave's three KiB of the 24 KiB stage; the pieces of a (pixel, slice) are 32 B apart
         unsigned char* A = dA;
-        unsigned char* B = dA + P_IMG;
+        unsigned char* B = dA + IMG;
         // an out-of-range offset stays out of range with the piece offset added
         // (the piece displacement rides in the scalar offset: the instruction's immediate offset would also move the LDS address)
 #ifdef IGAN_PLANES_NO_DMA_A       // TIMING EXPERIMENT ONLY (wrong results): the A operand's three DMA instructions become B re-fetches of the same size
@@ -1317,6 +1506,15 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
 #define IGAN_A_RSRC rx
 #define IGAN_A_OFF offA
 #endif
+        if constexpr (NP == 2) {        // 16 wave instructions per stage, two per wave: waves 0-3 A piece 0 and B piece 1, waves 4-7 A piece 1 and B piece 0
+            if (lowave) {
+                if (j == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)A, 16, offA, 0, 0, 0);
+                if (j == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(B + 4096), 16, voffB, soffB + 32u, 0, 0);
+            } else {
+                if (j == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(A + 4096), 16, offA, 32, 0, 0);
+                if (j == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)B, 16, voffB, soffB, 0, 0);
+            }
+        } else
         if (lowave) {
             if (j == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(IGAN_A_RSRC, (lds_void*)A, 16, IGAN_A_OFF, 0, 0, 0);
             if (j == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(IGAN_A_RSRC, (lds_void*)(A + 2 * 4096), 16, IGAN_A_OFF, 64, 0, 0);
@@ -1327,7 +1525,7 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
             if (j == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(B + 2 * 4096), 16, voffB, soffB + 64u, 0, 0);
         }
     };
-    auto dma_chunk = [&](int stage) { dma_prep(stage); dma_piece(0); dma_piece(1); dma_piece(2); };
+    auto dma_chunk = [&](int stage) { dma_prep(stage); dma_piece(0); dma_piece(1); if constexpr (NP == 3) dma_piece(2); };
 
     f32x16 acc[TM];
 #pragma unroll
@@ -1335,6 +1533,12 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[tm][r] = 0.0f;
 
+    // NP == 2: the two tensors' 1 / S, fetched first (they are needed after the last step; as wave-uniform scalars they cost the epilogue nothing)
+    float inv_a_v = 1.0f, inv_b_v = 1.0f;
+    if constexpr (NP == 2) {
+        inv_a_v = image_inv_scale(a.xp, (size_t)a.N * a.H * a.W * a.Cin);
+        inv_b_v = image_inv_scale(a.wp, (size_t)a.KH * a.KW * a.Cin * a.Cout);
+    }
     if (c_begin < c_end) { dma_chunk(0); dma_chunk(1); }
     // the epilogue's row tables, computed while the first chunks are in flight
     if (tid < BM) {
@@ -1358,13 +1562,15 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
         fa[tm] = (2 * r + (h ^ ((r >> 3) & 1))) * 16;
     }
     const int rb_ = wn * 32 + l31;
-    const int fb = P_IMG + (2 * rb_ + (h ^ ((rb_ >> 3) & 1))) * 16;
+    const int fb = IMG + (2 * rb_ + (h ^ ((rb_ >> 3) & 1))) * 16;
     if (a.prio) __builtin_amdgcn_s_setprio(0);
     stamp(1);
 
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int st = 0;
+    const float inv_a = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(inv_a_v))), inv_b = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(inv_b_v)));
 #ifdef IGAN_PLANES_TILE_SEQUENTIAL
+    static_assert(NP == 3, "the tile-sequential experiment exists for the bf16 form only");
     // MEASURED AND NOT KEPT (round 4; -DIGAN_PLANES_TILE_SEQUENTIAL builds it): bit-identical to the default form below and
     // 1.5 % slower forward, 4 % slower in the weight gradient (tools/planes_sched_ab.sh) -- the vector adds were not what the step waits for.
     // The two 32x32 tiles of a wave run ONE AFTER THE OTHER (six dependent products each: a chain on one
@@ -1393,7 +1599,7 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
     for (int c = c_begin; c < c_end; c++) {
         asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
         const int nst = st >= 1 ? st - 1 : P_NSTAGE - 1;
-        const unsigned char* S = smem + st * P_STAGE;
+        const unsigned char* S = smem + st * STAGE;
         bf16x8 af[TM][3], bfr[3];
 #pragma unroll
         for (int q = 0; q < 3; q++) {
@@ -1430,6 +1636,53 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
     }
     fold(acc[1], t1);
 #else
+    f32x16 u[TM];       // NP == 2: the cross terms p0a p1b + p1a p0b, chained in the matrix pipe over the whole reduction (2^-11 of the result)
+    if constexpr (NP == 2) {
+#pragma unroll
+        for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) u[tm][r] = 0.0f;
+        for (int c = c_begin; c < c_end; c++) {
+            asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");     // chunk c landed (two younger instructions: chunk c+1); stage st+2 is free
+            const int nst = st >= 1 ? st - 1 : P_NSTAGE - 1;
+            const unsigned char* S = smem + st * STAGE;
+            f16x8 a0[TM], a1[TM];
+            const f16x8 b0 = __builtin_bit_cast(f16x8, *reinterpret_cast<const bf16x8*>(S + fb));
+            const f16x8 b1 = __builtin_bit_cast(f16x8, *reinterpret_cast<const bf16x8*>(S + fb + 4096));
+#pragma unroll
+            for (int tm = 0; tm < TM; tm++) {
+                a0[tm] = __builtin_bit_cast(f16x8, *reinterpret_cast<const bf16x8*>(S + fa[tm]));
+                a1[tm] = __builtin_bit_cast(f16x8, *reinterpret_cast<const bf16x8*>(S + fa[tm] + 4096));
+            }
+            dma_prep(nst);
+            // The main term of the two 32x32 tiles goes through ONE set of 16 registers (tile 0's sum is folded while tile 1's products run): with
+            // acc, u and the fragments live, a second set does not fit the 128 registers of two workgroups per CU.
+            f32x16 t;
+            __builtin_amdgcn_sched_barrier(0);
+            t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[0], b0, zero, 0, 0, 0);       // main term: from an exact zero
+            u[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[0], b1, u[0], 0, 0, 0);
+            u[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[1], b1, u[1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            dma_piece(0); dma_piece(1);             // chunk c + 2, issued inside the matrix cluster
+            acc[0] += t;                            // vector ALU: round to nearest
+            __builtin_amdgcn_sched_barrier(0);
+            t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[1], b0, zero, 0, 0, 0);
+            u[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[0], b0, u[0], 0, 0, 0);
+            u[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[1], b0, u[1], 0, 0, 0);
+            acc[1] += t;
+            st = (st + 1 == P_NSTAGE) ? 0 : st + 1;
+        }
+        // sum = (main + 2^-11 cross) / (Sa Sb): both scales are powers of two (exact); applied one after the other so that no intermediate leaves fp32's range
+#pragma unroll
+        for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[tm][r] = ((acc[tm][r] + u[tm][r] * (1.0f / 2048.0f)) * inv_a) * inv_b;
+#ifdef IGAN_F16_LDS_EXIT_FILL     // DIAGNOSTIC BUILD: leave a known pattern in the stages (does a LATER kernel read LDS it never wrote?)
+        __syncthreads();
+        for (int i = tid; i < P_NSTAGE * STAGE / 4; i += 512) reinterpret_cast<unsigned*>(smem)[i] = (unsigned)(IGAN_F16_LDS_EXIT_FILL);
+        __syncthreads();
+#endif
+    } else {
 #ifdef IGAN_PLANES_NO_LDSREAD
     bf16x8 keep_a[TM][3], keep_b[3];
 #endif
@@ -1438,7 +1691,7 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
         asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
         // everyone has chunk c in stage st, and has finished reading stage st + 2 (chunk c-1): it is refilled with chunk c+2
         const int nst = st >= 1 ? st - 1 : P_NSTAGE - 1;
-        const unsigned char* S = smem + st * P_STAGE;
+        const unsigned char* S = smem + st * STAGE;
         bf16x8 af[TM][3], bfr[3];
 #ifdef IGAN_PLANES_NO_LDSREAD     // TIMING EXPERIMENT ONLY (wrong results): fragments read once, from the first stage
         const unsigned char* S0 = (c == c_begin) ? S : smem;
@@ -1482,6 +1735,7 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
 #pragma unroll
         for (int tm = 0; tm < TM; tm++) acc[tm] += t[tm];
         st = (st + 1 == P_NSTAGE) ? 0 : st + 1;
+    }
     }
 #endif
     stamp(2);
@@ -1808,9 +2062,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_wgr
 // that belongs in their slot; padding taps, the ragged end of the pixel axis and channel tails are out-of-range offsets (zeros).
 // grid and split as conv_wgrad_kernel; partial tiles go to the same workspace and plain_reduce_kernel adds them in fixed order.
 typedef __attribute__((ext_vector_type(4))) short s16x4;
+template <int NP>
 __global__ __launch_bounds__(512, 4) void conv_wgrad_planes_kernel(WgradArgs a) {
     constexpr int TM = 2, WN = 4;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[P_NSTAGE * P_STAGE];
+    static_assert(NP == 3 || NP == 2, "three bf16 pieces (six products) or two fp16 pieces (three products)");
+    constexpr int IMG = NP * 4096, STAGE = 2 * IMG;            // one operand's LDS image [NP pieces][16 pixel rows][256 B]; a stage = A + B
+    constexpr unsigned PB = NP * 32u;                          // bytes of one (pixel, 16-channel slice) in a piece image
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[P_NSTAGE * STAGE];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
@@ -1846,10 +2104,10 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_planes_kernel(WgradArgs a) 
     const int drow = 4 * (wave & 3) + (lane >> 4);
     const int dch = (lane & 15) ^ (((drow & 3) << 2) | ((drow >> 2) & 3));
     const bool lowave = wave < 4;
-    const unsigned rowA = (unsigned)a.Cin * 6u, rowB = (unsigned)a.Cout * 6u;       // bytes per pixel
+    const unsigned rowA = (unsigned)a.Cin * (2u * NP), rowB = (unsigned)a.Cout * (2u * NP);       // bytes per pixel
     const bool chA = m0 + 8 * dch < a.Cin, chB = n0 + 8 * dch < a.Cout;
-    const unsigned constA = (unsigned)((m0 >> 4) + (dch >> 1)) * 96u + (unsigned)(dch & 1) * 16u;
-    const unsigned constB = (unsigned)((n0 >> 4) + (dch >> 1)) * 96u + (unsigned)(dch & 1) * 16u;
+    const unsigned constA = (unsigned)((m0 >> 4) + (dch >> 1)) * PB + (unsigned)(dch & 1) * 16u;
+    const unsigned constB = (unsigned)((n0 >> 4) + (dch >> 1)) * PB + (unsigned)(dch & 1) * 16u;
     const int dQW = max(QW, 1), dQH = max(QH, 1);
     const int st_b = PK % dQW, st_a = PK / dQW, st_a2 = st_a % dQH, st_a1 = st_a / dQH;     // one step = 16 pixels = st_a1 samples + st_a2 rows + st_b columns
     int kp = c_begin * PK + drow, wn_ = 0, wqy = 0, wqx = 0;      // this lane's pixel of the next chunk to fetch
@@ -1858,7 +2116,7 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_planes_kernel(WgradArgs a) 
         const int r = kp - wn_ * (dQH * dQW);
         wqy = r / dQW; wqx = r - wqy * dQW;
     }
-    const unsigned xbytes = (unsigned)a.N * a.H * a.W * a.Cin * 6u, dybytes = (unsigned)a.N * a.OH * a.OW * a.Cout * 6u;   // host: both < OOB
+    const unsigned xbytes = (unsigned)a.N * a.H * a.W * a.Cin * (2u * NP), dybytes = (unsigned)a.N * a.OH * a.OW * a.Cout * (2u * NP);   // host: both < OOB
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.xp), 0, (int)xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.dyp), 0, (int)dybytes, 0x00020000);
     typedef __attribute__((address_space(3))) void lds_void;
@@ -1871,7 +2129,7 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_planes_kernel(WgradArgs a) 
         offA = okA ? (unsigned)((wn_ * a.H + iy) * a.W + ix) * rowA + constA : OOB;
         const int oy = (wqy << a.up_shift) + py, ox = (wqx << a.up_shift) + px;
         offB = (live & chB) ? (unsigned)((wn_ * a.OH + oy) * a.OW + ox) * rowB + constB : OOB;
-        dA = smem + stage * P_STAGE + (wave & 3) * 1024;
+        dA = smem + stage * STAGE + (wave & 3) * 1024;
         kp += PK;                                   // walk to the same row of the next chunk
         wqx += st_b;
         const bool c1 = wqx >= QW;
@@ -1883,7 +2141,16 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_planes_kernel(WgradArgs a) 
     };
     auto dma_piece = [&](int j) {       // as in conv_fwd_planes_kernel: waves 0-3 A pieces 0, 2 and B piece 1; waves 4-7 A piece 1 and B pieces 0, 2
         unsigned char* A = dA;
-        unsigned char* B = dA + P_IMG;
+        unsigned char* B = dA + IMG;
+        if constexpr (NP == 2) {        // waves 0-3 A piece 0 and B piece 1, waves 4-7 A piece 1 and B piece 0
+            if (lowave) {
+                if (j == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)A, 16, offA, 0, 0, 0);
+                if (j == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (lds_void*)(B + 4096), 16, offB, 32, 0, 0);
+            } else {
+                if (j == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(A + 4096), 16, offA, 32, 0, 0);
+                if (j == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (lds_void*)B, 16, offB, 0, 0, 0);
+            }
+        } else
         if (lowave) {
             if (j == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)A, 16, offA, 0, 0, 0);
             if (j == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(A + 2 * 4096), 16, offA, 64, 0, 0);
@@ -1909,7 +2176,7 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_planes_kernel(WgradArgs a) 
             fA[tm][hf] = 256 * row + 16 * (chunk ^ xr) + 8 * (tp & 1);
         }
         const int chunkb = wn * 4 + 2 * (tg & 1) + (tp >> 1);
-        fB[hf] = P_IMG + 256 * row + 16 * (chunkb ^ xr) + 8 * (tp & 1);
+        fB[hf] = IMG + 256 * row + 16 * (chunkb ^ xr) + 8 * (tp & 1);
     }
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     auto tr8 = [&](const unsigned char* base, int o0, int o1) -> bf16x8 {
@@ -1925,13 +2192,20 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_planes_kernel(WgradArgs a) 
     for (int tm = 0; tm < TM; tm++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[tm][r] = 0.0f;
+    float inv_a_v = 1.0f, inv_b_v = 1.0f;       // NP == 2: the two tensors' 1 / S (conv_fwd_planes_kernel)
+    if constexpr (NP == 2) {
+        inv_a_v = image_inv_scale(a.xp, (size_t)a.N * a.H * a.W * a.Cin);
+        inv_b_v = image_inv_scale(a.dyp, (size_t)a.N * a.OH * a.OW * a.Cout);
+    }
     if (c_begin < c_end) {
-        dma_prep(0); dma_piece(0); dma_piece(1); dma_piece(2);
-        dma_prep(1); dma_piece(0); dma_piece(1); dma_piece(2);
+        dma_prep(0); dma_piece(0); dma_piece(1); if constexpr (NP == 3) dma_piece(2);
+        dma_prep(1); dma_piece(0); dma_piece(1); if constexpr (NP == 3) dma_piece(2);
     }
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int st = 0;
+    const float inv_a = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(inv_a_v))), inv_b = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(inv_b_v)));
 #ifdef IGAN_PLANES_TILE_SEQUENTIAL
+    static_assert(NP == 3, "the tile-sequential experiment exists for the bf16 form only");
     // step schedule of conv_fwd_planes_kernel (tile after tile, tile 0 folded beside tile 1's products, tile 1 under the next step's reads)
     f32x16 t0, t1 = zero;
     // The adds are inline assembly, so the compiler's hazard recogniser does not see them: a vector read of an MFMA result needs
@@ -1952,7 +2226,7 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_planes_kernel(WgradArgs a) 
     for (int c = c_begin; c < c_end; c++) {
         asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
         const int nst = st >= 1 ? st - 1 : P_NSTAGE - 1;
-        const unsigned char* S = smem + st * P_STAGE;
+        const unsigned char* S = smem + st * STAGE;
         bf16x8 af[TM][3], bfr[3];
 #pragma unroll
         for (int q = 0; q < 3; q++) {
@@ -1989,10 +2263,54 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_planes_kernel(WgradArgs a) 
     }
     fold(acc[1], t1);
 #else
+    f32x16 u[TM];       // NP == 2: the cross terms, as in conv_fwd_planes_kernel
+    if constexpr (NP == 2) {
+#pragma unroll
+        for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) u[tm][r] = 0.0f;
+        for (int c = c_begin; c < c_end; c++) {
+            asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+            const int nst = st >= 1 ? st - 1 : P_NSTAGE - 1;
+            const unsigned char* S = smem + st * STAGE;
+            f16x8 a0[TM], a1[TM];
+            const f16x8 b0 = __builtin_bit_cast(f16x8, tr8(S, fB[0], fB[1]));
+            const f16x8 b1 = __builtin_bit_cast(f16x8, tr8(S + 4096, fB[0], fB[1]));
+#pragma unroll
+            for (int tm = 0; tm < TM; tm++) {
+                a0[tm] = __builtin_bit_cast(f16x8, tr8(S, fA[tm][0], fA[tm][1]));
+                a1[tm] = __builtin_bit_cast(f16x8, tr8(S + 4096, fA[tm][0], fA[tm][1]));
+            }
+            dma_prep(nst);
+            f32x16 t;           // one set of registers for the main term of both tiles, as in conv_fwd_planes_kernel
+            __builtin_amdgcn_sched_barrier(0);
+            t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[0], b0, zero, 0, 0, 0);
+            u[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[0], b1, u[0], 0, 0, 0);
+            u[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[1], b1, u[1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            dma_piece(0); dma_piece(1);
+            acc[0] += t;
+            __builtin_amdgcn_sched_barrier(0);
+            t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[1], b0, zero, 0, 0, 0);
+            u[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[0], b0, u[0], 0, 0, 0);
+            u[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[1], b0, u[1], 0, 0, 0);
+            acc[1] += t;
+            st = (st + 1 == P_NSTAGE) ? 0 : st + 1;
+        }
+#pragma unroll
+        for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[tm][r] = ((acc[tm][r] + u[tm][r] * (1.0f / 2048.0f)) * inv_a) * inv_b;
+#ifdef IGAN_F16_LDS_EXIT_FILL     // DIAGNOSTIC BUILD, as in conv_fwd_planes_kernel
+        __syncthreads();
+        for (int i = tid; i < P_NSTAGE * STAGE / 4; i += 512) reinterpret_cast<unsigned*>(smem)[i] = (unsigned)(IGAN_F16_LDS_EXIT_FILL);
+        __syncthreads();
+#endif
+    } else
     for (int c = c_begin; c < c_end; c++) {
         asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
         const int nst = st >= 1 ? st - 1 : P_NSTAGE - 1;
-        const unsigned char* S = smem + st * P_STAGE;
+        const unsigned char* S = smem + st * STAGE;
         bf16x8 af[TM][3], bfr[3];
 #pragma unroll
         for (int q = 0; q < 3; q++) {
@@ -2184,9 +2502,36 @@ bool walk_ok(const igan_conv2d_params* p) {
 }
 
 // The bf16-piece form is the DEFAULT for the shapes below (round 4); IGAN_CONV_PLANES=0 runs every convolution on the fp32 instruction.
-bool planes_enabled() {
-    static const bool on = !(getenv("IGAN_CONV_PLANES") && atoi(getenv("IGAN_CONV_PLANES")) == 0);
-    return on;
+// IGAN_CONV_PLANES=2 is the two-piece fp16 VARIANT of the same kernels (three products; see "TWO-PIECE fp16 form" above): same shapes, same buffers.
+int planes_mode() {
+    static const int mode = [] { const char* v = getenv("IGAN_CONV_PLANES"); const int m = v ? atoi(v) : 1; return m == 0 ? 0 : (m == 2 ? 2 : 1); }();
+    return mode;
+}
+bool planes_enabled() { return planes_mode() != 0; }
+
+// The piece image of x [P][C] (times scale [P / HW][C]) in the form that is switched on; `out` holds P * C * 6 bytes (the fp16 form uses 4 of
+// the 6 bytes per element for the image and 4100 bytes behind it for the tensor's scale: callers guarantee P * C >= 4096).
+void launch_piece_image(hipStream_t stream, const float* x, const float* scale, unsigned short* out, int P_, int HW, int C) {
+    const int cpp = C / PK, total = P_ * cpp;
+    if (planes_mode() == 2) {
+        float* trailer = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(out) + (size_t)P_ * C * 4);
+        hipLaunchKernelGGL(amax_partial_kernel, dim3(H_PARTIALS), dim3(256), 0, stream, x, scale, trailer, (int)((long long)P_ * C / 4), C / 4, (int)((long long)HW * C / 4));
+        hipLaunchKernelGGL(to_planes_f16_kernel, dim3(igan::ceil_div(total, 256)), dim3(256), 0, stream, x, scale, out, trailer, total, cpp, C, HW);
+    } else {
+        hipLaunchKernelGGL(to_planes_kernel, dim3(igan::ceil_div(total, 256)), dim3(256), 0, stream, x, scale, out, total, cpp, C, HW);
+    }
+}
+void launch_filter_image(hipStream_t stream, const float* w, unsigned short* wp, bool wt, int taps, int KW_, int Nn, int K) {
+    const int wtotal = taps * Nn * (K / PK);
+    if (planes_mode() == 2) {
+        float* trailer = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(wp) + (size_t)taps * Nn * K * 4);
+        hipLaunchKernelGGL(amax_partial_kernel, dim3(H_PARTIALS), dim3(256), 0, stream, w, (const float*)nullptr, trailer, taps * Nn * K / 4, 1, 1);
+        if (wt) hipLaunchKernelGGL((filter_planes_f16_kernel<true>), dim3(igan::ceil_div(wtotal, 256)), dim3(256), 0, stream, w, wp, trailer, taps, KW_, Nn, K);
+        else hipLaunchKernelGGL((filter_planes_f16_kernel<false>), dim3(igan::ceil_div(wtotal, 256)), dim3(256), 0, stream, w, wp, trailer, taps, KW_, Nn, K);
+    } else {
+        if (wt) hipLaunchKernelGGL((filter_planes_kernel<true>), dim3(igan::ceil_div(wtotal, 256)), dim3(256), 0, stream, w, wp, taps, KW_, Nn, K);
+        else hipLaunchKernelGGL((filter_planes_kernel<false>), dim3(igan::ceil_div(wtotal, 256)), dim3(256), 0, stream, w, wp, taps, KW_, Nn, K);
+    }
 }
 
 // Does this launch take the bf16-piece form (conv_fwd_planes_kernel)?  the form switched on, the 128x128 tile, Cin % 32 == 0, both
@@ -2402,17 +2747,15 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
         const int cpp = p->Cin / PK;
         if (xp == nullptr) {         // no image from the caller: write it behind the partial tiles
             unsigned short* own = reinterpret_cast<unsigned short*>(p->workspace + partial_floats);
-            const int total = p->N * p->H * p->W * cpp;
-            hipLaunchKernelGGL(to_planes_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, p->x, p->in_scale, own, total, cpp, p->Cin, p->H * p->W);
+            launch_piece_image(stream, p->x, p->in_scale, own, p->N * p->H * p->W, p->H * p->W, p->Cin);
             xp = own;
         }
-        const int wtotal = p->KH * p->KW * p->Cout * cpp;
-        if (wt) hipLaunchKernelGGL((filter_planes_kernel<true>), dim3(ceil_div(wtotal, 256)), dim3(256), 0, stream, p->w, wp, p->KH * p->KW, p->KW, p->Cout, p->Cin);
-        else hipLaunchKernelGGL((filter_planes_kernel<false>), dim3(ceil_div(wtotal, 256)), dim3(256), 0, stream, p->w, wp, p->KH * p->KW, p->KW, p->Cout, p->Cin);
+        launch_filter_image(stream, p->w, wp, wt, p->KH * p->KW, p->KW, p->Cout, p->Cin);
         a.xp = xp; a.wp = wp;
         a.cpt = cpp;
-        hipLaunchKernelGGL(conv_fwd_planes_kernel, grid, dim3(512), 0, stream, a);
-        IGAN_LAUNCH_CHECK("conv2d (bf16-piece) launch");
+        if (planes_mode() == 2) hipLaunchKernelGGL((conv_fwd_planes_kernel<2>), grid, dim3(512), 0, stream, a);
+        else hipLaunchKernelGGL((conv_fwd_planes_kernel<3>), grid, dim3(512), 0, stream, a);
+        IGAN_LAUNCH_CHECK("conv2d (piece form) launch");
         launched = true;
     } else
     if (use_dma_kernel(p, t, a.walk != 0)) {       // LDS-DMA form of the 128x128 tile
@@ -2530,6 +2873,15 @@ int wgrad_splits(const igan_conv2d_wgrad_params* p) {
 bool wgrad_planes_shape_ok(const igan_conv2d_wgrad_params* p) {
     static const bool wg = !(getenv("IGAN_WGRAD_PLANES") && atoi(getenv("IGAN_WGRAD_PLANES")) == 0);      // A/B switch inside the piece form
     if (!planes_enabled() || !wg || p->KH * p->KW == 1 || p->Cin < 128 || p->Cout < 128 || p->Cin % 32 != 0 || p->Cout % 32 != 0) return false;
+    {   // DIAGNOSTIC ONLY (bisecting by layer class): IGAN_WGRAD_PLANES_CIN=<n> keeps the piece form for weight gradients with Cin == n only,
+        // IGAN_WGRAD_PLANES_KIND=plain|stride|up for stride 1 without up-sampling / stride 2 / up 2 only
+        static const int only_cin = getenv("IGAN_WGRAD_PLANES_CIN") ? atoi(getenv("IGAN_WGRAD_PLANES_CIN")) : 0;
+        static const char* kind = getenv("IGAN_WGRAD_PLANES_KIND");
+        if (only_cin && p->Cin != only_cin) return false;
+        if (kind && kind[0] == 'p' && (p->stride != 1 || p->up != 1)) return false;
+        if (kind && kind[0] == 's' && p->stride != 2) return false;
+        if (kind && kind[0] == 'u' && p->up != 2) return false;
+    }
     if ((long long)p->N * p->OH * p->OW < 2048 * (long long)p->up * p->up) return false;
     if ((long long)p->N * p->H * p->W * p->Cin * 6 >= 0x7FFFFF00LL || (long long)p->N * p->OH * p->OW * p->Cout * 6 >= 0x7FFFFF00LL) return false;
     return true;
@@ -2625,21 +2977,20 @@ extern "C" int igan_conv2d_wgrad(igan_stream_t stream_, const igan_conv2d_wgrad_
         IGAN_REQUIRE(p->dy_pieces == nullptr || p->dy_pieces_bytes == wgrad_planes_dy_floats(p) * 4, "conv2d_wgrad: dy_pieces is not the image of this dy (dy_pieces_bytes != N*OH*OW*Cout*6)");
         const unsigned short* xp = reinterpret_cast<const unsigned short*>(p->x_pieces);
         const unsigned short* dyp = reinterpret_cast<const unsigned short*>(p->dy_pieces);
-        const int cpa = p->Cin / PK, cpb = p->Cout / PK;
-        const int ta = p->N * p->H * p->W * cpa, tb = p->N * p->OH * p->OW * cpb;
         if (xp == nullptr) {
             unsigned short* own = reinterpret_cast<unsigned short*>(p->workspace + partial_floats);
-            hipLaunchKernelGGL(to_planes_kernel, dim3(ceil_div(ta, 256)), dim3(256), 0, stream, p->x, p->in_scale, own, ta, cpa, p->Cin, p->H * p->W);
+            launch_piece_image(stream, p->x, p->in_scale, own, p->N * p->H * p->W, p->H * p->W, p->Cin);
             xp = own;
         }
         if (dyp == nullptr) {
             unsigned short* own = reinterpret_cast<unsigned short*>(p->workspace + partial_floats + wgrad_planes_x_floats(p));
-            hipLaunchKernelGGL(to_planes_kernel, dim3(ceil_div(tb, 256)), dim3(256), 0, stream, p->dy, p->out_scale, own, tb, cpb, p->Cout, p->OH * p->OW);
+            launch_piece_image(stream, p->dy, p->out_scale, own, p->N * p->OH * p->OW, p->OH * p->OW, p->Cout);
             dyp = own;
         }
         a.xp = xp; a.dyp = dyp;
-        hipLaunchKernelGGL(conv_wgrad_planes_kernel, grid, dim3(512), 0, stream, a);
-        IGAN_LAUNCH_CHECK("conv2d_wgrad (bf16-piece) launch");
+        if (planes_mode() == 2) hipLaunchKernelGGL((conv_wgrad_planes_kernel<2>), grid, dim3(512), 0, stream, a);
+        else hipLaunchKernelGGL((conv_wgrad_planes_kernel<3>), grid, dim3(512), 0, stream, a);
+        IGAN_LAUNCH_CHECK("conv2d_wgrad (piece form) launch");
         if (splits > 1) {
             const int total = (int)wsize;
             const int rg = std::min(ceil_div(total, 256), 2048);
@@ -2666,6 +3017,22 @@ extern "C" int igan_conv2d_wgrad(igan_stream_t stream_, const igan_conv2d_wgrad_
     return IGAN_OK;
 }
 
+// Diagnostic (two-piece fp16 variant): elements imaged so far below the exact window / in all; synchronises the device.  reset != 0 zeroes both.
+extern "C" int igan_debug_f16_window(unsigned long long* below, unsigned long long* imaged, int reset) {
+    using namespace igan;
+    unsigned long long v[2] = {0ull, 0ull};
+    if (hipMemcpyFromSymbol(&v[0], HIP_SYMBOL(g_f16_below_window), 8) != hipSuccess || hipMemcpyFromSymbol(&v[1], HIP_SYMBOL(g_f16_imaged), 8) != hipSuccess) return IGAN_ERR_HIP;
+    if (below) *below = v[0];
+    if (imaged) *imaged = v[1];
+    if (reset) {
+        const unsigned long long z = 0ull;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_f16_below_window), &z, 8) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(g_f16_imaged), &z, 8) != hipSuccess) return IGAN_ERR_HIP;
+    }
+    return IGAN_OK;
+}
+
+extern "C" int igan_conv_piece_form(void) { return planes_mode(); }
+
 extern "C" int igan_conv_pieces_wanted(int KH, int KW, int Cin, int Cout) {
     using namespace igan;
     return (planes_enabled() && KH * KW > 1 && Cin >= 128 && Cout >= 128 && Cin % 32 == 0 && Cout % 32 == 0) ? 1 : 0;
@@ -2682,9 +3049,8 @@ extern "C" int igan_to_pieces(igan_stream_t stream_, const float* x, const float
     IGAN_REQUIRE(N >= 1 && HW >= 1 && C >= 16 && C % 16 == 0, "to_pieces: C must be a positive multiple of 16");
     IGAN_REQUIRE((((uintptr_t)x | (uintptr_t)scale | (uintptr_t)out) & 15) == 0, "to_pieces: buffers must be 16-byte aligned");
     IGAN_REQUIRE((long long)N * HW * C * 6 < 0x7FFFFF00LL, "to_pieces: image too large (32-bit offsets)");
-    const int cpp = C / PK;
-    const int total = N * HW * cpp;
-    hipLaunchKernelGGL(to_planes_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream_, x, scale, reinterpret_cast<unsigned short*>(out), total, cpp, C, HW);
+    IGAN_REQUIRE(planes_mode() != 2 || (long long)N * HW * C >= 4096, "to_pieces: tensor too small for the two-piece form (its scale lives behind the image)");
+    launch_piece_image((hipStream_t)stream_, x, scale, reinterpret_cast<unsigned short*>(out), N * HW, HW, C);
     IGAN_LAUNCH_CHECK("to_pieces launch");
     return IGAN_OK;
 }

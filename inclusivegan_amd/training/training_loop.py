@@ -590,7 +590,8 @@ def training_loop(
                 ok = False
                 print('WARNING: hipGraph of training op %r does not reproduce its eager execution (%s; tensor index, max |diff|: %s); '
                       'running this op eagerly' % (step.name, reason, bad), flush=True)
-                step.enabled = False
+                if os.environ.get('IGAN_GRAPH_STRESS') != '1':     # stress runs (bench.py --revalidate-every) keep checking the op instead of retiring its graph
+                    step.enabled = False
         graph_checks.append(dict(when=reason, faithful=ok))
         return ok
 
@@ -741,13 +742,17 @@ def training_loop(
             # Run training ops (:474-479) -- handed to the submission thread in program order (or executed here when it is off).
             timed = hooks.get('op_times')          # optional: dict name -> list of (start, end) HIP events
             on_op = hooks.get('on_op')
+            host_timed = hooks.get('op_host_times')  # optional: dict name -> list of seconds the HOST spent inside the op's call (submission time)
             def run(name, op):
                 if timed is None:
                     res = op()
                 else:
                     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                    t0 = time.perf_counter()
                     e0.record(); res = op(); e1.record()
                     timed.setdefault(name, []).append((e0, e1))
+                    if host_timed is not None:
+                        host_timed.setdefault(name, []).append(time.perf_counter() - t0)
                 if on_op is not None and res is not None:
                     on_op(res[0], res[1], feed)
 

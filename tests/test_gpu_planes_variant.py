@@ -124,8 +124,11 @@ print('PLANES-VARIANT-OK')
 '''
 
 
-def test_bf16_piece_variant_against_fp64(cuda_device):
-    env = dict(os.environ, IGAN_CONV_PLANES='1')
+@pytest.mark.parametrize('form', ['1', '2'], ids=['bf16_x3_six_products', 'fp16_x2_three_products'])
+def test_piece_forms_against_fp64(cuda_device, form):
+    """IGAN_CONV_PLANES=1: three bf16 pieces, six products (the default form).  =2: the two-piece fp16 VARIANT (per-tensor power-of-two
+    scale, three products) -- same kernels, same shapes, same tolerances."""
+    env = dict(os.environ, IGAN_CONV_PLANES=form)
     r = subprocess.run([sys.executable, '-c', CHILD % ROOT], env=env, capture_output=True, text=True, timeout=600)
     sys.stdout.write(r.stdout[-3000:])
     assert r.returncode == 0 and 'PLANES-VARIANT-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
