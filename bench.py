@@ -46,16 +46,16 @@ PIECE_DTYPE = {0: 'f32',
 
 def piece_form():
     """Which form the large 3x3 convolutions run in (csrc/conv2d_mfma.hip planes_mode; igan_conv_piece_form() is the library's own answer):
-    IGAN_CONV_PLANES=0 -> 0 (fp32 matrix instruction everywhere), unset / 1 -> 1 (three bf16 pieces), 2 -> 2 (two fp16 pieces)."""
+    IGAN_CONV_PLANES=0 -> 0 (fp32 matrix instruction everywhere), 1 -> 1 (three bf16 pieces), unset / 2 -> 2 (two fp16 pieces: the default)."""
     v = os.environ.get('IGAN_CONV_PLANES')
     try:
         m = int(v) if v is not None else DEFAULT_PIECE_FORM
     except ValueError:
         m = 0
-    return 0 if m == 0 else (2 if m == 2 else 1)
+    return 0 if m == 0 else (1 if m == 1 else 2)
 
 
-DEFAULT_PIECE_FORM = 1
+DEFAULT_PIECE_FORM = 2
 
 
 def piece_form_on():

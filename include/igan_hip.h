@@ -257,7 +257,7 @@ int igan_conv2d_wgrad_kernel_name(const igan_conv2d_wgrad_params* p, char* buf, 
 int igan_conv_pieces_wanted(int KH, int KW, int Cin, int Cout);
 int igan_pieces_image_ok(int N, int HW, int C);
 /* ABI v7: which piece form this process runs (read once from IGAN_CONV_PLANES): 0 = none (every convolution on the fp32 matrix instruction),
- * 1 = three bf16 pieces / six products (the default), 2 = the two-piece fp16 VARIANT: per-tensor power-of-two scale, p0 = fp16(v S),
+ * 1 = three bf16 pieces / six products, 2 = two fp16 pieces (the default when the variable is unset): per-tensor power-of-two scale, p0 = fp16(v S),
  * p1 = fp16((v S - p0) 2^11), three products (main term folded per 16-deep step by the vector ALU, cross terms chained in the matrix pipe),
  * exact to 2^-24 for every element within 2^26 of its tensor's largest magnitude.  Piece images of form 2 live in the
  * SAME buffers (N * HW * C * 6 bytes): 4 bytes per element of image, then the tensor's block maxima and 1 / S -- callers need not know. */

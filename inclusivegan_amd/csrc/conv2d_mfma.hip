@@ -1183,13 +1183,14 @@ __global__ __launch_bounds__(256) void filter_planes_kernel(const float* __restr
 
 
 // ------------------------------------------------------------------------------
-// TWO-PIECE fp16 form of the piece kernels (IGAN_CONV_PLANES=2; a VARIANT, not the default: tools/piece_shape_probe.hip).
+// TWO-PIECE fp16 form of the piece kernels (IGAN_CONV_PLANES=2 or unset: the DEFAULT form; tools/piece_shape_probe.hip).
 //
 // Arithmetic.  fp16 carries 11 significand bits, so TWO pieces hold an fp32 value to 2^-24: with a per-tensor power-of-two scale S that brings
 // the tensor's largest magnitude into [2^14, 2^15) (exact: an exponent shift),  p0 = fp16(v S),  p1 = fp16((v S - p0) 2^11)  (|p1| <= |p0|: the
 // second piece is stored 2^11 up so that it lives in fp16's normal range too), and  v S = p0 + 2^-11 p1  to 2^-24 |v S| for every element within
-// 2^-26 of the tensor's largest (below that, one bit less per binade: fp16's subnormals; fp32 has the exponent range, this form does not -- which
-// is why it is a variant).  A product is three matrix instructions instead of six:
+// 2^-26 of the tensor's largest (below that, one bit less per binade: fp16's subnormals; the absolute error of ANY element is at most 2^-51 of
+// the tensor's largest magnitude -- 2^27 times smaller than one fp32 rounding of a sum that contains that largest element; igan_debug_f16_window
+// counts the elements outside the window).  A product is three matrix instructions instead of six:
 //     a b = (Sa Sb)^-1 [ p0a p0b + 2^-11 (p0a p1b + p1a p0b) ]        (dropped: 2^-22 p1a p1b <= 2^-24 |a b|, typically 2^-26)
 // the main term exactly as in the bf16 form (each 16-deep step from an exact zero, folded into the running fp32 sum by the vector ALU), the two
 // cross terms chained in a second accumulator of the matrix pipe (they carry 2^-11 of the result: the instruction's own rounding of them is
@@ -2062,6 +2063,29 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_wgr
 // that belongs in their slot; padding taps, the ragged end of the pixel axis and channel tails are out-of-range offsets (zeros).
 // grid and split as conv_wgrad_kernel; partial tiles go to the same workspace and plain_reduce_kernel adds them in fixed order.
 typedef __attribute__((ext_vector_type(4))) short s16x4;
+// The weight-gradient kernel issues its LDS-DMA through inline assembly (round 4, second session).  Its fragments are read with the
+// ds_read_b64_tr_b16 builtin, and the compiler -- which counts a `buffer_load ... lds` builtin as a pending write to LDS -- put an
+// `s_waitcnt vmcnt(0)` in front of those reads in every step: each wave then waited for the chunk it had issued ONE step earlier, i.e. the
+// two-deep prefetch was one deep.  (The forward kernel's plain ds_read_b128 do not get that wait.)  Issued from assembly the DMA is invisible to
+// the compiler's counters and the kernel's own `s_waitcnt vmcnt(NP)` in front of the barrier is the only wait, as designed; vector-memory
+// instructions the compiler does count (the epilogue's stores) only ever wait longer for it.  -DIGAN_WGRAD_ASM_DMA=0 restores the builtin.
+#ifndef IGAN_WGRAD_ASM_DMA
+#define IGAN_WGRAD_ASM_DMA 1
+#endif
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 raw_rsrc_words(const void* base, unsigned bytes) {     // the words __builtin_amdgcn_make_buffer_rsrc(base, 0, bytes, 0x00020000) makes
+    const unsigned long long b = (unsigned long long)(uintptr_t)base;
+    u32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((unsigned)b);
+    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32) & 0xFFFFu);
+    r[2] = __builtin_amdgcn_readfirstlane(bytes);
+    r[3] = 0x00020000u;
+    return r;
+}
+template <int SOFF>      // the piece displacement rides in the SCALAR offset (an inline constant): the instruction's immediate offset would also move the LDS address
+__device__ __forceinline__ void lds_dma16_asm(u32x4 rsrc, unsigned lds_addr, unsigned voffset) {      // 16 B per lane to lds_addr + 16 * lane
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voffset), "s"(rsrc), "n"(SOFF) : "memory", "m0");
+}
 template <int NP>
 __global__ __launch_bounds__(512, 4) void conv_wgrad_planes_kernel(WgradArgs a) {
     constexpr int TM = 2, WN = 4;
@@ -2139,6 +2163,30 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_planes_kernel(WgradArgs a) 
         wqy -= c2 ? QH : 0;
         wn_ += st_a1 + (c2 ? 1 : 0);
     };
+#if IGAN_WGRAD_ASM_DMA
+    const u32x4 wx = raw_rsrc_words(a.xp, xbytes), wdy = raw_rsrc_words(a.dyp, dybytes);
+    auto dma_piece = [&](int j) {       // as in conv_fwd_planes_kernel: waves 0-3 A pieces 0, 2 and B piece 1; waves 4-7 A piece 1 and B pieces 0, 2 (NP == 2: A 0, B 1 / A 1, B 0)
+        const unsigned A = (unsigned)(uintptr_t)(lds_void*)dA, B = A + IMG;
+        if constexpr (NP == 2) {
+            if (lowave) {
+                if (j == 0) lds_dma16_asm<0>(wx, A, offA);
+                if (j == 1) lds_dma16_asm<32>(wdy, B + 4096, offB);
+            } else {
+                if (j == 0) lds_dma16_asm<32>(wx, A + 4096, offA);
+                if (j == 1) lds_dma16_asm<0>(wdy, B, offB);
+            }
+        } else
+        if (lowave) {
+            if (j == 0) lds_dma16_asm<0>(wx, A, offA);
+            if (j == 1) lds_dma16_asm<64>(wx, A + 2 * 4096, offA);
+            if (j == 2) lds_dma16_asm<32>(wdy, B + 4096, offB);
+        } else {
+            if (j == 0) lds_dma16_asm<32>(wx, A + 4096, offA);
+            if (j == 1) lds_dma16_asm<0>(wdy, B, offB);
+            if (j == 2) lds_dma16_asm<64>(wdy, B + 2 * 4096, offB);
+        }
+    };
+#else
     auto dma_piece = [&](int j) {       // as in conv_fwd_planes_kernel: waves 0-3 A pieces 0, 2 and B piece 1; waves 4-7 A piece 1 and B pieces 0, 2
         unsigned char* A = dA;
         unsigned char* B = dA + IMG;
@@ -2162,6 +2210,7 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_planes_kernel(WgradArgs a) 
         }
     };
 
+#endif
     // ---- transposed fragment reads: lane 16 g + 4 q + p supplies row q, columns 4 p .. 4 p + 3 of its group's block
     // (k group g >> 1, channels 16 (g & 1) .. + 15 of the 32-wide fragment); the second read takes the block four rows below
     const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
@@ -2502,9 +2551,10 @@ bool walk_ok(const igan_conv2d_params* p) {
 }
 
 // The bf16-piece form is the DEFAULT for the shapes below (round 4); IGAN_CONV_PLANES=0 runs every convolution on the fp32 instruction.
-// IGAN_CONV_PLANES=2 is the two-piece fp16 VARIANT of the same kernels (three products; see "TWO-PIECE fp16 form" above): same shapes, same buffers.
+// Which piece form: IGAN_CONV_PLANES unset or 2 = two fp16 pieces, three products (see "TWO-PIECE fp16 form" above; the default since the second
+// session of round 4), 1 = three bf16 pieces, six products (the default before it), 0 = none.  Same shapes, same buffers for both piece forms.
 int planes_mode() {
-    static const int mode = [] { const char* v = getenv("IGAN_CONV_PLANES"); const int m = v ? atoi(v) : 1; return m == 0 ? 0 : (m == 2 ? 2 : 1); }();
+    static const int mode = [] { const char* v = getenv("IGAN_CONV_PLANES"); const int m = v ? atoi(v) : 2; return m == 0 ? 0 : (m == 1 ? 1 : 2); }();
     return mode;
 }
 bool planes_enabled() { return planes_mode() != 0; }

@@ -112,8 +112,11 @@ class GraphedStep:
             if other.graph is not None:
                 other.graph.replay()
         reset()
-        self.graph.replay()
-        a = snapshot(self.out)
+        if os.environ.get('IGAN_GRAPH_CHECK_EAGER_TWICE') == '1':      # DIAGNOSTIC: compare two EAGER executions instead (is the op itself reproducible here?)
+            a = snapshot(self._run_fn())
+        else:
+            self.graph.replay()
+            a = snapshot(self.out)
         reset()
         src = tfutil.random_source()
         tapped = src.by_op.get(self.name) if hasattr(src, 'by_op') else None     # a TapRandom must keep pointing at the GRAPH's draws

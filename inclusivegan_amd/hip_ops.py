@@ -564,7 +564,7 @@ def conv_flops(n, h, w, cin, oh, ow, cout, geom):
 
 
 PIECES_SHARE = os.environ.get('IGAN_PIECES_SHARE', '1') != '0'
-# ^ the bf16-piece form of the large 3x3 convolutions (csrc/conv2d_mfma.hip; the default since round 4, IGAN_CONV_PLANES=0 switches it off inside
+# ^ the piece forms of the large 3x3 convolutions (csrc/conv2d_mfma.hip; two fp16 pieces by default, IGAN_CONV_PLANES=1 three bf16 pieces, =0 switches them off inside
 #   the library) keeps its piece images shared between the calls of a layer (IGAN_PIECES_SHARE=0: every convolution call writes its own, A/B switch)
 
 _pieces_rule = {}

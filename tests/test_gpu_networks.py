@@ -130,6 +130,7 @@ def _check_losses_and_gradients(dev, res, fmap, B, lpips_weight, seed, only_g_lo
                               lpips_weight, phase=phase, state={})
         vo = lo if phase == 'loss' else ro
         vo.mean().backward()
+        worst['G_' + phase + '_value'] = rel_err(val, vo)
         assert rel_err(val, vo) < (2e-4 if phase == 'loss' else 1e-3), phase
         errs = _grad_errs(G, gp)
         w = max(errs, key=errs.get)
@@ -150,6 +151,7 @@ def _check_losses_and_gradients(dev, res, fmap, B, lpips_weight, seed, only_g_lo
         lo, ro, _ = OL.D_loss(gp, dp, cfg, Tape(rec.entries, torch.float64), B, reals.double(), gamma=100, phase=phase, state={})
         vo = lo if phase == 'loss' else ro
         vo.mean().backward()
+        worst['D_' + phase + '_value'] = rel_err(val, vo)
         assert rel_err(val, vo) < (2e-4 if phase == 'loss' else 1e-3), phase
         errs = _grad_errs(D, dp)
         w = max(errs, key=errs.get)

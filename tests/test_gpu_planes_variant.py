@@ -1,7 +1,8 @@
-"""GPU: the bf16-piece form of the forward / data-gradient / weight-gradient convolution (csrc/conv2d_mfma.hip conv_fwd_planes_kernel,
-conv_wgrad_planes_kernel) against fp64.  Since round 4 it is the DEFAULT form of the large 3x3 layers (IGAN_CONV_PLANES=0 restores the
-fp32 instruction everywhere): the switch is read once per process, so the checks run in child processes with the
-switch stated explicitly either way.  Tolerances are those of the exact-fp32 path's own full-size tests
+"""GPU: the piece forms of the forward / data-gradient / weight-gradient convolution (csrc/conv2d_mfma.hip conv_fwd_planes_kernel,
+conv_wgrad_planes_kernel) against fp64: three bf16 pieces / six products (IGAN_CONV_PLANES=1, the default of the first half of round 4) and two
+fp16 pieces under a per-tensor power-of-two scale / three products (IGAN_CONV_PLANES=2 or unset: the default now).  IGAN_CONV_PLANES=0 restores
+the fp32 instruction everywhere.  The switch is read once per process, so the checks run in child processes with the
+switch stated explicitly.  Tolerances are those of the exact-fp32 path's own full-size tests
 (3e-6 relative to the output rms per element, tests/test_gpu_fullsize.py), plus the property that made the variant acceptable at
 all: no coherent shift of the outputs (|mean error| below 5e-8 rms; profiles/r03_bf16_split_rounding.txt)."""
 import os
@@ -126,8 +127,8 @@ print('PLANES-VARIANT-OK')
 
 @pytest.mark.parametrize('form', ['1', '2'], ids=['bf16_x3_six_products', 'fp16_x2_three_products'])
 def test_piece_forms_against_fp64(cuda_device, form):
-    """IGAN_CONV_PLANES=1: three bf16 pieces, six products (the default form).  =2: the two-piece fp16 VARIANT (per-tensor power-of-two
-    scale, three products) -- same kernels, same shapes, same tolerances."""
+    """IGAN_CONV_PLANES=1: three bf16 pieces, six products.  =2: two fp16 pieces under a per-tensor power-of-two scale, three products (the
+    default form) -- same kernels, same shapes, same tolerances."""
     env = dict(os.environ, IGAN_CONV_PLANES=form)
     r = subprocess.run([sys.executable, '-c', CHILD % ROOT], env=env, capture_output=True, text=True, timeout=600)
     sys.stdout.write(r.stdout[-3000:])
@@ -170,12 +171,13 @@ print('DIGESTS ' + ' '.join(out))
 '''
 
 
-def test_shared_piece_images_change_nothing(cuda_device):
+@pytest.mark.parametrize('form', ['1', '2'], ids=['bf16_x3', 'fp16_x2'])
+def test_shared_piece_images_change_nothing(cuda_device, form):
     """The piece images written once per layer (hip_ops.to_pieces -> x_pieces / dy_pieces, ABI v5) against every convolution call
     writing its own (IGAN_PIECES_SHARE=0): the same arithmetic on the same images, so outputs and all gradients are bit-identical."""
     digs = []
     for share in ('1', '0'):
-        env = dict(os.environ, IGAN_CONV_PLANES='1', IGAN_PIECES_SHARE=share)
+        env = dict(os.environ, IGAN_CONV_PLANES=form, IGAN_PIECES_SHARE=share)
         r = subprocess.run([sys.executable, '-c', SHARE_CHILD % ROOT], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
         digs.append([l for l in r.stdout.splitlines() if l.startswith('DIGESTS ')][-1])
@@ -189,6 +191,7 @@ sys.path.insert(0, %r)
 from inclusivegan_amd import hip_ops, _abi
 dev = torch.device('cuda', 0)
 lib = _abi.get_plugin()
+assert lib.igan_conv_piece_form() == (2 if int(sys.argv[1]) else 0)         # nothing in the environment = the two-piece fp16 form (ABI v7)
 assert lib.igan_conv_pieces_wanted(3, 3, 256, 256) == int(sys.argv[1]) and lib.igan_conv_pieces_wanted(1, 1, 256, 256) == 0 and lib.igan_conv_pieces_wanted(3, 3, 64, 256) == 0
 assert lib.igan_pieces_image_ok(4, 1024, 256) == int(sys.argv[1]) and lib.igan_pieces_image_ok(1, 1024, 256) == 0 and lib.igan_pieces_image_ok(4, 1024, 144) == 0
 p = _abi.Conv2DParams(x=1 << 20, w=1 << 20, y=1 << 20, in_scale=None, out_scale=None, workspace=None, workspace_floats=0, N=4, H=32, W=32, Cin=256, OH=32, OW=32,

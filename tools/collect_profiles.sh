@@ -10,7 +10,8 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 python bench.py --conv-shapes $OUT/conv_shapes.txt 2>$OUT/bench.err | tail -1 > $OUT/bench_n1.json        # the driver's command: full-size data set, refresh included
 python tools/conv_layers.py 0.2 > $OUT/conv_layers.txt 2>/dev/null
-IGAN_CONV_PLANES=0 python tools/conv_layers.py 0.2 > $OUT/conv_layers_exact_fp32.txt 2>/dev/null       # the second line's kernels
+IGAN_CONV_PLANES=0 python tools/conv_layers.py 0.2 > $OUT/conv_layers_exact_fp32.txt 2>/dev/null       # the labelled lines' kernels
+IGAN_CONV_PLANES=1 python tools/conv_layers.py 0.2 > $OUT/conv_layers_bf16_pieces.txt 2>/dev/null
 python tools/kernel_bench.py upfirdn 6 40 > $OUT/kernel_bench.txt 2>/dev/null
 python tools/kernel_bench.py epilogue 6 40 >> $OUT/kernel_bench.txt 2>/dev/null
 python tools/conv_sustain.py 1.5 2 4 6 8 12 >> $OUT/kernel_bench.txt 2>/dev/null
