@@ -587,7 +587,7 @@ def main():
         period = data_size * 10
         out['amortised_img_s'] = round(period / (period / out['value'] + state['refresh'][0]), 3)
     if piece_form() == 2:
-        # how often the two-piece fp16 form met an element outside the window in which it is exact to 2^-24 (more than 2^26 below its tensor's largest)
+        # how often the two-piece fp16 form met an element outside the window in which its two pieces hold the operand to 2^-23 (more than 2^26 below its tensor's largest)
         import ctypes
         below, imaged = ctypes.c_ulonglong(0), ctypes.c_ulonglong(0)
         _abi.check(_abi.get_plugin().igan_debug_f16_window(ctypes.byref(below), ctypes.byref(imaged), 0))

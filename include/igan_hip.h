@@ -259,7 +259,7 @@ int igan_pieces_image_ok(int N, int HW, int C);
 /* ABI v7: which piece form this process runs (read once from IGAN_CONV_PLANES): 0 = none (every convolution on the fp32 matrix instruction),
  * 1 = three bf16 pieces / six products, 2 = two fp16 pieces (the default when the variable is unset): per-tensor power-of-two scale, p0 = fp16(v S),
  * p1 = fp16((v S - p0) 2^11), three products (main term folded per 16-deep step by the vector ALU, cross terms chained in the matrix pipe),
- * exact to 2^-24 for every element within 2^26 of its tensor's largest magnitude.  Piece images of form 2 live in the
+ * the operand to 2^-23 (exactly in three cases of four) for every element within 2^26 of its tensor's largest magnitude.  Piece images of form 2 live in the
  * SAME buffers (N * HW * C * 6 bytes): 4 bytes per element of image, then the tensor's block maxima and 1 / S -- callers need not know. */
 int igan_conv_piece_form(void);
 /* Diagnostic for form 2 (synchronises the device): non-zero elements imaged so far BELOW the exact window (|v S| < 2^-12) and elements imaged in

@@ -1185,13 +1185,15 @@ __global__ __launch_bounds__(256) void filter_planes_kernel(const float* __restr
 // ------------------------------------------------------------------------------
 // TWO-PIECE fp16 form of the piece kernels (IGAN_CONV_PLANES=2 or unset: the DEFAULT form; tools/piece_shape_probe.hip).
 //
-// Arithmetic.  fp16 carries 11 significand bits, so TWO pieces hold an fp32 value to 2^-24: with a per-tensor power-of-two scale S that brings
+// Arithmetic.  fp16 carries 11 significand bits, so TWO pieces (11 + 11 + the sign of the second) hold 23 of an fp32 value's 24 significand bits always and
+// all 24 in three cases of four (tests/test_fp16_pairs_arithmetic.py: exact for 74.5 % of random values, at most ONE unit in the last place = 2^-23 |v| for
+// the rest, rms 4.4e-8 -- the size of one more fp32 rounding of the operand): with a per-tensor power-of-two scale S that brings
 // the tensor's largest magnitude into [2^14, 2^15) (exact: an exponent shift),  p0 = fp16(v S),  p1 = fp16((v S - p0) 2^11)  (|p1| <= |p0|: the
-// second piece is stored 2^11 up so that it lives in fp16's normal range too), and  v S = p0 + 2^-11 p1  to 2^-24 |v S| for every element within
-// 2^-26 of the tensor's largest (below that, one bit less per binade: fp16's subnormals; the absolute error of ANY element is at most 2^-51 of
-// the tensor's largest magnitude -- 2^27 times smaller than one fp32 rounding of a sum that contains that largest element; igan_debug_f16_window
+// second piece is stored 2^11 up so that it lives in fp16's normal range too), and  v S = p0 + 2^-11 p1  to 2^-23 |v S| for every element within
+// 2^-26 of the tensor's largest (below that, one bit less per binade: fp16's subnormals; the absolute error of ANY element is at most 2^-50 of
+// the tensor's largest magnitude -- 2^26 times smaller than one fp32 rounding of a sum that contains that largest element; igan_debug_f16_window
 // counts the elements outside the window).  A product is three matrix instructions instead of six:
-//     a b = (Sa Sb)^-1 [ p0a p0b + 2^-11 (p0a p1b + p1a p0b) ]        (dropped: 2^-22 p1a p1b <= 2^-24 |a b|, typically 2^-26)
+//     a b = (Sa Sb)^-1 [ p0a p0b + 2^-11 (p0a p1b + p1a p0b) ]        (dropped: 2^-22 p1a p1b -- at most 2^-22 |a b|, 2^-24.6 |a b| rms: one fp32 rounding of the product)
 // the main term exactly as in the bf16 form (each 16-deep step from an exact zero, folded into the running fp32 sum by the vector ALU), the two
 // cross terms chained in a second accumulator of the matrix pipe (they carry 2^-11 of the result: the instruction's own rounding of them is
 // 2^-35 of it).  Image layout [pixel][C/16][2][16] fp16 = 4 B per element -- the SAME buffers the bf16 form sizes at 6 B per element hold it and,
@@ -1199,7 +1201,7 @@ __global__ __launch_bounds__(256) void filter_planes_kernel(const float* __restr
 // No host involvement, no atomics: the maxima are combined by every block that needs S (max is order-independent: bit-reproducible).
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr int H_PARTIALS = 1024;     // block maxima per image (four per thread of a 256-thread consumer)
-// Diagnostic (igan_debug_f16_window): how many non-zero elements were imaged BELOW the window in which the two pieces are exact to 2^-24
+// Diagnostic (igan_debug_f16_window): how many non-zero elements were imaged BELOW the window in which the two pieces hold the value to 2^-23
 // (|v S| < 2^-12, i.e. more than 2^26 below the tensor's largest magnitude), and how many elements were imaged in all.
 __device__ unsigned long long g_f16_below_window = 0ull, g_f16_imaged = 0ull;
 

@@ -112,8 +112,9 @@ def main():
         f.write('\n# reading (GRBM_GUI_ACTIVE summed over 8 XCDs; FETCH_SIZE / WRITE_SIZE in KiB, FETCH_SIZE doubled per the gfx950 correction):\n')
         f.write('#  headline modconv, B=6 (M=98304, N=128, K=1152), %s:\n' % kname)
         f.write('#    cycles/launch = %.4g;  MFMA busy = %.4g / (cycles * 1024 SIMDs) = %.1f %% of cycles\n' % (gui, one(sq1, 'SQ_VALU_MFMA_BUSY_CYCLES'), busy * 100))
-        mops = one(sq2, 'SQ_INSTS_VALU_MFMA_MOPS_F32') + next((v[1] for (k, c), v in sq2.items() if c == 'SQ_INSTS_VALU_MFMA_MOPS_BF16' and norm(k) == kname), 0.0)
-        f.write('#    MFMA op count = %.4g MOPS * 512 = %.4g FLOP issued (algorithmic 2*M*N*K = 2.899e10; the piece form issues 6 bf16 products per fp32 product)\n' % (mops, mops * 512))
+        mops = one(sq2, 'SQ_INSTS_VALU_MFMA_MOPS_F32') + sum(next((v[1] for (k, c), v in sq2.items() if c == ctr and norm(k) == kname), 0.0)
+                                                             for ctr in ('SQ_INSTS_VALU_MFMA_MOPS_BF16', 'SQ_INSTS_VALU_MFMA_MOPS_F16'))
+        f.write('#    MFMA op count = %.4g MOPS * 512 = %.4g FLOP issued (algorithmic 2*M*N*K = 2.899e10; the piece forms issue 3 fp16 / 6 bf16 products per fp32 product)\n' % (mops, mops * 512))
         f.write('#    wave cycles: issue-stalled %.1f %% (SQ_WAIT_INST_ANY), parked on s_waitcnt / s_barrier %.1f %% (SQ_WAIT_ANY), issuing %.1f %%; LDS bank conflicts %g\n' % (
             one(sq1, 'SQ_WAIT_INST_ANY') / wc * 100, one(sq1, 'SQ_WAIT_ANY') / wc * 100, one(sq1, 'SQ_ACTIVE_INST_ANY') / wc * 100, one(sq1, 'SQ_LDS_BANK_CONFLICT')))
         f.write('#    instructions: %.3g MFMA, %.3g VALU (incl. MFMA), %.3g LDS, %.3g SALU, %.3g VMEM reads, %.3g VMEM writes\n' % (
