@@ -1089,10 +1089,6 @@ constexpr int PK = 16;                          // reduction depth of a stage
 constexpr int P_IMG = 3 * 128 * 32;             // bytes of one operand image: [3 pieces][128 rows][32 B]
 constexpr int P_STAGE = 2 * P_IMG;              // A + B
 constexpr int P_NSTAGE = 3;
-// Stages of the fp16 form's ring (its stage is 16 KiB: four fit two workgroups per CU; the bf16 form's 24 KiB stages do not): -DIGAN_F16_STAGES=4 is the EXPERIMENT.
-#ifndef IGAN_F16_STAGES
-#define IGAN_F16_STAGES 3
-#endif
 
 __device__ __forceinline__ void split3(float v, unsigned short (&o)[3]) {
     float r = v;
@@ -1377,11 +1373,10 @@ template <int NP>
 __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
     constexpr int BM = 128, BN = 128, WN = 4, TM = 2;
     static_assert(NP == 3 || NP == 2, "three bf16 pieces (six products) or two fp16 pieces (three products)");
-    constexpr int NST = (NP == 2) ? IGAN_F16_STAGES : P_NSTAGE;      // ring stages; chunks c+1 .. c+NST-2 are in flight while chunk c is consumed
     constexpr int IMG = NP * 128 * 32, STAGE = 2 * IMG;       // one operand's LDS image [NP pieces][128 rows][32 B]; a stage = A + B
     constexpr unsigned PB = NP * 32u;                          // bytes of one (pixel, 16-channel slice) in a piece image
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE + 3 * BM * 4];
-    int* row_pix = reinterpret_cast<int*>(smem + NST * STAGE);
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[P_NSTAGE * STAGE + 3 * BM * 4];
+    int* row_pix = reinterpret_cast<int*>(smem + P_NSTAGE * STAGE);
     int* row_n = row_pix + BM;
     float* row_nz = reinterpret_cast<float*>(row_n + BM);
 
@@ -1547,10 +1542,7 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
         inv_a_v = image_inv_scale(a.xp, (size_t)a.N * a.H * a.W * a.Cin);
         inv_b_v = image_inv_scale(a.wp, (size_t)a.KH * a.KW * a.Cin * a.Cout);
     }
-    if (c_begin < c_end) {
-#pragma unroll
-        for (int k = 0; k < NST - 1; k++) dma_chunk(k);
-    }
+    if (c_begin < c_end) { dma_chunk(0); dma_chunk(1); }
     // the epilogue's row tables, computed while the first chunks are in flight
     if (tid < BM) {
         const int m = m0 + tid;
@@ -1609,7 +1601,7 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
     };
     for (int c = c_begin; c < c_end; c++) {
         asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
-        const int nst = st >= 1 ? st - 1 : NST - 1;
+        const int nst = st >= 1 ? st - 1 : P_NSTAGE - 1;
         const unsigned char* S = smem + st * STAGE;
         bf16x8 af[TM][3], bfr[3];
 #pragma unroll
@@ -1643,7 +1635,7 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
         t1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][1], bfr[1], t1, 0, 0, 0);
         t1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][2], bfr[0], t1, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        st = (st + 1 == NST) ? 0 : st + 1;
+        st = (st + 1 == P_NSTAGE) ? 0 : st + 1;
     }
     fold(acc[1], t1);
 #else
@@ -1654,8 +1646,8 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; r++) u[tm][r] = 0.0f;
         for (int c = c_begin; c < c_end; c++) {
-            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * (NST - 2)) : "memory");     // chunk c landed (younger: chunks c+1 .. c+NST-2, two instructions each); the stage of chunk c-1 is free
-            const int nst = st >= 1 ? st - 1 : NST - 1;
+            asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");     // chunk c landed (two younger instructions: chunk c+1); stage st+2 is free
+            const int nst = st >= 1 ? st - 1 : P_NSTAGE - 1;
             const unsigned char* S = smem + st * STAGE;
             f16x8 a0[TM], a1[TM];
             const f16x8 b0 = __builtin_bit_cast(f16x8, *reinterpret_cast<const bf16x8*>(S + fb));
@@ -1681,7 +1673,7 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
             u[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[0], b0, u[0], 0, 0, 0);
             u[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[1], b0, u[1], 0, 0, 0);
             acc[1] += t;
-            st = (st + 1 == NST) ? 0 : st + 1;
+            st = (st + 1 == P_NSTAGE) ? 0 : st + 1;
         }
         // sum = (main + 2^-11 cross) / (Sa Sb): both scales are powers of two (exact); applied one after the other so that no intermediate leaves fp32's range
 #pragma unroll
@@ -1690,7 +1682,7 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
             for (int r = 0; r < 16; r++) acc[tm][r] = ((acc[tm][r] + u[tm][r] * (1.0f / 2048.0f)) * inv_a) * inv_b;
 #ifdef IGAN_F16_LDS_EXIT_FILL     // DIAGNOSTIC BUILD: leave a known pattern in the stages (does a LATER kernel read LDS it never wrote?)
         __syncthreads();
-        for (int i = tid; i < NST * STAGE / 4; i += 512) reinterpret_cast<unsigned*>(smem)[i] = (unsigned)(IGAN_F16_LDS_EXIT_FILL);
+        for (int i = tid; i < P_NSTAGE * STAGE / 4; i += 512) reinterpret_cast<unsigned*>(smem)[i] = (unsigned)(IGAN_F16_LDS_EXIT_FILL);
         __syncthreads();
 #endif
     } else {
@@ -1701,7 +1693,7 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
         // chunk c: issued two iterations ago (three instructions of this wave are younger: chunk c+1)
         asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
         // everyone has chunk c in stage st, and has finished reading stage st + 2 (chunk c-1): it is refilled with chunk c+2
-        const int nst = st >= 1 ? st - 1 : NST - 1;
+        const int nst = st >= 1 ? st - 1 : P_NSTAGE - 1;
         const unsigned char* S = smem + st * STAGE;
         bf16x8 af[TM][3], bfr[3];
 #ifdef IGAN_PLANES_NO_LDSREAD     // TIMING EXPERIMENT ONLY (wrong results): fragments read once, from the first stage
@@ -1745,7 +1737,7 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
 #endif
 #pragma unroll
         for (int tm = 0; tm < TM; tm++) acc[tm] += t[tm];
-        st = (st + 1 == NST) ? 0 : st + 1;
+        st = (st + 1 == P_NSTAGE) ? 0 : st + 1;
     }
     }
 #endif
@@ -2100,10 +2092,9 @@ template <int NP>
 __global__ __launch_bounds__(512, 4) void conv_wgrad_planes_kernel(WgradArgs a) {
     constexpr int TM = 2, WN = 4;
     static_assert(NP == 3 || NP == 2, "three bf16 pieces (six products) or two fp16 pieces (three products)");
-    constexpr int NST = (NP == 2) ? IGAN_F16_STAGES : P_NSTAGE;
     constexpr int IMG = NP * 4096, STAGE = 2 * IMG;            // one operand's LDS image [NP pieces][16 pixel rows][256 B]; a stage = A + B
     constexpr unsigned PB = NP * 32u;                          // bytes of one (pixel, 16-channel slice) in a piece image
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE];
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[P_NSTAGE * STAGE];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
@@ -2258,8 +2249,8 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_planes_kernel(WgradArgs a) 
         inv_b_v = image_inv_scale(a.dyp, (size_t)a.N * a.OH * a.OW * a.Cout);
     }
     if (c_begin < c_end) {
-#pragma unroll
-        for (int k = 0; k < NST - 1; k++) { dma_prep(k); dma_piece(0); dma_piece(1); if constexpr (NP == 3) dma_piece(2); }
+        dma_prep(0); dma_piece(0); dma_piece(1); if constexpr (NP == 3) dma_piece(2);
+        dma_prep(1); dma_piece(0); dma_piece(1); if constexpr (NP == 3) dma_piece(2);
     }
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int st = 0;
@@ -2285,7 +2276,7 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_planes_kernel(WgradArgs a) 
     };
     for (int c = c_begin; c < c_end; c++) {
         asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
-        const int nst = st >= 1 ? st - 1 : NST - 1;
+        const int nst = st >= 1 ? st - 1 : P_NSTAGE - 1;
         const unsigned char* S = smem + st * STAGE;
         bf16x8 af[TM][3], bfr[3];
 #pragma unroll
@@ -2319,7 +2310,7 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_planes_kernel(WgradArgs a) 
         t1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][1], bfr[1], t1, 0, 0, 0);
         t1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][2], bfr[0], t1, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        st = (st + 1 == NST) ? 0 : st + 1;
+        st = (st + 1 == P_NSTAGE) ? 0 : st + 1;
     }
     fold(acc[1], t1);
 #else
@@ -2330,8 +2321,8 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_planes_kernel(WgradArgs a) 
 #pragma unroll
             for (int r = 0; r < 16; r++) u[tm][r] = 0.0f;
         for (int c = c_begin; c < c_end; c++) {
-            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * (NST - 2)) : "memory");
-            const int nst = st >= 1 ? st - 1 : NST - 1;
+            asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+            const int nst = st >= 1 ? st - 1 : P_NSTAGE - 1;
             const unsigned char* S = smem + st * STAGE;
             f16x8 a0[TM], a1[TM];
             const f16x8 b0 = __builtin_bit_cast(f16x8, tr8(S, fB[0], fB[1]));
@@ -2355,7 +2346,7 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_planes_kernel(WgradArgs a) 
             u[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[0], b0, u[0], 0, 0, 0);
             u[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[1], b0, u[1], 0, 0, 0);
             acc[1] += t;
-            st = (st + 1 == NST) ? 0 : st + 1;
+            st = (st + 1 == P_NSTAGE) ? 0 : st + 1;
         }
 #pragma unroll
         for (int tm = 0; tm < TM; tm++)
@@ -2363,13 +2354,13 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_planes_kernel(WgradArgs a) 
             for (int r = 0; r < 16; r++) acc[tm][r] = ((acc[tm][r] + u[tm][r] * (1.0f / 2048.0f)) * inv_a) * inv_b;
 #ifdef IGAN_F16_LDS_EXIT_FILL     // DIAGNOSTIC BUILD, as in conv_fwd_planes_kernel
         __syncthreads();
-        for (int i = tid; i < NST * STAGE / 4; i += 512) reinterpret_cast<unsigned*>(smem)[i] = (unsigned)(IGAN_F16_LDS_EXIT_FILL);
+        for (int i = tid; i < P_NSTAGE * STAGE / 4; i += 512) reinterpret_cast<unsigned*>(smem)[i] = (unsigned)(IGAN_F16_LDS_EXIT_FILL);
         __syncthreads();
 #endif
     } else
     for (int c = c_begin; c < c_end; c++) {
         asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
-        const int nst = st >= 1 ? st - 1 : NST - 1;
+        const int nst = st >= 1 ? st - 1 : P_NSTAGE - 1;
         const unsigned char* S = smem + st * STAGE;
         bf16x8 af[TM][3], bfr[3];
 #pragma unroll
@@ -2395,7 +2386,7 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_planes_kernel(WgradArgs a) 
             }
 #pragma unroll
         for (int tm = 0; tm < TM; tm++) acc[tm] += t[tm];
-        st = (st + 1 == NST) ? 0 : st + 1;
+        st = (st + 1 == P_NSTAGE) ? 0 : st + 1;
     }
 #endif
     // epilogue: rows = input channels, columns = output channels (contiguous across lanes)
