@@ -14,11 +14,12 @@ separately (`imle_refresh_s`), as BASELINE.md prescribes.
 
 Prints ONE JSON line on rank 0.  Besides the contract fields it carries
   roofline      the conv family timed per call INSIDE the replayed training graphs with device-side time stamps, grouped by kernel
-                family; `kernel` = the family with the largest total time: algorithmic FLOPs / time vs its peak (bf16-piece families:
-                2.5 PFLOP/s bf16 dense / 6 products = 416.7 fp32-equivalent TFLOP/s; fp32-instruction families: 157.3 TFLOP/s), plus
+                family; `kernel` = the family with the largest total time: algorithmic FLOPs / time vs its peak (piece families: the 2.5 PFLOP/s
+                fp16 / bf16 dense peak over the form's products per fp32 product -- 3 for the default two-piece fp16 form = 833.3 fp32-equivalent
+                TFLOP/s, 6 for the bf16-piece form = 416.7; fp32-instruction families: 157.3 TFLOP/s), plus
                 `wgrad`, `families`; the north-star shape (128x128 Conv1) alone and the HBM-bound upfirdn2d (GB/s vs 8 TB/s) with HIP
                 events, sustained; `traffic` only from a --pmc pass taken on the kernels as they are now;
-  second_line_* the same steady state with the other convolution form (default path: the exact-fp32-instruction run), labelled;
+  second_line_exact_fp32 / line_bf16_pieces / line_fp16_pairs: the same steady state with the other convolution forms (child runs), labelled;
   cpu_baseline  the CPU oracle (oracle/, PyTorch-CPU fp32) timed on this box's host cores on a
                 bounded sample of the same workload (rank 0, N = 1 only).
 """
@@ -117,7 +118,7 @@ def parse_args():
     p.add_argument('--lpips-weight', type=float, default=2.5)
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true')
-    p.add_argument('--no-variant-line', action='store_true', help='skip the second, labelled measurement with the other convolution form (a child run of this script; default path: the exact-fp32 run)')
+    p.add_argument('--no-variant-line', action='store_true', help='skip the labelled measurements with the other convolution forms (child runs of this script: exact fp32 and the other piece form)')
     p.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='process-group backend for --gpus > 1 (nccl = RCCL; gloo for the one-GPU tests)')
     p.add_argument('--one-gpu', action='store_true', help='test hook: every rank on device 0 (needs --backend gloo: RCCL refuses two ranks on one device)')
     p.add_argument('--revalidate-every', type=int, default=0, help='stress check: every N iterations (untimed work inside the loop) replay each captured op against its eager execution again; the results land in hip_graphs.checks')

@@ -34,7 +34,8 @@
 extern "C" {
 #endif
 
-/* Bumped whenever a struct layout or a signature changes (2: fused conv epilogue fields, fp64 nearest-neighbour state). */
+/* Bumped whenever a struct layout, a signature or the set of exports changes (2: fused conv epilogue fields, fp64 nearest-neighbour state;
+ * 5 / 6: piece images and their sizes; 7: igan_conv_piece_form, igan_debug_f16_window -- no struct changed since 6). */
 #define IGAN_ABI_VERSION 7
 
 typedef void* igan_stream_t; /* hipStream_t */

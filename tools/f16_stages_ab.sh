@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 4: three stages (product) against four (libigan_hip_st4.so, -DIGAN_F16_STAGES=4) in the fp16 form's ring: digests, per-layer times, bench A/B.
+# Round 4: three stages (product) against four (libigan_hip_st4.so, -DIGAN_F16_STAGES=4: the knob exists in commit 81fce54 only) in the fp16 form's ring: digests, per-layer times, bench A/B.
 mkdir -p gpurun_out; OUT=gpurun_out/f16_stages_ab.txt; : > $OUT
 V=$PWD/inclusivegan_amd/csrc/libigan_hip_st4.so
 python tools/planes_digest.py > /tmp/dig_a.txt 2>/dev/null; IGAN_LIB=$V python tools/planes_digest.py > /tmp/dig_b.txt 2>/dev/null
