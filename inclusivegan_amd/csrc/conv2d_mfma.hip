@@ -1272,42 +1272,54 @@ __device__ __forceinline__ void split2(float vs, unsigned short (&o)[2]) {      
 }
 
 // x [P][C] fp32 (times scale[p / HW][C] when given) -> [P][C/16][2][16] fp16 with the tensor's scale; trailer = out + 4 * P * C bytes.
-// One float4 per lane and pass, lanes contiguous (a wave reads one KiB and writes one KiB, whole lines both ways): the four lanes of a 16-channel unit exchange
-// their 8-byte piece halves (quad shuffles) so that lane q of the unit stores the q-th 16 bytes of its 64.  A fixed grid walks the tensor: the block maxima
-// (4 KiB at device scope) are read once per BLOCK, not once per 16 KiB of input as in the first version of this kernel (one block per 256 units).
 __global__ __launch_bounds__(256) void to_planes_f16_kernel(const float* __restrict__ x, const float* __restrict__ scale, unsigned short* __restrict__ out,
-                                                             float* __restrict__ trailer, int total4, int C4, int HWC4) {
+                                                             float* __restrict__ trailer, int total, int cpp, int C, int HW) {
     __shared__ float red[4];
+    __shared__ uint4 stage[256 * 4];
     const float amax = image_amax(trailer, red);
     const float S = scale_from_amax(amax);
     if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(trailer + H_PARTIALS, inv_scale_from_amax(amax), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int q = threadIdx.x & 3;              // this lane's quarter of its unit (the stride of the walk is a multiple of 256: it never changes)
-    const int src = (q & 1) * 2;                // the two lanes of the quad whose halves this lane stores: 0, 1 or 2, 3
-    const bool second = q >= 2;                 // lanes 2, 3 store the second piece
-    int below = 0;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < total4; i += gridDim.x * 256) {
-        float4 v = reinterpret_cast<const float4*>(x)[i];
-        if (scale != nullptr) {
-            const float4 f = reinterpret_cast<const float4*>(scale)[(i / HWC4) * C4 + i % C4];
-            v.x *= f.x; v.y *= f.y; v.z *= f.z; v.w *= f.w;
-        }
-        const float vs[4] = {v.x * S, v.y * S, v.z * S, v.w * S};
-        unsigned short o[4][2];
+    const int idx = min((int)(blockIdx.x * 256 + threadIdx.x), total - 1);
+    const int p = idx / cpp, c = idx - p * cpp;
+    const float4* src = reinterpret_cast<const float4*>(x + (size_t)p * C + 16 * c);
+    float v[16];
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            split2(vs[e], o[e]);
-            below += (vs[e] != 0.0f && fabsf(vs[e]) < 0x1p-12f) ? 1 : 0;
-        }
-        const unsigned a0 = o[0][0] | ((unsigned)o[1][0] << 16), a1 = o[2][0] | ((unsigned)o[3][0] << 16);      // first piece of channels 4 q .. 4 q + 3
-        const unsigned b0 = o[0][1] | ((unsigned)o[1][1] << 16), b1 = o[2][1] | ((unsigned)o[3][1] << 16);      // second piece
-        uint4 u;
-        const unsigned la0 = __shfl(a0, src, 4), la1 = __shfl(a1, src, 4), ha0 = __shfl(a0, src + 1, 4), ha1 = __shfl(a1, src + 1, 4);
-        const unsigned lb0 = __shfl(b0, src, 4), lb1 = __shfl(b1, src, 4), hb0 = __shfl(b0, src + 1, 4), hb1 = __shfl(b1, src + 1, 4);
-        u.x = second ? lb0 : la0; u.y = second ? lb1 : la1; u.z = second ? hb0 : ha0; u.w = second ? hb1 : ha1;
-        reinterpret_cast<uint4*>(out)[i] = u;       // unit i / 4 at 64 (i / 4) bytes, its q-th 16 bytes: [piece 0: ch 0-7][piece 0: ch 8-15][piece 1: ch 0-7][piece 1: ch 8-15]
+    for (int i = 0; i < 4; i++) { const float4 f = src[i]; v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w; }
+    if (scale != nullptr) {
+        const float4* sc = reinterpret_cast<const float4*>(scale + (size_t)(p / HW) * C + 16 * c);
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const float4 f = sc[i]; v[4 * i] *= f.x; v[4 * i + 1] *= f.y; v[4 * i + 2] *= f.z; v[4 * i + 3] *= f.w; }
+    }
+    unsigned short pc[2][16];
+    int below = 0;
+    const bool mine = (int)(blockIdx.x * 256 + threadIdx.x) < total;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        unsigned short o[2];
+        const float vs = v[i] * S;
+        split2(vs, o);
+        pc[0][i] = o[0]; pc[1][i] = o[1];
+        below += (mine && vs != 0.0f && fabsf(vs) < 0x1p-12f) ? 1 : 0;
     }
     count_window(below, red);
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_f16_imaged, (unsigned long long)total4 * 4ull);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_f16_imaged, (unsigned long long)total * 16ull);
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++) {
+            uint4 u;
+            u.x = pc[q][8 * hh + 0] | ((unsigned)pc[q][8 * hh + 1] << 16); u.y = pc[q][8 * hh + 2] | ((unsigned)pc[q][8 * hh + 3] << 16);
+            u.z = pc[q][8 * hh + 4] | ((unsigned)pc[q][8 * hh + 5] << 16); u.w = pc[q][8 * hh + 6] | ((unsigned)pc[q][8 * hh + 7] << 16);
+            stage[threadIdx.x * 4 + 2 * q + hh] = u;
+        }
+    __syncthreads();
+    const int units = min(256, total - (int)blockIdx.x * 256);
+    uint4* dst = reinterpret_cast<uint4*>(out + (size_t)blockIdx.x * 256 * 32);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int j = k * 256 + threadIdx.x;
+        if (j < units * 4) dst[j] = stage[j];
+    }
 }
 
 // filter -> [K/16][tap][n][2][16] fp16 with the filter's scale (trailer as above; orientation as filter_planes_kernel)
@@ -2556,8 +2568,7 @@ void launch_piece_image(hipStream_t stream, const float* x, const float* scale, 
     if (planes_mode() == 2) {
         float* trailer = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(out) + (size_t)P_ * C * 4);
         hipLaunchKernelGGL(amax_partial_kernel, dim3(H_PARTIALS), dim3(256), 0, stream, x, scale, trailer, (int)((long long)P_ * C / 4), C / 4, (int)((long long)HW * C / 4));
-        const int total4 = (int)((long long)P_ * C / 4);
-        hipLaunchKernelGGL(to_planes_f16_kernel, dim3(std::min(igan::ceil_div(total4, 256), 4096)), dim3(256), 0, stream, x, scale, out, trailer, total4, C / 4, (int)((long long)HW * C / 4));
+        hipLaunchKernelGGL(to_planes_f16_kernel, dim3(igan::ceil_div(total, 256)), dim3(256), 0, stream, x, scale, out, trailer, total, cpp, C, HW);
     } else {
         hipLaunchKernelGGL(to_planes_kernel, dim3(igan::ceil_div(total, 256)), dim3(256), 0, stream, x, scale, out, total, cpp, C, HW);
     }
