@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 4: to_planes_f16_kernel rewritten (lane-contiguous float4 loads, quad shuffles, 16 B stores, fixed grid: block maxima read once per block) against the first version
-# (libigan_hip_oldimg.so = the evidence build): digests, piece / op tests, image times, bench A/B.
+# (libigan_hip_oldimg.so = the evidence build; the rewritten kernel itself is in commit ed78f43, not in the tree): digests, piece / op tests, image times, bench A/B.
 mkdir -p gpurun_out; OUT=gpurun_out/to_planes_ab.txt; : > $OUT
 V=$PWD/inclusivegan_amd/csrc/libigan_hip_oldimg.so
 python tools/planes_digest.py > /tmp/dig_a.txt 2>/dev/null; IGAN_LIB=$V python tools/planes_digest.py > /tmp/dig_b.txt 2>/dev/null
