@@ -35,8 +35,10 @@ extern "C" {
 #endif
 
 /* Bumped whenever a struct layout, a signature or the set of exports changes (2: fused conv epilogue fields, fp64 nearest-neighbour state;
- * 5 / 6: piece images and their sizes; 7: igan_conv_piece_form, igan_debug_f16_window -- no struct changed since 6). */
-#define IGAN_ABI_VERSION 7
+ * 5 / 6: piece images and their sizes; 7: igan_conv_piece_form, igan_debug_f16_window; 8: the two-piece fp16 form scales every tensor per
+ * pixel (forward / data gradient) or per channel (weight gradient) and writes its own images -- caller-written images (igan_to_pieces, x_pieces,
+ * dy_pieces) belong to the bf16-piece form only; no struct changed since 6). */
+#define IGAN_ABI_VERSION 8
 
 typedef void* igan_stream_t; /* hipStream_t */
 
@@ -150,7 +152,12 @@ int igan_bias_act_noise_bwd_dd(igan_stream_t stream, const float* dy, const floa
                                float* workspace, int noise_bcast, int N, int HW, int C, int act, float alpha, float gain);
 
 /* ------------------------------------------------------------------------
- * conv2d (implicit GEMM on f32 MFMA, exact fp32 accumulate).
+ * conv2d (implicit GEMM on the matrix cores, fp32 sums).  Three arithmetic forms, chosen once per process by IGAN_CONV_PLANES
+ * (igan_conv_piece_form() tells which): 0 = every convolution on the fp32 matrix instruction (exact fp32 FMA chain); 1 = the large 3x3 layers from
+ * three bf16 pieces per operand (all 24 significand bits, six products); 2 (default) = the large 3x3 layers from two fp16 pieces per operand
+ * (<= 1 ulp of the fp32 operand, three products) under power-of-two scales that follow every axis a matrix-instruction chain does not sum over:
+ * one per pixel of x in_scale and one per output channel of the filter in the forward / data-gradient kernel, one per channel of each operand in
+ * the weight gradient.  Small, 1x1 and thin layers always run on the fp32 instruction.
  * One entry point covers what the reference gets from tf.nn.conv2d (SAME stride 1,
  * networks_stylegan2.py:60,120; VALID stride 2, upfirdn_2d.py:332),
  * tf.nn.conv2d_transpose (VALID stride 2, upfirdn_2d.py:291), tf.matmul
@@ -184,10 +191,9 @@ typedef struct igan_conv2d_params {
     const float* in_scale;  /* [N, Cin] or NULL */
     const float* out_scale; /* [N, Cout] or NULL */
     float* workspace;       /* igan_conv2d_plan()'s workspace_floats floats, 16-byte aligned; NULL iff the plan asked for none.  It
-                             * holds the partial tiles of the sliced tail (splits > 1) and, for the shapes the library runs in its
-                             * bf16-piece form (the default for the large 3x3 layers; environment IGAN_CONV_PLANES=0 = exact-fp32
-                             * instruction everywhere), the piece images behind them; a launch that gets no room for the images runs
-                             * the fp32 kernel */
+                             * holds the partial tiles of the sliced tail (splits > 1) and, for the shapes the library runs in a
+                             * piece form (forms 1 and 2 above), the piece images of x and of the filter behind them (with their
+                             * scales in form 2); a launch that gets no room for the images runs the fp32 kernel */
     size_t workspace_floats;
     int N, H, W, Cin;
     int OH, OW, Cout;
@@ -207,8 +213,10 @@ typedef struct igan_conv2d_params {
                              * y = act(y + noise[n, oy, ox] * noise_strength[0] + bias[co]) * act_gain; NULL = no noise */
     const float* noise_strength; /* device scalar */
     int noise_bcast;        /* 1: noise is [1, OH, OW], shared by the batch (the layer's stored noise); 0: [N, OH, OW] */
-    const void* x_pieces;   /* bf16-piece form only (else NULL / ignored): the piece image of x * in_scale, written by igan_to_pieces(),
-                             * so that a caller who runs several convolutions on one tensor writes its image once */
+    const void* x_pieces;   /* bf16-piece form (IGAN_CONV_PLANES=1) only: the piece image of x * in_scale, written by igan_to_pieces(),
+                             * so that a caller who runs several convolutions on one tensor writes its image once.  NULL otherwise:
+                             * the fp16 form rejects a non-NULL image (ABI v8: its images are scaled per pixel here and per channel in
+                             * the weight gradient, so no image serves two calls), form 0 ignores it */
     size_t x_pieces_bytes;  /* its size, N * H * W * Cin * 6 (ABI v6): an image of any other size is rejected, never read */
 } igan_conv2d_params;
 
@@ -224,7 +232,7 @@ int igan_conv2d_kernel_name(const igan_conv2d_params* p, char* buf, int buflen);
  * written in HWIO [KH][KW][Cin][Cout].  The pixel axis is always reduced through
  * the caller's workspace in fixed order (bit-reproducible);
  * igan_conv2d_wgrad_plan() returns the split count and workspace size (the partial filters of the pixel
- * slices; in the bf16-piece variant also the piece images of x and dy, as for igan_conv2d). */
+ * slices; in the piece forms also the piece images of x and dy, as for igan_conv2d). */
 typedef struct igan_conv2d_wgrad_params {
     const float* x;         /* [N, H, W, Cin] */
     const float* dy;        /* [N, OH, OW, Cout] */
@@ -240,7 +248,7 @@ typedef struct igan_conv2d_wgrad_params {
     int pad_y, pad_x;
     int splits;
     float alpha;            /* dw is multiplied by alpha (see igan_conv2d_params) */
-    const void* x_pieces;   /* bf16-piece form only (else NULL / ignored): piece images of x * in_scale and dy * out_scale */
+    const void* x_pieces;   /* bf16-piece form (IGAN_CONV_PLANES=1) only: piece images of x * in_scale and dy * out_scale; NULL otherwise (as igan_conv2d_params) */
     const void* dy_pieces;
     size_t x_pieces_bytes;  /* N * H * W * Cin * 6 and N * OH * OW * Cout * 6 (ABI v6): checked before an image is read */
     size_t dy_pieces_bytes;
@@ -252,22 +260,22 @@ int igan_conv2d_wgrad(igan_stream_t stream, const igan_conv2d_wgrad_params* p);
  * "conv_wgrad_planes_kernel", "thin_wgrad_kernel", "dense_small_wgrad_kernel").  For profiling tools. */
 int igan_conv2d_wgrad_kernel_name(const igan_conv2d_wgrad_params* p, char* buf, int buflen);
 
-/* ABI v6: the library's own answer to "will a layer with this filter take the bf16-piece form?" (the batch-independent part of the
- * rule: 3x3 taps, both channel counts >= 128 and whole 32s, the form switched on) and "is a tensor [N, HW, C] one igan_to_pieces() can
- * image for it?" -- so that a host does not restate the rules.  Both return 0 / 1. */
+/* ABI v6: the library's own answer to "will a layer with this filter take a piece form?" (the batch-independent part of the
+ * rule: 3x3 taps, both channel counts >= 128 and whole 32s, a piece form switched on) and "is a tensor [N, HW, C] one igan_to_pieces() can
+ * image for it?" (form 1 only: always 0 in forms 0 and 2) -- so that a host does not restate the rules.  Both return 0 / 1. */
 int igan_conv_pieces_wanted(int KH, int KW, int Cin, int Cout);
 int igan_pieces_image_ok(int N, int HW, int C);
 /* ABI v7: which piece form this process runs (read once from IGAN_CONV_PLANES): 0 = none (every convolution on the fp32 matrix instruction),
- * 1 = three bf16 pieces / six products, 2 = two fp16 pieces (the default when the variable is unset): per-tensor power-of-two scale, p0 = fp16(v S),
- * p1 = fp16((v S - p0) 2^11), three products (main term folded per 16-deep step by the vector ALU, cross terms chained in the matrix pipe),
- * the operand to 2^-23 (exactly in three cases of four) for every element within 2^26 of its tensor's largest magnitude.  Piece images of form 2 live in the
- * SAME buffers (N * HW * C * 6 bytes): 4 bytes per element of image, then the tensor's block maxima and 1 / S -- callers need not know. */
+ * 1 = three bf16 pieces / six products, 2 = two fp16 pieces (the default when the variable is unset): p0 = fp16(v S), p1 = fp16((v S - p0) 2^11)
+ * with a power-of-two S per scale group (ABI v8: a pixel's channel vector / a filter's output channel in the forward and data-gradient kernel, a
+ * channel's pixels in the weight gradient -- never a whole tensor), three products; the operand to 2^-23 (exactly in three cases of four) for every
+ * element within 2^26 of the largest of its own group. */
 int igan_conv_piece_form(void);
-/* Diagnostic for form 2 (synchronises the device): non-zero elements imaged so far BELOW the exact window (|v S| < 2^-12) and elements imaged in
- * all; reset != 0 zeroes both counters. */
+/* Diagnostic for form 2 (synchronises the device): non-zero elements imaged so far BELOW the exact window (|v S| < 2^-12: more than 2^26 below the
+ * largest magnitude of the element's own scale group) and elements imaged in all; reset != 0 zeroes both counters. */
 int igan_debug_f16_window(unsigned long long* below, unsigned long long* imaged, int reset);
 
-/* bf16-piece form (default for the large 3x3 layers, IGAN_CONV_PLANES=0 switches it off -- DESIGN.md section 4): the piece image of a channel-minor tensor
+/* bf16-piece form (IGAN_CONV_PLANES=1) only -- IGAN_ERR_UNSUPPORTED in the other forms: the piece image of a channel-minor tensor
  * x [N, HW, C] (times scale [N, C] when given), `out` = N * HW * C * 6 bytes, 16-byte aligned, C % 16 == 0.  The convolution entry
  * points write the images they need themselves; a caller that feeds one tensor to several of them (dy to the data and the
  * weight gradient, x to the forward pass and the weight gradient) writes it once with this and passes it as x_pieces / dy_pieces. */

@@ -114,7 +114,7 @@ class TapsParams(ctypes.Structure):
                 ('taps', ctypes.c_int), ('n', ctypes.c_int), ('scale', ctypes.c_float)]
 
 
-ABI_VERSION = 7      # include/igan_hip.h IGAN_ABI_VERSION
+ABI_VERSION = 8      # include/igan_hip.h IGAN_ABI_VERSION
 STRUCTS = (UpFirDn2DParams, FusedBiasActParams, Conv2DParams, Conv2DWgradParams, DenseParams, DenseWgradParams, TapsParams)   # igan_struct_size ids
 
 DENSE_MAX_GROUPS = 24

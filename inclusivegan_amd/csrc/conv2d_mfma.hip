@@ -1187,32 +1187,42 @@ __global__ __launch_bounds__(256) void filter_planes_kernel(const float* __restr
 //
 // Arithmetic.  fp16 carries 11 significand bits, so TWO pieces (11 + 11 + the sign of the second) hold 23 of an fp32 value's 24 significand bits always and
 // all 24 in three cases of four (tests/test_fp16_pairs_arithmetic.py: exact for 74.5 % of random values, at most ONE unit in the last place = 2^-23 |v| for
-// the rest, rms 4.4e-8 -- the size of one more fp32 rounding of the operand): with a per-tensor power-of-two scale S that brings
-// the tensor's largest magnitude into [2^14, 2^15) (exact: an exponent shift),  p0 = fp16(v S),  p1 = fp16((v S - p0) 2^11)  (|p1| <= |p0|: the
-// second piece is stored 2^11 up so that it lives in fp16's normal range too), and  v S = p0 + 2^-11 p1  to 2^-23 |v S| for every element within
-// 2^-26 of the tensor's largest (below that, one bit less per binade: fp16's subnormals; the absolute error of ANY element is at most 2^-50 of
-// the tensor's largest magnitude -- 2^26 times smaller than one fp32 rounding of a sum that contains that largest element; igan_debug_f16_window
-// counts the elements outside the window).  A product is three matrix instructions instead of six:
+// the rest, rms 4.4e-8 -- the size of one more fp32 rounding of the operand): with a power-of-two scale S (exact: an exponent shift) that brings the largest
+// magnitude of the element's SCALE GROUP into [2^14, 2^15),  p0 = fp16(v S),  p1 = fp16((v S - p0) 2^11)  (|p1| <= |p0|: the second piece is stored 2^11 up
+// so that it lives in fp16's normal range too), and  v S = p0 + 2^-11 p1  to 2^-23 |v S| for every element within 2^26 of its group's largest.
+//
+// Scale groups (round 5: NO per-tensor window any more).  A scale may vary along any axis of an operand that is NOT summed over inside one matrix
+// instruction chain, because there it factors out of the chain exactly:
+//   forward / data gradient   A = x in_scale: one scale per PIXEL (its whole channel vector; the "row image").  A 3x3 output row reads nine different
+//                             pixels, so the scale does not factor out of the whole reduction -- it factors out of every 16-deep STEP (one tap, 16
+//                             channels of one pixel per row), and the step's sum is multiplied by 1 / S_pixel when the vector ALU folds it into the
+//                             running fp32 sum (one v_fma instead of one v_add).      B = the filter: one scale per OUTPUT CHANNEL (column n; the
+//                             epilogue multiplies by 1 / S_n).
+//   weight gradient           both operands are summed over pixels: one scale per CHANNEL of x in_scale and of dy out_scale (the "column image");
+//                             the epilogue multiplies row ci by 1 / S_ci and column co by 1 / S_co.
+// What is left is the window INSIDE one group, along the summed axis: an element more than 2^26 below the largest of its own pixel's channel vector
+// (forward), of its own filter column, or of its own channel's pixels (weight gradient) keeps one bit less per binade -- next to a term 2^26 larger in
+// the same sum, i.e. beyond what an fp32 sum of those terms resolves.  igan_debug_f16_window counts such elements.
+// A product is three matrix instructions instead of six:
 //     a b = (Sa Sb)^-1 [ p0a p0b + 2^-11 (p0a p1b + p1a p0b) ]        (dropped: 2^-22 p1a p1b -- at most 2^-22 |a b|, 2^-24.6 |a b| rms: one fp32 rounding of the product)
-// the main term exactly as in the bf16 form (each 16-deep step from an exact zero, folded into the running fp32 sum by the vector ALU), the two
-// cross terms chained in a second accumulator of the matrix pipe (they carry 2^-11 of the result: the instruction's own rounding of them is
-// 2^-35 of it).  Image layout [pixel][C/16][2][16] fp16 = 4 B per element -- the SAME buffers the bf16 form sizes at 6 B per element hold it and,
-// behind it (byte offset 4 * elements), a trailer of floats: partial[256] (block maxima of |v|, written by amax_partial_kernel), then 1 / S.
-// No host involvement, no atomics: the maxima are combined by every block that needs S (max is order-independent: bit-reproducible).
+// Forward: per 16-deep step the main term and the two cross terms each start from an exact zero in the matrix pipe; the vector ALU forms
+// (main + 2^-11 cross) / S_pixel and adds it to the running sum (round to nearest).  Weight gradient: main term folded per step, the cross terms chained
+// in a second accumulator of the matrix pipe over the whole reduction (the scales are constant along it).
+// Image layout [pixel][C/16][2][16] fp16 = 4 B per element.  Behind a row image: 1 / S per pixel (P floats).  Behind a column image: 1 / S per channel
+// (C floats), S per channel (C floats), the column-maximum partials (H_COLBLOCKS x C floats).  Behind a filter image: 1 / S per output channel, the
+// column-maximum partials.  No host involvement, no atomics in the data path (max is order-independent: bit-reproducible).
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-constexpr int H_PARTIALS = 1024;     // block maxima per image (four per thread of a 256-thread consumer)
+constexpr int H_COLBLOCKS = 1024;    // partial rows of a column-maximum pass (as many blocks stream the tensor)
+constexpr int H_KSK = 4;             // a filter's column maxima: partial rows per tap (HWIO orientation)
 // Diagnostic (igan_debug_f16_window): how many non-zero elements were imaged BELOW the window in which the two pieces hold the value to 2^-23
-// (|v S| < 2^-12, i.e. more than 2^26 below the tensor's largest magnitude), and how many elements were imaged in all.
+// (|v S| < 2^-12, i.e. more than 2^26 below the largest magnitude of the element's scale group), and how many elements were imaged in all.
 __device__ unsigned long long g_f16_below_window = 0ull, g_f16_imaged = 0ull;
 
-__device__ __forceinline__ float image_amax(const float* trailer, float* red);
-__device__ __forceinline__ float block_max_256(float v, float* red) {      // all 256 threads receive the maximum
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-}
+__host__ __device__ inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+// bytes of a row image of [P][C] (image + 1 / S per pixel), of a column image (image + 1 / S, S per channel + partials) and of a filter image
+inline size_t rows_part_bytes(size_t P_, size_t C) { return align256(4 * P_ * C + 4 * P_); }
+inline size_t cols_part_bytes(size_t P_, size_t C) { return align256(4 * P_ * C + 8 * C + 4 * (size_t)H_COLBLOCKS * C); }
+inline size_t filter_part_bytes(size_t taps, size_t Nn, size_t K) { return align256(4 * taps * Nn * K + 4 * Nn + 4 * taps * H_KSK * Nn); }
 
 // S = 2^(14 - floor(log2 amax)) as a float (amax = 0, subnormal or below 2^-112: the largest shift that keeps 1 / S normal; inf / nan: 2^-113)
 __device__ __forceinline__ float scale_from_amax(float amax) {
@@ -1225,43 +1235,10 @@ __device__ __forceinline__ float inv_scale_from_amax(float amax) {
     e = max(15, min(e, 254));
     return __uint_as_float((unsigned)(e - 14) << 23);
 }
-
-__device__ __forceinline__ float image_amax(const float* trailer, float* red) {       // the tensor's largest magnitude from its H_PARTIALS block maxima
-    // The trailer is a few KiB at a fixed address that one kernel writes from every XCD and the next reads from every XCD, replay after replay:
-    // it is read and written at DEVICE scope (past the XCDs' L2s), so that its coherence does not rest on the kernel-boundary cache maintenance.
-    float m = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 4; k++) m = fmaxf(m, __hip_atomic_load(trailer + 4 * threadIdx.x + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    return block_max_256(m, red);
-}
-__device__ __forceinline__ void count_window(int below, float* red) {      // per block: one atomic when anything is to be counted (diagnostic)
+__device__ __forceinline__ void count_window(int below) {      // per wave: one atomic when anything is to be counted (diagnostic)
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) below += __shfl_xor(below, o);
     if ((threadIdx.x & 63) == 0 && below != 0) atomicAdd(&g_f16_below_window, (unsigned long long)below);
-}
-
-// block maxima of |x * scale| over a flat fp32 array of n4 float4s (scale [N][C] per (sample, channel) or NULL; C % 4 == 0)
-__global__ __launch_bounds__(256) void amax_partial_kernel(const float* __restrict__ x, const float* __restrict__ scale, float* __restrict__ partial,
-                                                            int n4, int C4, int HWC4) {
-    __shared__ float red[4];
-    float m = 0.0f;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += 2 * H_PARTIALS * 256) {      // two loads in flight per lane
-        const int j = i + H_PARTIALS * 256;
-        float4 v = reinterpret_cast<const float4*>(x)[i];
-        float4 q = (j < n4) ? reinterpret_cast<const float4*>(x)[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (scale != nullptr) {
-            const float4 f = reinterpret_cast<const float4*>(scale)[(i / HWC4) * C4 + i % C4];
-            v.x *= f.x; v.y *= f.y; v.z *= f.z; v.w *= f.w;
-            if (j < n4) {
-                const float4 g = reinterpret_cast<const float4*>(scale)[(j / HWC4) * C4 + j % C4];
-                q.x *= g.x; q.y *= g.y; q.z *= g.z; q.w *= g.w;
-            }
-        }
-        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-        m = fmaxf(m, fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fmaxf(fabsf(q.z), fabsf(q.w))));
-    }
-    m = block_max_256(m, red);
-    if (threadIdx.x == 0) __hip_atomic_store(partial + blockIdx.x, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ __forceinline__ void split2(float vs, unsigned short (&o)[2]) {        // vs = v * S
@@ -1271,18 +1248,9 @@ __device__ __forceinline__ void split2(float vs, unsigned short (&o)[2]) {      
     o[1] = __builtin_bit_cast(unsigned short, p1);
 }
 
-// x [P][C] fp32 (times scale[p / HW][C] when given) -> [P][C/16][2][16] fp16 with the tensor's scale; trailer = out + 4 * P * C bytes.
-__global__ __launch_bounds__(256) void to_planes_f16_kernel(const float* __restrict__ x, const float* __restrict__ scale, unsigned short* __restrict__ out,
-                                                             float* __restrict__ trailer, int total, int cpp, int C, int HW) {
-    __shared__ float red[4];
-    __shared__ uint4 stage[256 * 4];
-    const float amax = image_amax(trailer, red);
-    const float S = scale_from_amax(amax);
-    if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(trailer + H_PARTIALS, inv_scale_from_amax(amax), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int idx = min((int)(blockIdx.x * 256 + threadIdx.x), total - 1);
-    const int p = idx / cpp, c = idx - p * cpp;
+// the 16 values of one (pixel, 16-channel slice) unit of x [P][C] (times scale[p / HW][C] when given)
+__device__ __forceinline__ void load_unit16(const float* __restrict__ x, const float* __restrict__ scale, int p, int c, int C, int HW, float (&v)[16]) {
     const float4* src = reinterpret_cast<const float4*>(x + (size_t)p * C + 16 * c);
-    float v[16];
 #pragma unroll
     for (int i = 0; i < 4; i++) { const float4 f = src[i]; v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w; }
     if (scale != nullptr) {
@@ -1290,19 +1258,9 @@ __global__ __launch_bounds__(256) void to_planes_f16_kernel(const float* __restr
 #pragma unroll
         for (int i = 0; i < 4; i++) { const float4 f = sc[i]; v[4 * i] *= f.x; v[4 * i + 1] *= f.y; v[4 * i + 2] *= f.z; v[4 * i + 3] *= f.w; }
     }
-    unsigned short pc[2][16];
-    int below = 0;
-    const bool mine = (int)(blockIdx.x * 256 + threadIdx.x) < total;
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-        unsigned short o[2];
-        const float vs = v[i] * S;
-        split2(vs, o);
-        pc[0][i] = o[0]; pc[1][i] = o[1];
-        below += (mine && vs != 0.0f && fabsf(vs) < 0x1p-12f) ? 1 : 0;
-    }
-    count_window(below, red);
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_f16_imaged, (unsigned long long)total * 16ull);
+}
+// the block's 256 units (16 KiB of contiguous image) go through LDS so that every store instruction of a wave writes one contiguous KiB
+__device__ __forceinline__ void store_units(const unsigned short (&pc)[2][16], uint4* stage, unsigned short* __restrict__ out, int total) {
 #pragma unroll
     for (int q = 0; q < 2; q++)
 #pragma unroll
@@ -1322,20 +1280,158 @@ __global__ __launch_bounds__(256) void to_planes_f16_kernel(const float* __restr
     }
 }
 
-// filter -> [K/16][tap][n][2][16] fp16 with the filter's scale (trailer as above; orientation as filter_planes_kernel)
+// ROW image: x [P][C] fp32 (times scale[p / HW][C] when given) -> [P][C/16][2][16] fp16, one scale per pixel, 1 / S to rowinv[P].  One thread per
+// (pixel, 16 channels); the cpp = C / 16 threads of a pixel (a power of two <= 64: they sit in one wave) share the pixel's maximum by shuffles.  ONE pass.
+__global__ __launch_bounds__(256) void rows_f16_kernel(const float* __restrict__ x, const float* __restrict__ scale, unsigned short* __restrict__ out,
+                                                        float* __restrict__ rowinv, int total, int cpp, int lcpp, int C, int HW) {
+    __shared__ uint4 stage[256 * 4];
+    const bool mine = (int)(blockIdx.x * 256 + threadIdx.x) < total;
+    const int idx = min((int)(blockIdx.x * 256 + threadIdx.x), total - 1);      // the last block's spare threads repeat its last unit (not stored)
+    const int p = idx >> lcpp, c = idx & (cpp - 1);
+    float v[16];
+    load_unit16(x, scale, p, c, C, HW, v);
+    float m = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) m = fmaxf(m, fabsf(v[i]));
+    for (int o = 1; o < cpp; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+    const float S = scale_from_amax(m);
+    if (mine && c == 0) rowinv[p] = inv_scale_from_amax(m);
+    unsigned short pc[2][16];
+    int below = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        unsigned short o[2];
+        const float vs = v[i] * S;
+        split2(vs, o);
+        pc[0][i] = o[0]; pc[1][i] = o[1];
+        below += (mine && vs != 0.0f && fabsf(vs) < 0x1p-12f) ? 1 : 0;
+    }
+    count_window(below);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_f16_imaged, (unsigned long long)total * 16ull);
+    store_units(pc, stage, out, total);
+}
+
+// Column maxima of |x scale| over a [P][C] tensor: partial[block][C].  A thread owns one channel quad (C4 = C / 4, a power of two <= 256) and
+// every (256 / C4)-th pixel of the block's share; two loads in flight per lane.
+__global__ __launch_bounds__(256) void cols_amax_kernel(const float* __restrict__ x, const float* __restrict__ scale, float* __restrict__ partial,
+                                                         int P_, int C4, int lC4, int HW) {
+    __shared__ float4 red[256];
+    const int q = threadIdx.x & (C4 - 1), pl = threadIdx.x >> lC4, ppi = 256 >> lC4;
+    const int step = gridDim.x * ppi;
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto take = [&](int p) {
+        float4 v = reinterpret_cast<const float4*>(x)[(size_t)p * C4 + q];
+        if (scale != nullptr) {
+            const float4 f = reinterpret_cast<const float4*>(scale)[(size_t)(p / HW) * C4 + q];
+            v.x *= f.x; v.y *= f.y; v.z *= f.z; v.w *= f.w;
+        }
+        m.x = fmaxf(m.x, fabsf(v.x)); m.y = fmaxf(m.y, fabsf(v.y)); m.z = fmaxf(m.z, fabsf(v.z)); m.w = fmaxf(m.w, fabsf(v.w));
+    };
+    int p = blockIdx.x * ppi + pl;
+    for (; p + step < P_; p += 2 * step) { take(p); take(p + step); }
+    if (p < P_) take(p);
+    red[threadIdx.x] = m;
+    __syncthreads();
+    if (pl == 0) {
+        for (int j = 1; j < ppi; j++) {
+            const float4 o = red[j * C4 + q];
+            m.x = fmaxf(m.x, o.x); m.y = fmaxf(m.y, o.y); m.z = fmaxf(m.z, o.z); m.w = fmaxf(m.w, o.w);
+        }
+        reinterpret_cast<float4*>(partial)[(size_t)blockIdx.x * C4 + q] = m;
+    }
+}
+// partial[rows][C] -> inv[C] = 1 / S, sc[C] = S.  grid = C / 8 blocks of 32 row lanes x 8 channels (a thread takes every 32nd row: the
+// partials are a latency chain otherwise -- four row lanes over 1024 rows took 44 us).
+__global__ __launch_bounds__(256) void cols_finalize_kernel(const float* __restrict__ partial, float* __restrict__ inv, float* __restrict__ sc, int rows, int C) {
+    __shared__ float red[256];
+    const int c = blockIdx.x * 8 + (threadIdx.x & 7), rl = threadIdx.x >> 3;
+    float m0 = 0.0f, m1 = 0.0f, m2 = 0.0f, m3 = 0.0f;
+    if (c < C) {
+        int r = rl;
+        for (; r + 96 < rows; r += 128) {       // four loads in flight per lane
+            m0 = fmaxf(m0, partial[(size_t)r * C + c]); m1 = fmaxf(m1, partial[(size_t)(r + 32) * C + c]);
+            m2 = fmaxf(m2, partial[(size_t)(r + 64) * C + c]); m3 = fmaxf(m3, partial[(size_t)(r + 96) * C + c]);
+        }
+        for (; r < rows; r += 32) m0 = fmaxf(m0, partial[(size_t)r * C + c]);
+    }
+    red[threadIdx.x] = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        float m = red[threadIdx.x];
+        for (int j = 1; j < 32; j++) m = fmaxf(m, red[8 * j + threadIdx.x]);
+        inv[c] = inv_scale_from_amax(m);
+        sc[c] = scale_from_amax(m);
+    }
+}
+// COLUMN image: x [P][C] fp32 (times scale[p / HW][C]) -> [P][C/16][2][16] fp16 with the per-channel scales sc[C]
+__global__ __launch_bounds__(256) void cols_f16_kernel(const float* __restrict__ x, const float* __restrict__ scale, unsigned short* __restrict__ out,
+                                                        const float* __restrict__ sc, int total, int cpp, int C, int HW) {
+    __shared__ uint4 stage[256 * 4];
+    const bool mine = (int)(blockIdx.x * 256 + threadIdx.x) < total;
+    const int idx = min((int)(blockIdx.x * 256 + threadIdx.x), total - 1);
+    const int p = idx / cpp, c = idx - p * cpp;
+    float v[16], S[16];
+    load_unit16(x, scale, p, c, C, HW, v);
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const float4 f = reinterpret_cast<const float4*>(sc + 16 * c)[i]; S[4 * i] = f.x; S[4 * i + 1] = f.y; S[4 * i + 2] = f.z; S[4 * i + 3] = f.w; }
+    unsigned short pc[2][16];
+    int below = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        unsigned short o[2];
+        const float vs = v[i] * S[i];
+        split2(vs, o);
+        pc[0][i] = o[0]; pc[1][i] = o[1];
+        below += (mine && vs != 0.0f && fabsf(vs) < 0x1p-12f) ? 1 : 0;
+    }
+    count_window(below);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_f16_imaged, (unsigned long long)total * 16ull);
+    store_units(pc, stage, out, total);
+}
+
+// Column maxima of a filter: the largest |W(tap, k, n)| over k per (tap [, k quarter], n).  The image kernel below takes the maximum over the partial rows.
+//   !WT: w[tap][k][n] (HWIO; n contiguous): grid (taps * H_KSK, ceil(Nn / 64)), 4 row lanes x 64 columns, partial[(tap * H_KSK + j) * Nn + n]
+//    WT: w[tap][n][k] (k contiguous): one wave per (tap, n) row, partial[tap * Nn + n]
 template <bool WT>
-__global__ __launch_bounds__(256) void filter_planes_f16_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, float* __restrict__ trailer,
-                                                                 int taps, int KW_, int Nn, int K) {
-    __shared__ float red[4];
-    const float amax = image_amax(trailer, red);
-    const float S = scale_from_amax(amax);
-    if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(trailer + H_PARTIALS, inv_scale_from_amax(amax), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__global__ __launch_bounds__(256) void filter_amax_kernel(const float* __restrict__ w, float* __restrict__ partial, int taps, int Nn, int K) {
+    if constexpr (WT) {
+        const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+        if (row >= taps * Nn) return;
+        const float4* src = reinterpret_cast<const float4*>(w + (size_t)row * K);
+        float m = 0.0f;
+        for (int i = lane; i < (K >> 2); i += 64) { const float4 f = src[i]; m = fmaxf(m, fmaxf(fmaxf(fabsf(f.x), fabsf(f.y)), fmaxf(fabsf(f.z), fabsf(f.w)))); }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0) partial[row] = m;
+    } else {
+        __shared__ float red[256];
+        const int tap = blockIdx.x / H_KSK, j = blockIdx.x - tap * H_KSK;
+        const int n = blockIdx.y * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+        const int k0 = (int)(((long long)j * K) / H_KSK), k1 = (int)(((long long)(j + 1) * K) / H_KSK);
+        float m = 0.0f;
+        if (n < Nn)
+            for (int k = k0 + rl; k < k1; k += 4) m = fmaxf(m, fabsf(w[((size_t)tap * K + k) * Nn + n]));
+        red[threadIdx.x] = m;
+        __syncthreads();
+        if (rl == 0 && n < Nn) partial[(size_t)blockIdx.x * Nn + n] = fmaxf(fmaxf(m, red[64 + threadIdx.x]), fmaxf(red[128 + threadIdx.x], red[192 + threadIdx.x]));
+    }
+}
+
+// filter -> [K/16][tap][n][2][16] fp16 with one scale per OUTPUT channel n (orientation as filter_planes_kernel); 1 / S_n to inv[Nn].
+// partial: `prow` rows of Nn column maxima (filter_amax_kernel).
+template <bool WT>
+__global__ __launch_bounds__(256) void filter_planes_f16_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, float* __restrict__ inv,
+                                                                 const float* __restrict__ partial, int prow, int taps, int KW_, int Nn, int K) {
     const int cpk = K >> 4;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= taps * Nn * cpk) return;
     int tap, n, c;
     if constexpr (WT) { c = idx % cpk; const int r = idx / cpk; n = r % Nn; tap = r / Nn; }
     else { n = idx % Nn; const int r = idx / Nn; c = r % cpk; tap = r / cpk; }
+    float amax = 0.0f;
+    for (int r = 0; r < prow; r++) amax = fmaxf(amax, partial[(size_t)r * Nn + n]);
+    const float S = scale_from_amax(amax);
+    if (tap == 0 && c == 0) inv[n] = inv_scale_from_amax(amax);
     float v[16];
     if constexpr (WT) {
         const float4* src = reinterpret_cast<const float4*>(w + ((size_t)(taps - 1 - tap) * Nn + n) * K + 16 * c);
@@ -1364,21 +1460,23 @@ __global__ __launch_bounds__(256) void filter_planes_f16_kernel(const float* __r
         }
 }
 
-// 1 / S of the image of `elems` elements at `img` (read by the tile kernels' epilogues)
-__device__ __forceinline__ float image_inv_scale(const unsigned short* img, size_t elems) {
-    return __hip_atomic_load(reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(img) + elems * 4) + H_PARTIALS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-template <int NP>
+// TAPO (fp16 form only): the reduction runs TAP outermost, the 16-channel slices of a tap inside it.  A row's pixel -- and with it the row's scale --
+// then stays the same for Cin / 16 consecutive steps, so the cross terms are chained in the matrix pipe over a tap and folded once per tap
+// (32 vector instructions per step instead of 64).  !TAPO: slice outermost, taps inside (the taps of a slice re-read the same shifted rows back to
+// back); every step folds its own cross terms.  Same products and the same per-step rounding of the main term either way; which one a layer takes is
+// a measured choice (igan_conv2d: IGAN_F16_TAP_OUTER).
+template <int NP, bool TAPO = false>
 __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
     constexpr int BM = 128, BN = 128, WN = 4, TM = 2;
     static_assert(NP == 3 || NP == 2, "three bf16 pieces (six products) or two fp16 pieces (three products)");
     constexpr int IMG = NP * 128 * 32, STAGE = 2 * IMG;       // one operand's LDS image [NP pieces][128 rows][32 B]; a stage = A + B
     constexpr unsigned PB = NP * 32u;                          // bytes of one (pixel, 16-channel slice) in a piece image
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[P_NSTAGE * STAGE + 3 * BM * 4];
+    constexpr int TABS = (NP == 2) ? 9 * BM * 4 : 0;           // fp16 form: 1 / S of the input pixel each (tap, tile row) reads (at most 3x3 taps)
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[P_NSTAGE * STAGE + 3 * BM * 4 + TABS];
     int* row_pix = reinterpret_cast<int*>(smem + P_NSTAGE * STAGE);
     int* row_n = row_pix + BM;
     float* row_nz = reinterpret_cast<float*>(row_n + BM);
+    float* tab_s = row_nz + BM;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: kept in a scalar register
@@ -1442,8 +1540,14 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
     // reduction order: 16-channel slice outermost, taps inside it -- the taps of a slice re-read the same (shifted) 96 B row
     // pieces back to back, so eight of the nine fetches of a row piece hit the XCD's L2
     const int ntap = nky * nkx;
-    int ld_cc = (c_begin < c_end) ? c_begin / ntap : 0;
-    int ld_t0 = (c_begin < c_end) ? c_begin - ld_cc * ntap : 0;
+    int ld_cc, ld_t0;
+    if constexpr (TAPO) {
+        ld_t0 = (c_begin < c_end) ? c_begin / a.cpt : 0;
+        ld_cc = (c_begin < c_end) ? c_begin - ld_t0 * a.cpt : 0;
+    } else {
+        ld_cc = (c_begin < c_end) ? c_begin / ntap : 0;
+        ld_t0 = (c_begin < c_end) ? c_begin - ld_cc * ntap : 0;
+    }
     int ld_ta = (c_begin < c_end) ? ld_t0 / nkx : 0;
     int ld_tb = (c_begin < c_end) ? ld_t0 - ld_ta * nkx : 0;
     const unsigned xbytes = (unsigned)a.N * a.H * a.W * a.Cin * (2u * NP), wbytes = (unsigned)a.KH * a.KW * a.Cin * a.Cout * (2u * NP);   // host: both < OOB
@@ -1478,37 +1582,35 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
     typedef __attribute__((address_space(3))) void lds_void;
     unsigned char* dA = nullptr;
     auto dma_prep = [&](int stage) {        // addresses of the next chunk, then one step forward in (slice, tap) order
-#ifdef IGAN_PLANES_NO_PREP      // TIMING EXPERIMENT ONLY (wrong results): how much of the step is the scalar address work?
-        dA = smem + stage * STAGE + (wave & 3) * 1024;
-        offA = baseA; soffB = 0u;
-        return;
-#endif
         const unsigned disp = (unsigned)(ld_ta * a.W + ld_tb) * pixA + (unsigned)ld_cc * PB;                      // scalar
         const unsigned bit = 1u << (ld_ta * nkx + ld_tb);                                                           // scalar
         offA = (maskA & bit) ? baseA + disp : OOB;
         const int ky = ky0 + (ld_ta << a.up_shift), kx = kx0 + (ld_tb << a.up_shift);
         soffB = (unsigned)((ld_cc * (a.KH * a.KW) + ky * a.KW + kx) * a.Cout) * PB;                               // scalar
         dA = smem + stage * STAGE + (wave & 3) * 1024;
-        ++ld_tb;
-        const int w1 = (ld_tb == nkx) ? 1 : 0;
-        ld_tb = w1 ? 0 : ld_tb;
-        ld_ta += w1;
-        const int w2 = (ld_ta == nky) ? 1 : 0;
-        ld_ta = w2 ? 0 : ld_ta;
-        ld_cc += w2;
+        if constexpr (TAPO) {
+            ++ld_cc;
+            const int w1 = (ld_cc == a.cpt) ? 1 : 0;
+            ld_cc = w1 ? 0 : ld_cc;
+            ld_tb += w1;
+            const int w2 = (ld_tb == nkx) ? 1 : 0;
+            ld_tb = w2 ? 0 : ld_tb;
+            ld_ta += w2;
+        } else {
+            ++ld_tb;
+            const int w1 = (ld_tb == nkx) ? 1 : 0;
+            ld_tb = w1 ? 0 : ld_tb;
+            ld_ta += w1;
+            const int w2 = (ld_ta == nky) ? 1 : 0;
+            ld_ta = w2 ? 0 : ld_ta;
+            ld_cc += w2;
+        }
     };
     auto dma_piece = [&](int j) {           // one of this wave's three KiB of the 24 KiB stage; the pieces of a (pixel, slice) are 32 B apart
         unsigned char* A = dA;
         unsigned char* B = dA + IMG;
         // an out-of-range offset stays out of range with the piece offset added
         // (the piece displacement rides in the scalar offset: the instruction's immediate offset would also move the LDS address)
-#ifdef IGAN_PLANES_NO_DMA_A       // TIMING EXPERIMENT ONLY (wrong results): the A operand's three DMA instructions become B re-fetches of the same size
-#define IGAN_A_RSRC rw
-#define IGAN_A_OFF voffB
-#else
-#define IGAN_A_RSRC rx
-#define IGAN_A_OFF offA
-#endif
         if constexpr (NP == 2) {        // 16 wave instructions per stage, two per wave: waves 0-3 A piece 0 and B piece 1, waves 4-7 A piece 1 and B piece 0
             if (lowave) {
                 if (j == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)A, 16, offA, 0, 0, 0);
@@ -1519,11 +1621,11 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
             }
         } else
         if (lowave) {
-            if (j == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(IGAN_A_RSRC, (lds_void*)A, 16, IGAN_A_OFF, 0, 0, 0);
-            if (j == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(IGAN_A_RSRC, (lds_void*)(A + 2 * 4096), 16, IGAN_A_OFF, 64, 0, 0);
+            if (j == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)A, 16, offA, 0, 0, 0);
+            if (j == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(A + 2 * 4096), 16, offA, 64, 0, 0);
             if (j == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(B + 4096), 16, voffB, soffB + 32u, 0, 0);
         } else {
-            if (j == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(IGAN_A_RSRC, (lds_void*)(A + 4096), 16, IGAN_A_OFF, 32, 0, 0);
+            if (j == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(A + 4096), 16, offA, 32, 0, 0);
             if (j == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)B, 16, voffB, soffB, 0, 0);
             if (j == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(B + 2 * 4096), 16, voffB, soffB + 64u, 0, 0);
         }
@@ -1536,13 +1638,34 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[tm][r] = 0.0f;
 
-    // NP == 2: the two tensors' 1 / S, fetched first (they are needed after the last step; as wave-uniform scalars they cost the epilogue nothing)
-    float inv_a_v = 1.0f, inv_b_v = 1.0f;
+    // NP == 2: 1 / S of the input pixel that tile row r reads under tap t (0 for padding taps and rows past the end: their A rows are zeros), fetched
+    // BEFORE the first DMA instructions (vmcnt counts in order: the table's loads must not wait behind the chunks) and stored to LDS behind them.
+    float tabv[3] = {0.0f, 0.0f, 0.0f};
     if constexpr (NP == 2) {
-        inv_a_v = image_inv_scale(a.xp, (size_t)a.N * a.H * a.W * a.Cin);
-        inv_b_v = image_inv_scale(a.wp, (size_t)a.KH * a.KW * a.Cin * a.Cout);
+        const float* rowinv = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.xp) + (size_t)a.N * a.H * a.W * a.Cin * 4);
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int i = tid + 512 * j;
+            const int t = i >> 7, r = i & 127;
+            if (t < ntap) {
+                const int ta = t / nkx, tb = t - ta * nkx;
+                const int m = m0 + r;
+                const bool rok = m < Mcls;
+                const int mm = rok ? m : 0;
+                const int nn = div_small(mm, QH * QW, inv_hw);
+                const int rr = mm - nn * (QH * QW);
+                const int qy = div_small(rr, QW, inv_w), qx = rr - qy * QW;
+                const int iy = (((qy * up + py) * a.stride - a.pad_y + ky0) >> a.up_shift) + ta, ix = (((qx * up + px) * a.stride - a.pad_x + kx0) >> a.up_shift) + tb;
+                if (rok & (iy >= 0) & (ix >= 0) & (iy < a.H) & (ix < a.W)) tabv[j] = rowinv[(nn * a.H + iy) * a.W + ix];
+            }
+        }
     }
     if (c_begin < c_end) { dma_chunk(0); dma_chunk(1); }
+    if constexpr (NP == 2) {
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            if (tid + 512 * j < 9 * BM) tab_s[tid + 512 * j] = tabv[j];
+    }
     // the epilogue's row tables, computed while the first chunks are in flight
     if (tid < BM) {
         const int m = m0 + tid;
@@ -1571,82 +1694,66 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
 
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int st = 0;
-    const float inv_a = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(inv_a_v))), inv_b = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(inv_b_v)));
-#ifdef IGAN_PLANES_TILE_SEQUENTIAL
-    static_assert(NP == 3, "the tile-sequential experiment exists for the bf16 form only");
-    // MEASURED AND NOT KEPT (round 4; -DIGAN_PLANES_TILE_SEQUENTIAL builds it): bit-identical to the default form below and
-    // 1.5 % slower forward, 4 % slower in the weight gradient (tools/planes_sched_ab.sh) -- the vector adds were not what the step waits for.
-    // The two 32x32 tiles of a wave run ONE AFTER THE OTHER (six dependent products each: a chain on one
-    // accumulator issues back to back, MI355X_MICROARCH.md), so the vector adds that fold a tile's step sum into its running sum no
-    // longer wait behind the whole cluster: tile 0's sixteen adds issue while tile 1's products execute, and tile 1's are deferred
-    // to the top of the NEXT step, where they fill the latency of the fragment reads behind the barrier (t1 stays live across the
-    // back edge; its next chain starts six products later).  The adds are plain v_add_f32: beside MFMAs a packed add costs 13 issue
-    // cycles against 4 (same guide), and the compiler packs them when left alone.  Same products, same order within a tile, same
-    // sums: bit-identical to the interleaved form.
-    f32x16 t0, t1 = zero;
-    // The adds are inline assembly, so the compiler's hazard recogniser does not see them: a vector read of an MFMA result needs
-    // 11 wait states behind the 8-pass write (it put `s_nop 9` there itself in the interleaved form), and nothing in the hardware
-    // interlocks it.  Both call sites sit far behind the chain they read (three MFMAs of the other tile / a barrier and nine LDS
-    // reads); the explicit s_nop keeps that true whatever the scheduler does around the fences.
-    auto fold = [](f32x16& acc_, const f32x16& t_) {
-        asm volatile("s_nop 7\n\ts_nop 3\n\t"
-                     "v_add_f32 %0, %8, %0\n\tv_add_f32 %1, %9, %1\n\tv_add_f32 %2, %10, %2\n\tv_add_f32 %3, %11, %3\n\t"
-                     "v_add_f32 %4, %12, %4\n\tv_add_f32 %5, %13, %5\n\tv_add_f32 %6, %14, %6\n\tv_add_f32 %7, %15, %7"
-                     : "+v"(acc_[0]), "+v"(acc_[1]), "+v"(acc_[2]), "+v"(acc_[3]), "+v"(acc_[4]), "+v"(acc_[5]), "+v"(acc_[6]), "+v"(acc_[7])
-                     : "v"(t_[0]), "v"(t_[1]), "v"(t_[2]), "v"(t_[3]), "v"(t_[4]), "v"(t_[5]), "v"(t_[6]), "v"(t_[7]));
-        asm volatile("v_add_f32 %0, %8, %0\n\tv_add_f32 %1, %9, %1\n\tv_add_f32 %2, %10, %2\n\tv_add_f32 %3, %11, %3\n\t"
-                     "v_add_f32 %4, %12, %4\n\tv_add_f32 %5, %13, %5\n\tv_add_f32 %6, %14, %6\n\tv_add_f32 %7, %15, %7"
-                     : "+v"(acc_[8]), "+v"(acc_[9]), "+v"(acc_[10]), "+v"(acc_[11]), "+v"(acc_[12]), "+v"(acc_[13]), "+v"(acc_[14]), "+v"(acc_[15])
-                     : "v"(t_[8]), "v"(t_[9]), "v"(t_[10]), "v"(t_[11]), "v"(t_[12]), "v"(t_[13]), "v"(t_[14]), "v"(t_[15]));
-    };
-    for (int c = c_begin; c < c_end; c++) {
-        asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
-        const int nst = st >= 1 ? st - 1 : P_NSTAGE - 1;
-        const unsigned char* S = smem + st * STAGE;
-        bf16x8 af[TM][3], bfr[3];
-#pragma unroll
-        for (int q = 0; q < 3; q++) {
-            bfr[q] = *reinterpret_cast<const bf16x8*>(S + fb + q * 4096);
-            af[0][q] = *reinterpret_cast<const bf16x8*>(S + fa[0] + q * 4096);
-        }
-#pragma unroll
-        for (int q = 0; q < 3; q++) af[1][q] = *reinterpret_cast<const bf16x8*>(S + fa[1] + q * 4096);
-        __builtin_amdgcn_sched_barrier(0);
-        fold(acc[1], t1);                       // the previous step's tile 1 (zero before the first step): under the read latency
-        dma_prep(nst);
-        __builtin_amdgcn_sched_barrier(0);
-        t0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][0], bfr[0], zero, 0, 0, 0);
-        t0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][0], bfr[1], t0, 0, 0, 0);
-        t0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][1], bfr[0], t0, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        dma_piece(0); dma_piece(1); dma_piece(2);       // chunk c + 2, issued inside the matrix cluster
-        __builtin_amdgcn_sched_barrier(0);
-        t0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][0], bfr[2], t0, 0, 0, 0);
-        t0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][1], bfr[1], t0, 0, 0, 0);
-        t0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][2], bfr[0], t0, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);      // tile 0's chain ends here: the fold below must stay three products behind it
-        t1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][0], bfr[0], zero, 0, 0, 0);
-        t1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][0], bfr[1], t1, 0, 0, 0);
-        t1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][1], bfr[0], t1, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        fold(acc[0], t0);                       // tile 0's chain ended three products ago: its adds run beside tile 1's products
-        __builtin_amdgcn_sched_barrier(0);
-        t1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][0], bfr[2], t1, 0, 0, 0);
-        t1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][1], bfr[1], t1, 0, 0, 0);
-        t1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][2], bfr[0], t1, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        st = (st + 1 == P_NSTAGE) ? 0 : st + 1;
-    }
-    fold(acc[1], t1);
-#else
-    f32x16 u[TM];       // NP == 2: the cross terms p0a p1b + p1a p0b, chained in the matrix pipe over the whole reduction (2^-11 of the result)
     if constexpr (NP == 2) {
+        // The FILTER fragment is the matrix instruction's first operand, so the accumulators hold the tile transposed: a lane owns ONE pixel row
+        // (l31) and its 16 registers are output channels (r & 3) + 8 (r >> 2) + 4 h of the wave's 32 -- the pixel's 1 / S is one value per lane
+        // and tile, and the epilogue stores 16 B per register quad.
+        const float* tab_row = tab_s + wm * 64 + l31;
+        if constexpr (TAPO) {
+            int ct = (c_begin < c_end) ? c_begin / a.cpt : 0;                       // tap of the chunk being consumed
+            int cs = (c_begin < c_end) ? c_begin - ct * a.cpt : 0;                  // its slice
+            f32x16 u[TM];       // the cross terms p0a p1b + p1a p0b of the current tap, chained in the matrix pipe (2^-11 of the tap's sum)
 #pragma unroll
-        for (int tm = 0; tm < TM; tm++)
+            for (int tm = 0; tm < TM; tm++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) u[tm][r] = 0.0f;
+                for (int r = 0; r < 16; r++) u[tm][r] = 0.0f;
+            for (int c = c_begin; c < c_end; c++) {
+                asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // as below
+                const int nst = st >= 1 ? st - 1 : P_NSTAGE - 1;
+                const unsigned char* S = smem + st * STAGE;
+                f16x8 a0[TM], a1[TM];
+                const f16x8 b0 = __builtin_bit_cast(f16x8, *reinterpret_cast<const bf16x8*>(S + fb));
+                const f16x8 b1 = __builtin_bit_cast(f16x8, *reinterpret_cast<const bf16x8*>(S + fb + 4096));
+#pragma unroll
+                for (int tm = 0; tm < TM; tm++) {
+                    a0[tm] = __builtin_bit_cast(f16x8, *reinterpret_cast<const bf16x8*>(S + fa[tm]));
+                    a1[tm] = __builtin_bit_cast(f16x8, *reinterpret_cast<const bf16x8*>(S + fa[tm] + 4096));
+                }
+                const float sc0 = tab_row[ct * BM], sc1 = tab_row[ct * BM + 32];
+                dma_prep(nst);
+                f32x16 t;           // one set of registers for the main term of both tiles
+                __builtin_amdgcn_sched_barrier(0);
+                t = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a0[0], zero, 0, 0, 0);       // main term: from an exact zero
+                u[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1, a0[0], u[0], 0, 0, 0);
+                u[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1, a0[1], u[1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                dma_piece(0); dma_piece(1);             // chunk c + 2, issued inside the matrix cluster
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[0][r] = __builtin_fmaf(t[r], sc0, acc[0][r]);        // vector ALU: round to nearest
+                __builtin_amdgcn_sched_barrier(0);
+                t = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a0[1], zero, 0, 0, 0);
+                u[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a1[0], u[0], 0, 0, 0);
+                u[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a1[1], u[1], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[1][r] = __builtin_fmaf(t[r], sc1, acc[1][r]);
+                ++cs;
+                if (cs == a.cpt || c + 1 == c_end) {        // the tap (or this slice of the reduction) ends: its cross terms join the sum under the tap's scale
+                    const float f0 = sc0 * (1.0f / 2048.0f), f1 = sc1 * (1.0f / 2048.0f);
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        acc[0][r] = __builtin_fmaf(u[0][r], f0, acc[0][r]); acc[1][r] = __builtin_fmaf(u[1][r], f1, acc[1][r]);
+                        u[0][r] = 0.0f; u[1][r] = 0.0f;
+                    }
+                    cs = 0; ++ct;
+                }
+                st = (st + 1 == P_NSTAGE) ? 0 : st + 1;
+            }
+        } else {
+        int ct = (c_begin < c_end) ? c_begin - (c_begin / ntap) * ntap : 0;      // tap of the chunk being consumed (the reduction runs slice outermost, taps inside)
         for (int c = c_begin; c < c_end; c++) {
-            asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");     // chunk c landed (two younger instructions: chunk c+1); stage st+2 is free
+            // chunk c landed (two younger instructions: chunk c+1); stage st+2 is free.  lgkmcnt(0): the first barrier also publishes the scale table
+            // (every wave's ds_write has completed before it arrives); later iterations have no LDS operation in flight at this point.
+            asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             const int nst = st >= 1 ? st - 1 : P_NSTAGE - 1;
             const unsigned char* S = smem + st * STAGE;
             f16x8 a0[TM], a1[TM];
@@ -1657,38 +1764,79 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
                 a0[tm] = __builtin_bit_cast(f16x8, *reinterpret_cast<const bf16x8*>(S + fa[tm]));
                 a1[tm] = __builtin_bit_cast(f16x8, *reinterpret_cast<const bf16x8*>(S + fa[tm] + 4096));
             }
+            const float sc0 = tab_row[ct * BM], sc1 = tab_row[ct * BM + 32];
+            ct = (ct + 1 == ntap) ? 0 : ct + 1;
             dma_prep(nst);
-            // The main term of the two 32x32 tiles goes through ONE set of 16 registers (tile 0's sum is folded while tile 1's products run): with
-            // acc, u and the fragments live, a second set does not fit the 128 registers of two workgroups per CU.
-            f32x16 t;
+            // One set of 32 registers (main term t, cross terms v) serves both 32x32 tiles of the wave: every product chain of a step starts from an exact
+            // zero, and (t + 2^-11 v) / S_pixel is added to the running sum by the vector ALU (round to nearest).
+            f32x16 t, v;
             __builtin_amdgcn_sched_barrier(0);
-            t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[0], b0, zero, 0, 0, 0);       // main term: from an exact zero
-            u[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[0], b1, u[0], 0, 0, 0);
-            u[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[1], b1, u[1], 0, 0, 0);
+            t = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a0[0], zero, 0, 0, 0);
+            v = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1, a0[0], zero, 0, 0, 0);
+            v = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a1[0], v, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             dma_piece(0); dma_piece(1);             // chunk c + 2, issued inside the matrix cluster
-            acc[0] += t;                            // vector ALU: round to nearest
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[0][r] = __builtin_fmaf(__builtin_fmaf(v[r], 1.0f / 2048.0f, t[r]), sc0, acc[0][r]);
             __builtin_amdgcn_sched_barrier(0);
-            t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[1], b0, zero, 0, 0, 0);
-            u[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[0], b0, u[0], 0, 0, 0);
-            u[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[1], b0, u[1], 0, 0, 0);
-            acc[1] += t;
+            t = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a0[1], zero, 0, 0, 0);
+            v = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1, a0[1], zero, 0, 0, 0);
+            v = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a1[1], v, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[1][r] = __builtin_fmaf(__builtin_fmaf(v[r], 1.0f / 2048.0f, t[r]), sc1, acc[1][r]);
             st = (st + 1 == P_NSTAGE) ? 0 : st + 1;
         }
-        // sum = (main + 2^-11 cross) / (Sa Sb): both scales are powers of two (exact); applied one after the other so that no intermediate leaves fp32's range
+        }
+        stamp(2);
+        // ---- epilogue of the transposed tile: every register quad is four consecutive output channels of the lane's pixel ----
+        // 1 / S_n of the filter's columns (exact: a power of two), then as in conv_fwd_dma_kernel
+        const float* winv = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.wp) + (size_t)a.KH * a.KW * a.Cin * a.Cout * 4);
+        const int cq = n0 + wn * 32 + 4 * h;        // channel of register quad q: cq + 8 q
+        float4 wi[4];
 #pragma unroll
-        for (int tm = 0; tm < TM; tm++)
+        for (int q = 0; q < 4; q++) wi[q] = (cq + 8 * q < a.Cout) ? *reinterpret_cast<const float4*>(winv + cq + 8 * q) : f4zero();     // Cout % 4 == 0 (host)
+        if (sliced && nsplit > 1) {
+            float* wst = a.y + ((size_t)(tile - a.full_tiles) * a.splits + split) * (BM * BN);
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[tm][r] = ((acc[tm][r] + u[tm][r] * (1.0f / 2048.0f)) * inv_a) * inv_b;
-#ifdef IGAN_F16_LDS_EXIT_FILL     // DIAGNOSTIC BUILD: leave a known pattern in the stages (does a LATER kernel read LDS it never wrote?)
-        __syncthreads();
-        for (int i = tid; i < P_NSTAGE * STAGE / 4; i += 512) reinterpret_cast<unsigned*>(smem)[i] = (unsigned)(IGAN_F16_LDS_EXIT_FILL);
-        __syncthreads();
-#endif
+            for (int tm = 0; tm < TM; tm++) {
+                const int row = wm * 64 + tm * 32 + l31;
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    *reinterpret_cast<float4*>(wst + row * BN + wn * 32 + 8 * q + 4 * h) =
+                        make_float4(acc[tm][4 * q] * wi[q].x, acc[tm][4 * q + 1] * wi[q].y, acc[tm][4 * q + 2] * wi[q].z, acc[tm][4 * q + 3] * wi[q].w);
+            }
+            return;
+        }
+        __syncthreads();        // the row tables
+        const bool scale = a.out_scale != nullptr;
+        const float alpha = a.alpha;
+        float4 bia[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) bia[q] = (a.act && a.bias && cq + 8 * q < a.Cout) ? *reinterpret_cast<const float4*>(a.bias + cq + 8 * q) : f4zero();
+#pragma unroll
+        for (int tm = 0; tm < TM; tm++) {
+            const int row = wm * 64 + tm * 32 + l31;
+            const int pix = row_pix[row];
+            if (pix < 0) continue;
+            const float* osc = a.out_scale + (size_t)row_n[row] * a.Cout;
+            const float nz = row_nz[row];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int co = cq + 8 * q;
+                if (co >= a.Cout) continue;
+                float4 o = make_float4(acc[tm][4 * q] * wi[q].x, acc[tm][4 * q + 1] * wi[q].y, acc[tm][4 * q + 2] * wi[q].z, acc[tm][4 * q + 3] * wi[q].w);
+                o.x *= alpha; o.y *= alpha; o.z *= alpha; o.w *= alpha;
+                if (scale) { const float4 d = *reinterpret_cast<const float4*>(osc + co); o.x *= d.x; o.y *= d.y; o.z *= d.z; o.w *= d.w; }
+                if (a.act) {
+                    o.x = epi_act(a.act, o.x + nz + bia[q].x, a.act_alpha) * a.act_gain; o.y = epi_act(a.act, o.y + nz + bia[q].y, a.act_alpha) * a.act_gain;
+                    o.z = epi_act(a.act, o.z + nz + bia[q].z, a.act_alpha) * a.act_gain; o.w = epi_act(a.act, o.w + nz + bia[q].w, a.act_alpha) * a.act_gain;
+                }
+                *reinterpret_cast<float4*>(a.out + (size_t)pix * a.Cout + co) = o;
+            }
+        }
+        stamp(3);
+        return;
     } else {
-#ifdef IGAN_PLANES_NO_LDSREAD
-    bf16x8 keep_a[TM][3], keep_b[3];
-#endif
     for (int c = c_begin; c < c_end; c++) {
         // chunk c: issued two iterations ago (three instructions of this wave are younger: chunk c+1)
         asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
@@ -1696,23 +1844,12 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
         const int nst = st >= 1 ? st - 1 : P_NSTAGE - 1;
         const unsigned char* S = smem + st * STAGE;
         bf16x8 af[TM][3], bfr[3];
-#ifdef IGAN_PLANES_NO_LDSREAD     // TIMING EXPERIMENT ONLY (wrong results): fragments read once, from the first stage
-        const unsigned char* S0 = (c == c_begin) ? S : smem;
-#else
         const unsigned char* S0 = S;
-#endif
 #pragma unroll
         for (int q = 0; q < 3; q++) {
-#ifdef IGAN_PLANES_NO_LDSREAD
-            if (c == c_begin) {
-#endif
             bfr[q] = *reinterpret_cast<const bf16x8*>(S0 + fb + q * 4096);
 #pragma unroll
             for (int tm = 0; tm < TM; tm++) af[tm][q] = *reinterpret_cast<const bf16x8*>(S0 + fa[tm] + q * 4096);
-#ifdef IGAN_PLANES_NO_LDSREAD
-            } else { bfr[q] = keep_b[q]; af[0][q] = keep_a[0][q]; af[1][q] = keep_a[1][q]; }
-            keep_b[q] = bfr[q]; keep_a[0][q] = af[0][q]; keep_a[1][q] = af[1][q];
-#endif
         }
         dma_prep(nst);
         f32x16 t[TM];
@@ -1732,15 +1869,11 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
                 for (int tm = 0; tm < TM; tm++) t[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][i], bfr[o - i], t[tm], 0, 0, 0);
                 ++g;
             }
-#ifdef IGAN_PLANES_NO_FOLD        // TIMING EXPERIMENT ONLY (wrong results): what do the 32 vector adds of a step cost?
-        if (c + 1 == c_end)
-#endif
 #pragma unroll
         for (int tm = 0; tm < TM; tm++) acc[tm] += t[tm];
         st = (st + 1 == P_NSTAGE) ? 0 : st + 1;
     }
     }
-#endif
     stamp(2);
     // ---- epilogue (as conv_fwd_dma_kernel) ----
     if (sliced && nsplit > 1) {
@@ -2243,77 +2376,12 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_planes_kernel(WgradArgs a) 
     for (int tm = 0; tm < TM; tm++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[tm][r] = 0.0f;
-    float inv_a_v = 1.0f, inv_b_v = 1.0f;       // NP == 2: the two tensors' 1 / S (conv_fwd_planes_kernel)
-    if constexpr (NP == 2) {
-        inv_a_v = image_inv_scale(a.xp, (size_t)a.N * a.H * a.W * a.Cin);
-        inv_b_v = image_inv_scale(a.dyp, (size_t)a.N * a.OH * a.OW * a.Cout);
-    }
     if (c_begin < c_end) {
         dma_prep(0); dma_piece(0); dma_piece(1); if constexpr (NP == 3) dma_piece(2);
         dma_prep(1); dma_piece(0); dma_piece(1); if constexpr (NP == 3) dma_piece(2);
     }
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int st = 0;
-    const float inv_a = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(inv_a_v))), inv_b = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(inv_b_v)));
-#ifdef IGAN_PLANES_TILE_SEQUENTIAL
-    static_assert(NP == 3, "the tile-sequential experiment exists for the bf16 form only");
-    // step schedule of conv_fwd_planes_kernel (tile after tile, tile 0 folded beside tile 1's products, tile 1 under the next step's reads)
-    f32x16 t0, t1 = zero;
-    // The adds are inline assembly, so the compiler's hazard recogniser does not see them: a vector read of an MFMA result needs
-    // 11 wait states behind the 8-pass write (it put `s_nop 9` there itself in the interleaved form), and nothing in the hardware
-    // interlocks it.  Both call sites sit far behind the chain they read (three MFMAs of the other tile / a barrier and nine LDS
-    // reads); the explicit s_nop keeps that true whatever the scheduler does around the fences.
-    auto fold = [](f32x16& acc_, const f32x16& t_) {
-        asm volatile("s_nop 7\n\ts_nop 3\n\t"
-                     "v_add_f32 %0, %8, %0\n\tv_add_f32 %1, %9, %1\n\tv_add_f32 %2, %10, %2\n\tv_add_f32 %3, %11, %3\n\t"
-                     "v_add_f32 %4, %12, %4\n\tv_add_f32 %5, %13, %5\n\tv_add_f32 %6, %14, %6\n\tv_add_f32 %7, %15, %7"
-                     : "+v"(acc_[0]), "+v"(acc_[1]), "+v"(acc_[2]), "+v"(acc_[3]), "+v"(acc_[4]), "+v"(acc_[5]), "+v"(acc_[6]), "+v"(acc_[7])
-                     : "v"(t_[0]), "v"(t_[1]), "v"(t_[2]), "v"(t_[3]), "v"(t_[4]), "v"(t_[5]), "v"(t_[6]), "v"(t_[7]));
-        asm volatile("v_add_f32 %0, %8, %0\n\tv_add_f32 %1, %9, %1\n\tv_add_f32 %2, %10, %2\n\tv_add_f32 %3, %11, %3\n\t"
-                     "v_add_f32 %4, %12, %4\n\tv_add_f32 %5, %13, %5\n\tv_add_f32 %6, %14, %6\n\tv_add_f32 %7, %15, %7"
-                     : "+v"(acc_[8]), "+v"(acc_[9]), "+v"(acc_[10]), "+v"(acc_[11]), "+v"(acc_[12]), "+v"(acc_[13]), "+v"(acc_[14]), "+v"(acc_[15])
-                     : "v"(t_[8]), "v"(t_[9]), "v"(t_[10]), "v"(t_[11]), "v"(t_[12]), "v"(t_[13]), "v"(t_[14]), "v"(t_[15]));
-    };
-    for (int c = c_begin; c < c_end; c++) {
-        asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
-        const int nst = st >= 1 ? st - 1 : P_NSTAGE - 1;
-        const unsigned char* S = smem + st * STAGE;
-        bf16x8 af[TM][3], bfr[3];
-#pragma unroll
-        for (int q = 0; q < 3; q++) {
-            bfr[q] = tr8(S + q * 4096, fB[0], fB[1]);
-            af[0][q] = tr8(S + q * 4096, fA[0][0], fA[0][1]);
-        }
-#pragma unroll
-        for (int q = 0; q < 3; q++) af[1][q] = tr8(S + q * 4096, fA[1][0], fA[1][1]);
-        __builtin_amdgcn_sched_barrier(0);
-        fold(acc[1], t1);
-        dma_prep(nst);
-        __builtin_amdgcn_sched_barrier(0);
-        t0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][0], bfr[0], zero, 0, 0, 0);
-        t0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][0], bfr[1], t0, 0, 0, 0);
-        t0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][1], bfr[0], t0, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        dma_piece(0); dma_piece(1); dma_piece(2);
-        __builtin_amdgcn_sched_barrier(0);
-        t0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][0], bfr[2], t0, 0, 0, 0);
-        t0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][1], bfr[1], t0, 0, 0, 0);
-        t0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][2], bfr[0], t0, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);      // tile 0's chain ends here: the fold below must stay three products behind it
-        t1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][0], bfr[0], zero, 0, 0, 0);
-        t1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][0], bfr[1], t1, 0, 0, 0);
-        t1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][1], bfr[0], t1, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        fold(acc[0], t0);
-        __builtin_amdgcn_sched_barrier(0);
-        t1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][0], bfr[2], t1, 0, 0, 0);
-        t1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][1], bfr[1], t1, 0, 0, 0);
-        t1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][2], bfr[0], t1, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        st = (st + 1 == P_NSTAGE) ? 0 : st + 1;
-    }
-    fold(acc[1], t1);
-#else
     f32x16 u[TM];       // NP == 2: the cross terms, as in conv_fwd_planes_kernel
     if constexpr (NP == 2) {
 #pragma unroll
@@ -2348,15 +2416,23 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_planes_kernel(WgradArgs a) 
             acc[1] += t;
             st = (st + 1 == P_NSTAGE) ? 0 : st + 1;
         }
+        // sum = (main + 2^-11 cross) / (S_ci S_co): the scales are per channel of x in_scale (rows) and of dy out_scale (columns), constant along the
+        // reduction, powers of two (exact); applied one after the other so that no intermediate leaves fp32's range
+        const float* xinv = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.xp) + (size_t)a.N * a.H * a.W * a.Cin * 4);
+        const float* dyinv = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.dyp) + (size_t)a.N * a.OH * a.OW * a.Cout * 4);
+        const int co_ = n0 + wn * 32 + l31;
+        const float inv_b = (co_ < a.Cout) ? dyinv[co_] : 0.0f;
 #pragma unroll
         for (int tm = 0; tm < TM; tm++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[tm][r] = ((acc[tm][r] + u[tm][r] * (1.0f / 2048.0f)) * inv_a) * inv_b;
-#ifdef IGAN_F16_LDS_EXIT_FILL     // DIAGNOSTIC BUILD, as in conv_fwd_planes_kernel
-        __syncthreads();
-        for (int i = tid; i < P_NSTAGE * STAGE / 4; i += 512) reinterpret_cast<unsigned*>(smem)[i] = (unsigned)(IGAN_F16_LDS_EXIT_FILL);
-        __syncthreads();
-#endif
+            for (int q = 0; q < 4; q++) {
+                const int ci = m0 + wm * 64 + tm * 32 + 8 * q + 4 * h;       // rows of register quad q: ci .. ci + 3 (Cin % 32 == 0: all in or all out)
+                const float4 ia = (ci < a.Cin) ? *reinterpret_cast<const float4*>(xinv + ci) : f4zero();
+                acc[tm][4 * q + 0] = ((acc[tm][4 * q + 0] + u[tm][4 * q + 0] * (1.0f / 2048.0f)) * ia.x) * inv_b;
+                acc[tm][4 * q + 1] = ((acc[tm][4 * q + 1] + u[tm][4 * q + 1] * (1.0f / 2048.0f)) * ia.y) * inv_b;
+                acc[tm][4 * q + 2] = ((acc[tm][4 * q + 2] + u[tm][4 * q + 2] * (1.0f / 2048.0f)) * ia.z) * inv_b;
+                acc[tm][4 * q + 3] = ((acc[tm][4 * q + 3] + u[tm][4 * q + 3] * (1.0f / 2048.0f)) * ia.w) * inv_b;
+            }
     } else
     for (int c = c_begin; c < c_end; c++) {
         asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
@@ -2388,7 +2464,6 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_planes_kernel(WgradArgs a) 
         for (int tm = 0; tm < TM; tm++) acc[tm] += t[tm];
         st = (st + 1 == P_NSTAGE) ? 0 : st + 1;
     }
-#endif
     // epilogue: rows = input channels, columns = output channels (contiguous across lanes)
     const size_t wsize = (size_t)a.KH * a.KW * a.Cin * a.Cout;
     float* out = a.out + (a.splits > 1 ? (size_t)split * wsize : (size_t)0) + (size_t)tap * a.Cin * a.Cout;
@@ -2561,25 +2636,44 @@ int planes_mode() {
 }
 bool planes_enabled() { return planes_mode() != 0; }
 
-// The piece image of x [P][C] (times scale [P / HW][C]) in the form that is switched on; `out` holds P * C * 6 bytes (the fp16 form uses 4 of
-// the 6 bytes per element for the image and 4100 bytes behind it for the tensor's scale: callers guarantee P * C >= 4096).
+int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// bf16 form: the piece image of x [P][C] (times scale [P / HW][C]); `out` holds P * C * 6 bytes.
 void launch_piece_image(hipStream_t stream, const float* x, const float* scale, unsigned short* out, int P_, int HW, int C) {
     const int cpp = C / PK, total = P_ * cpp;
-    if (planes_mode() == 2) {
-        float* trailer = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(out) + (size_t)P_ * C * 4);
-        hipLaunchKernelGGL(amax_partial_kernel, dim3(H_PARTIALS), dim3(256), 0, stream, x, scale, trailer, (int)((long long)P_ * C / 4), C / 4, (int)((long long)HW * C / 4));
-        hipLaunchKernelGGL(to_planes_f16_kernel, dim3(igan::ceil_div(total, 256)), dim3(256), 0, stream, x, scale, out, trailer, total, cpp, C, HW);
-    } else {
-        hipLaunchKernelGGL(to_planes_kernel, dim3(igan::ceil_div(total, 256)), dim3(256), 0, stream, x, scale, out, total, cpp, C, HW);
-    }
+    hipLaunchKernelGGL(to_planes_kernel, dim3(igan::ceil_div(total, 256)), dim3(256), 0, stream, x, scale, out, total, cpp, C, HW);
+}
+// fp16 form, forward / data gradient: the ROW image (one scale per pixel) of x [P][C]; `out` holds rows_part_bytes(P, C).  C / 16 a power of two <= 64.
+void launch_row_image(hipStream_t stream, const float* x, const float* scale, unsigned short* out, int P_, int HW, int C) {
+    const int cpp = C / PK, total = P_ * cpp;
+    float* rowinv = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(out) + (size_t)P_ * C * 4);
+    hipLaunchKernelGGL(rows_f16_kernel, dim3(igan::ceil_div(total, 256)), dim3(256), 0, stream, x, scale, out, rowinv, total, cpp, ilog2(cpp), C, HW);
+}
+// fp16 form, weight gradient: the COLUMN image (one scale per channel) of x [P][C]; `out` holds cols_part_bytes(P, C).  C / 4 a power of two <= 256.
+void launch_col_image(hipStream_t stream, const float* x, const float* scale, unsigned short* out, int P_, int HW, int C) {
+    const int cpp = C / PK, total = P_ * cpp, C4 = C / 4;
+    float* inv = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(out) + (size_t)P_ * C * 4);
+    float* sc = inv + C;
+    float* partial = sc + C;
+    const int ppi = 256 / C4;
+    const int blocks = std::min(H_COLBLOCKS, igan::ceil_div(P_, ppi));
+    hipLaunchKernelGGL(cols_amax_kernel, dim3(blocks), dim3(256), 0, stream, x, scale, partial, P_, C4, ilog2(C4), HW);
+    hipLaunchKernelGGL(cols_finalize_kernel, dim3(igan::ceil_div(C, 8)), dim3(256), 0, stream, (const float*)partial, inv, sc, blocks, C);
+    hipLaunchKernelGGL(cols_f16_kernel, dim3(igan::ceil_div(total, 256)), dim3(256), 0, stream, x, scale, out, (const float*)sc, total, cpp, C, HW);
 }
 void launch_filter_image(hipStream_t stream, const float* w, unsigned short* wp, bool wt, int taps, int KW_, int Nn, int K) {
     const int wtotal = taps * Nn * (K / PK);
     if (planes_mode() == 2) {
-        float* trailer = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(wp) + (size_t)taps * Nn * K * 4);
-        hipLaunchKernelGGL(amax_partial_kernel, dim3(H_PARTIALS), dim3(256), 0, stream, w, (const float*)nullptr, trailer, taps * Nn * K / 4, 1, 1);
-        if (wt) hipLaunchKernelGGL((filter_planes_f16_kernel<true>), dim3(igan::ceil_div(wtotal, 256)), dim3(256), 0, stream, w, wp, trailer, taps, KW_, Nn, K);
-        else hipLaunchKernelGGL((filter_planes_f16_kernel<false>), dim3(igan::ceil_div(wtotal, 256)), dim3(256), 0, stream, w, wp, trailer, taps, KW_, Nn, K);
+        float* inv = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(wp) + (size_t)taps * Nn * K * 4);
+        float* partial = inv + Nn;
+        if (wt) {
+            hipLaunchKernelGGL((filter_amax_kernel<true>), dim3(igan::ceil_div(taps * Nn, 4)), dim3(256), 0, stream, w, partial, taps, Nn, K);
+            hipLaunchKernelGGL((filter_planes_f16_kernel<true>), dim3(igan::ceil_div(wtotal, 256)), dim3(256), 0, stream, w, wp, inv, (const float*)partial, taps, taps, KW_, Nn, K);
+        } else {
+            hipLaunchKernelGGL((filter_amax_kernel<false>), dim3(taps * H_KSK, igan::ceil_div(Nn, 64)), dim3(256), 0, stream, w, partial, taps, Nn, K);
+            hipLaunchKernelGGL((filter_planes_f16_kernel<false>), dim3(igan::ceil_div(wtotal, 256)), dim3(256), 0, stream, w, wp, inv, (const float*)partial, taps * H_KSK, taps, KW_, Nn, K);
+        }
     } else {
         if (wt) hipLaunchKernelGGL((filter_planes_kernel<true>), dim3(igan::ceil_div(wtotal, 256)), dim3(256), 0, stream, w, wp, taps, KW_, Nn, K);
         else hipLaunchKernelGGL((filter_planes_kernel<false>), dim3(igan::ceil_div(wtotal, 256)), dim3(256), 0, stream, w, wp, taps, KW_, Nn, K);
@@ -2597,13 +2691,25 @@ bool planes_shape_ok(const igan_conv2d_params* p, const FwdTile& t, int Mmax) {
     if (p->KH * p->KW == 1 || (long long)p->KH * p->KW * p->Cin < 1152 || Mmax < 2048) return false;      // 1x1: the Skip layers and the nearest-neighbour distance GEMM stay on the fp32 instruction
     if ((long long)p->N * p->OH * p->OW >= (1LL << 24)) return false;
     if ((long long)p->N * p->H * p->W * p->Cin * 6 >= 0x7FFFFF00LL || (long long)p->KH * p->KW * p->Cin * p->Cout * 6 >= 0x7FFFFF00LL) return false;
+    // fp16 form: the pixel's scale is shared by shuffles among the Cin / 16 threads of a pixel (a power of two within one wave), the kernel's scale
+    // table holds nine taps, and the transposed tile stores four output channels per lane and register quad
+    if (planes_mode() == 2 && (!pow2(p->Cin / PK) || p->Cin / PK > 64 || p->KH * p->KW > 9 || p->Cout % 4 != 0)) return false;
     return true;
 }
 bool use_planes_kernel(const igan_conv2d_params* p, const FwdTile& t, int Mmax) {
-    return planes_shape_ok(p, t, Mmax) && (((uintptr_t)p->x | (uintptr_t)p->w | (uintptr_t)p->in_scale | (uintptr_t)p->x_pieces) & 15) == 0;
+    if (!planes_shape_ok(p, t, Mmax) || (((uintptr_t)p->x | (uintptr_t)p->w | (uintptr_t)p->in_scale | (uintptr_t)p->x_pieces) & 15) != 0) return false;
+    if (planes_mode() == 2 && (((uintptr_t)p->y | (uintptr_t)p->out_scale | (uintptr_t)p->bias) & 15) != 0) return false;      // 16 B epilogue accesses
+    return true;
 }
-size_t planes_x_floats(const igan_conv2d_params* p) { return (size_t)p->N * p->H * p->W * p->Cin * 6 / 4; }
-size_t planes_w_floats(const igan_conv2d_params* p) { return (size_t)p->KH * p->KW * p->Cin * p->Cout * 6 / 4; }
+// room for the piece images behind the partial tiles: the bf16 form's are 6 bytes per element, the fp16 form's a row image of x and a filter image with their scales
+size_t planes_x_floats(const igan_conv2d_params* p) {
+    if (planes_mode() == 2) return rows_part_bytes((size_t)p->N * p->H * p->W, (size_t)p->Cin) / 4;
+    return (size_t)p->N * p->H * p->W * p->Cin * 6 / 4;
+}
+size_t planes_w_floats(const igan_conv2d_params* p) {
+    if (planes_mode() == 2) return filter_part_bytes((size_t)p->KH * p->KW, (size_t)p->Cout, (size_t)p->Cin) / 4;
+    return (size_t)p->KH * p->KW * p->Cin * p->Cout * 6 / 4;
+}
 
 }  // namespace
 
@@ -2793,20 +2899,29 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
     const bool vec = a.vecA && a.vecB && (a.in_scale == nullptr || a.vecS);
     bool launched = false;
     if (planes) {       // bf16-piece form: write the two piece images, then the tile kernel
+        IGAN_REQUIRE(p->x_pieces == nullptr || planes_mode() == 1, "conv2d: the two-piece fp16 form writes its own images (one scale per pixel here, per channel in the weight gradient): x_pieces must be NULL");
         IGAN_REQUIRE(p->x_pieces == nullptr || p->x_pieces_bytes == planes_x_floats(p) * 4, "conv2d: x_pieces is not the image of this x (x_pieces_bytes != N*H*W*Cin*6)");
         const unsigned short* xp = reinterpret_cast<const unsigned short*>(p->x_pieces);
         unsigned short* wp = reinterpret_cast<unsigned short*>(p->workspace + partial_floats + planes_x_floats(p));
         const int cpp = p->Cin / PK;
         if (xp == nullptr) {         // no image from the caller: write it behind the partial tiles
             unsigned short* own = reinterpret_cast<unsigned short*>(p->workspace + partial_floats);
-            launch_piece_image(stream, p->x, p->in_scale, own, p->N * p->H * p->W, p->H * p->W, p->Cin);
+            if (planes_mode() == 2) launch_row_image(stream, p->x, p->in_scale, own, p->N * p->H * p->W, p->H * p->W, p->Cin);
+            else launch_piece_image(stream, p->x, p->in_scale, own, p->N * p->H * p->W, p->H * p->W, p->Cin);
             xp = own;
         }
         launch_filter_image(stream, p->w, wp, wt, p->KH * p->KW, p->KW, p->Cout, p->Cin);
         a.xp = xp; a.wp = wp;
         a.cpt = cpp;
-        if (planes_mode() == 2) hipLaunchKernelGGL((conv_fwd_planes_kernel<2>), grid, dim3(512), 0, stream, a);
-        else hipLaunchKernelGGL((conv_fwd_planes_kernel<3>), grid, dim3(512), 0, stream, a);
+        if (planes_mode() == 2) {
+            // reduction order of the fp16 form (see the kernel): tap outermost (the cross terms are folded once per tap); A/B switch IGAN_F16_TAP_OUTER=0:
+            // slice outermost, every step folds its cross terms.  Measured (profiles/r05_f16_rowscale.txt): kernel 490.6 -> 457.2 us on G 128 Conv1
+            // (Cin 128), 451.4 -> 428.0 us on G 32 Conv1 (Cin 512); whole layer list forward 186.0 -> 194.4, data gradient 189.2 -> 198.0 TFLOP/s.
+            static const int force = getenv("IGAN_F16_TAP_OUTER") ? atoi(getenv("IGAN_F16_TAP_OUTER")) : 1;
+            const bool tapo = force != 0;
+            if (tapo) hipLaunchKernelGGL((conv_fwd_planes_kernel<2, true>), grid, dim3(512), 0, stream, a);
+            else hipLaunchKernelGGL((conv_fwd_planes_kernel<2, false>), grid, dim3(512), 0, stream, a);
+        } else hipLaunchKernelGGL((conv_fwd_planes_kernel<3>), grid, dim3(512), 0, stream, a);
         IGAN_LAUNCH_CHECK("conv2d (piece form) launch");
         launched = true;
     } else
@@ -2936,10 +3051,18 @@ bool wgrad_planes_shape_ok(const igan_conv2d_wgrad_params* p) {
     }
     if ((long long)p->N * p->OH * p->OW < 2048 * (long long)p->up * p->up) return false;
     if ((long long)p->N * p->H * p->W * p->Cin * 6 >= 0x7FFFFF00LL || (long long)p->N * p->OH * p->OW * p->Cout * 6 >= 0x7FFFFF00LL) return false;
+    // fp16 form: the column-maximum pass gives every thread one channel quad (C / 4 a power of two <= 256)
+    if (planes_mode() == 2 && (!pow2(p->Cin) || !pow2(p->Cout) || p->Cin > 1024 || p->Cout > 1024)) return false;
     return true;
 }
-size_t wgrad_planes_x_floats(const igan_conv2d_wgrad_params* p) { return (size_t)p->N * p->H * p->W * p->Cin * 6 / 4; }
-size_t wgrad_planes_dy_floats(const igan_conv2d_wgrad_params* p) { return (size_t)p->N * p->OH * p->OW * p->Cout * 6 / 4; }
+size_t wgrad_planes_x_floats(const igan_conv2d_wgrad_params* p) {
+    if (planes_mode() == 2) return cols_part_bytes((size_t)p->N * p->H * p->W, (size_t)p->Cin) / 4;
+    return (size_t)p->N * p->H * p->W * p->Cin * 6 / 4;
+}
+size_t wgrad_planes_dy_floats(const igan_conv2d_wgrad_params* p) {
+    if (planes_mode() == 2) return cols_part_bytes((size_t)p->N * p->OH * p->OW, (size_t)p->Cout) / 4;
+    return (size_t)p->N * p->OH * p->OW * p->Cout * 6 / 4;
+}
 
 }  // namespace
 
@@ -3025,18 +3148,21 @@ extern "C" int igan_conv2d_wgrad(igan_stream_t stream_, const igan_conv2d_wgrad_
     const size_t partial_floats = (splits > 1) ? (size_t)splits * wsize : 0;
     if (wgrad_planes_shape_ok(p) && p->workspace != nullptr && (((uintptr_t)p->workspace | (uintptr_t)p->x | (uintptr_t)p->dy | (uintptr_t)p->in_scale | (uintptr_t)p->out_scale | (uintptr_t)p->x_pieces | (uintptr_t)p->dy_pieces) & 15) == 0 &&
         p->workspace_floats >= partial_floats + wgrad_planes_x_floats(p) + wgrad_planes_dy_floats(p)) {
+        IGAN_REQUIRE((p->x_pieces == nullptr && p->dy_pieces == nullptr) || planes_mode() == 1, "conv2d_wgrad: the two-piece fp16 form writes its own images (one scale per channel): x_pieces / dy_pieces must be NULL");
         IGAN_REQUIRE(p->x_pieces == nullptr || p->x_pieces_bytes == wgrad_planes_x_floats(p) * 4, "conv2d_wgrad: x_pieces is not the image of this x (x_pieces_bytes != N*H*W*Cin*6)");
         IGAN_REQUIRE(p->dy_pieces == nullptr || p->dy_pieces_bytes == wgrad_planes_dy_floats(p) * 4, "conv2d_wgrad: dy_pieces is not the image of this dy (dy_pieces_bytes != N*OH*OW*Cout*6)");
         const unsigned short* xp = reinterpret_cast<const unsigned short*>(p->x_pieces);
         const unsigned short* dyp = reinterpret_cast<const unsigned short*>(p->dy_pieces);
         if (xp == nullptr) {
             unsigned short* own = reinterpret_cast<unsigned short*>(p->workspace + partial_floats);
-            launch_piece_image(stream, p->x, p->in_scale, own, p->N * p->H * p->W, p->H * p->W, p->Cin);
+            if (planes_mode() == 2) launch_col_image(stream, p->x, p->in_scale, own, p->N * p->H * p->W, p->H * p->W, p->Cin);
+            else launch_piece_image(stream, p->x, p->in_scale, own, p->N * p->H * p->W, p->H * p->W, p->Cin);
             xp = own;
         }
         if (dyp == nullptr) {
             unsigned short* own = reinterpret_cast<unsigned short*>(p->workspace + partial_floats + wgrad_planes_x_floats(p));
-            launch_piece_image(stream, p->dy, p->out_scale, own, p->N * p->OH * p->OW, p->OH * p->OW, p->Cout);
+            if (planes_mode() == 2) launch_col_image(stream, p->dy, p->out_scale, own, p->N * p->OH * p->OW, p->OH * p->OW, p->Cout);
+            else launch_piece_image(stream, p->dy, p->out_scale, own, p->N * p->OH * p->OW, p->OH * p->OW, p->Cout);
             dyp = own;
         }
         a.xp = xp; a.dyp = dyp;
@@ -3092,7 +3218,9 @@ extern "C" int igan_conv_pieces_wanted(int KH, int KW, int Cin, int Cout) {
 
 extern "C" int igan_pieces_image_ok(int N, int HW, int C) {
     using namespace igan;
-    return (planes_enabled() && C >= 128 && C % 32 == 0 && (long long)N * HW >= 2048 && (long long)N * HW * C * 6 < 0x7FFFFF00LL) ? 1 : 0;
+    // only the bf16 form shares an image between calls: the fp16 form scales a tensor per pixel for the forward / data-gradient kernel and per channel for
+    // the weight gradient, so every call writes the image it needs
+    return (planes_mode() == 1 && C >= 128 && C % 32 == 0 && (long long)N * HW >= 2048 && (long long)N * HW * C * 6 < 0x7FFFFF00LL) ? 1 : 0;
 }
 
 extern "C" int igan_to_pieces(igan_stream_t stream_, const float* x, const float* scale, void* out, int N, int HW, int C) {
@@ -3101,7 +3229,7 @@ extern "C" int igan_to_pieces(igan_stream_t stream_, const float* x, const float
     IGAN_REQUIRE(N >= 1 && HW >= 1 && C >= 16 && C % 16 == 0, "to_pieces: C must be a positive multiple of 16");
     IGAN_REQUIRE((((uintptr_t)x | (uintptr_t)scale | (uintptr_t)out) & 15) == 0, "to_pieces: buffers must be 16-byte aligned");
     IGAN_REQUIRE((long long)N * HW * C * 6 < 0x7FFFFF00LL, "to_pieces: image too large (32-bit offsets)");
-    IGAN_REQUIRE(planes_mode() != 2 || (long long)N * HW * C >= 4096, "to_pieces: tensor too small for the two-piece form (its scale lives behind the image)");
+    if (planes_mode() != 1) return igan::fail(IGAN_ERR_UNSUPPORTED, "to_pieces: only the bf16-piece form (IGAN_CONV_PLANES=1) takes caller-written images (igan_pieces_image_ok() says so)");
     launch_piece_image((hipStream_t)stream_, x, scale, reinterpret_cast<unsigned short*>(out), N * HW, HW, C);
     IGAN_LAUNCH_CHECK("to_pieces launch");
     return IGAN_OK;

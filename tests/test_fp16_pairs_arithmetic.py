@@ -1,5 +1,6 @@
 """CPU: the arithmetic of the two-piece fp16 form of the large 3x3 convolutions (csrc/conv2d_mfma.hip "TWO-PIECE fp16 form"),
-restated in NumPy bit for bit -- the scale chosen from a tensor's largest magnitude (scale_from_amax / inv_scale_from_amax: exponent arithmetic on
+restated in NumPy bit for bit -- the scale chosen from a scale group's largest magnitude (round 5: a pixel's channel vector, a filter's output channel,
+a channel's pixels -- never a whole tensor; scale_from_amax / inv_scale_from_amax: exponent arithmetic on
 the float's bits), the split (split2: p0 = fp16(v S), p1 = fp16((v S - p0) 2^11), both round to nearest even) and the product rule
 a b = (Sa Sb)^-1 [p0a p0b + 2^-11 (p0a p1b + p1a p0b)] -- and the claims the header makes about them: the scale is an exact power of two that puts the
 largest magnitude in [2^14, 2^15); the pieces reconstruct v S to ONE unit in the last place of the fp32 value (2^-23 |v S|; exactly in about three
@@ -56,6 +57,120 @@ def test_two_pieces_hold_the_value_to_one_ulp_inside_the_window_and_2m36_absolut
     assert 0.70 < float((rel == 0).mean()) < 0.80                          # and exact in about three cases of four
     assert float(np.sqrt((rel ** 2).mean())) < 5e-8                        # rms: the size of one fp32 rounding (2^-24 / sqrt(3) = 3.4e-8)
     assert np.all(err[~inside] <= 2.0 ** -36)                              # below the window: fp16's subnormal spacing of the second piece (2^-24 / 2^11), one bit less per binade
+
+
+def _conv1d_pairs(x, w):
+    """The forward kernel's arithmetic (conv_fwd_planes_kernel<2>) on a 1-D three-tap convolution  y[m, n] = sum_t sum_c x[m + t - 1, c] w[t, c, n]:
+    one scale per PIXEL of x (its channel vector: rows_f16_kernel) and per OUTPUT CHANNEL of w (filter_planes_f16_kernel); the reduction runs 16-channel
+    slice outermost, taps inside; per step the main term and the two cross terms start from zero in the matrix pipe (modelled: exact sums rounded to
+    fp32), the vector ALU forms t' = fp32(t + v / 2048) and acc = fma(t', 1 / S_pixel, acc); the epilogue multiplies by 1 / S_n."""
+    P, C = x.shape
+    T, _, N = w.shape
+    Sp = np.array([scale_bits(np.abs(x[p]).max()) for p in range(P)], np.float32)           # [P, 2]: S, 1 / S
+    Sn = np.array([scale_bits(np.abs(w[:, :, n]).max()) for n in range(N)], np.float32)
+    a0, a1 = split2(x * Sp[:, :1]); b0, b1 = split2(w * Sn[None, None, :, 0])
+    a0, a1, b0, b1 = (t.astype(np.float64) for t in (a0, a1, b0, b1))
+    acc = np.zeros((P, N), np.float32)
+    for c0 in range(0, C, 16):
+        cs = slice(c0, c0 + 16)
+        for t in range(T):
+            sh = t - T // 2
+            lo, hi = max(0, -sh), min(P, P - sh)                                              # output rows whose tap-t pixel exists (others read zeros)
+            src = slice(lo + sh, hi + sh)
+            main = (a0[src, cs] @ b0[t, cs]).astype(np.float32)
+            cross = (a0[src, cs] @ b1[t, cs] + a1[src, cs] @ b0[t, cs]).astype(np.float32)
+            step = (main.astype(np.float64) + cross.astype(np.float64) / 2048.0).astype(np.float32)
+            acc[lo:hi] = (acc[lo:hi].astype(np.float64) + step.astype(np.float64) * Sp[src, 1:].astype(np.float64)).astype(np.float32)
+    return (acc.astype(np.float64) * Sn[None, :, 1].astype(np.float64)).astype(np.float32)
+
+
+def _conv1d_fp32_chain(x, w):
+    """The exact-fp32 matrix instruction: one fp32 FMA per term, in the kernel's order (tap outermost, channels inside)."""
+    P, C = x.shape
+    T, _, N = w.shape
+    acc = np.zeros((P, N), np.float32)
+    for t in range(T):
+        sh = t - T // 2
+        lo, hi = max(0, -sh), min(P, P - sh)
+        for c in range(C):
+            acc[lo:hi] = (acc[lo:hi].astype(np.float64) + np.outer(x[lo + sh:hi + sh, c].astype(np.float64), w[t, c].astype(np.float64))).astype(np.float32)
+    return acc
+
+
+def _conv1d_exact(x, w, absolute=False):
+    x = x.astype(np.float64); w = w.astype(np.float64)
+    if absolute:
+        x, w = np.abs(x), np.abs(w)
+    P = x.shape[0]
+    y = np.zeros((P, w.shape[2]))
+    for t in range(w.shape[0]):
+        sh = t - w.shape[0] // 2
+        lo, hi = max(0, -sh), min(P, P - sh)
+        y[lo:hi] += x[lo + sh:hi + sh] @ w[t]
+    return y
+
+
+def test_forward_arithmetic_has_no_window_across_pixels_or_output_channels():
+    """Round 5: scales per pixel and per output channel.  Measured per element against its own sum of magnitudes, the fp16 form is no worse than the
+    fp32 FMA chain on tensors with an outlier of 2^30, a dead pixel run at 2^-30, a dead output channel, a dead input channel -- the inputs on which
+    ONE scale per tensor (round 4) lost up to a bit per binade beyond 2^26 (the GPU side of the same statement: tests/test_gpu_f16_dynamic_range.py)."""
+    rng = np.random.default_rng(5)
+    P, C, N = 96, 128, 40
+    def base():
+        return rng.standard_normal((P, C)).astype(np.float32), (rng.standard_normal((3, C, N)) / np.sqrt(3 * C)).astype(np.float32)
+    cases = {}
+    x, w = base(); cases['randn'] = (x, w)
+    x, w = base(); x[17, 5] *= np.float32(2.0 ** 30); w[1, 9, 3] *= np.float32(2.0 ** 30); cases['outlier 2^30'] = (x, w)
+    x, w = base(); x[40:60] *= np.float32(2.0 ** -30); cases['pixels at 2^-30'] = (x, w)
+    x, w = base(); w[:, :, 7] *= np.float32(2.0 ** -30); w[:, 11, :] *= np.float32(2.0 ** -30); x[:, 3] *= np.float32(2.0 ** -30); cases['channels at 2^-30'] = (x, w)
+    x, w = base(); w *= np.float32(2.0 ** -100); cases['filters at 2^-100'] = (x, w)
+    for name, (x, w) in cases.items():
+        exact, mag = _conv1d_exact(x, w), _conv1d_exact(x, w, absolute=True)
+        e16 = np.abs(_conv1d_pairs(x, w) - exact) / mag
+        e32 = np.abs(_conv1d_fp32_chain(x, w) - exact) / mag
+        assert e16.max() <= 2.0 * e32.max() and np.sqrt((e16 ** 2).mean()) <= np.sqrt((e32 ** 2).mean()), (name, e16.max(), e32.max())
+        assert e16.max() < 2.0 ** -21, (name, e16.max())
+
+
+def test_one_scale_per_tensor_would_fail_the_same_inputs():
+    """The sensitivity of the check above: with ONE power-of-two scale for the whole of x (round 4's form) the run of pixels at 2^-30 of the rest loses
+    four of its 24 bits (2^30 / 2^26): measured per element against its own sum of magnitudes, ten times the per-pixel form's error on those rows."""
+    rng = np.random.default_rng(6)
+    P, C, N = 64, 128, 24
+    x = rng.standard_normal((P, C)).astype(np.float32); w = (rng.standard_normal((3, C, N)) / np.sqrt(3 * C)).astype(np.float32)
+    x[20:40] *= np.float32(2.0 ** -30)
+    S, inv = scale_bits(np.abs(x).max())
+    p0, p1 = split2(x * S)
+    xq = ((p0.astype(np.float64) + p1.astype(np.float64) / 2048.0) * float(inv))            # what the per-tensor image holds
+    rows = slice(22, 38)                                                                      # outputs that read dark pixels only
+    exact, mag = _conv1d_exact(x, w)[rows], _conv1d_exact(x, w, absolute=True)[rows]
+    e_tensor = (np.abs(_conv1d_exact(xq, w)[rows] - exact) / mag).max()
+    e_pixel = (np.abs(_conv1d_pairs(x, w)[rows] - exact) / mag).max()
+    assert e_tensor > 2.0 ** -22 > 4.0 * e_pixel, (e_tensor, e_pixel)         # measured: 2^-21.3 against 2^-24.6
+
+
+def test_weight_gradient_arithmetic_scales_per_channel():
+    """conv_wgrad_planes_kernel<2>: both operands are summed over pixels, so each carries one scale per CHANNEL (cols_f16_kernel); the main term is folded
+    per 16-pixel step, the cross terms are chained over the whole reduction, the epilogue multiplies row ci by 1 / S_ci and column co by 1 / S_co."""
+    rng = np.random.default_rng(7)
+    P, Ci, Co = 512, 48, 40
+    x = rng.standard_normal((P, Ci)).astype(np.float32); dy = rng.standard_normal((P, Co)).astype(np.float32)
+    x[:, 5] *= np.float32(2.0 ** -30); dy[:, 9] *= np.float32(2.0 ** -30); x[100, 7] *= np.float32(2.0 ** 30); dy[300, 2] *= np.float32(2.0 ** 30)
+    Sx = np.array([scale_bits(np.abs(x[:, c]).max()) for c in range(Ci)], np.float32); Sd = np.array([scale_bits(np.abs(dy[:, c]).max()) for c in range(Co)], np.float32)
+    a0, a1 = split2(x * Sx[None, :, 0]); b0, b1 = split2(dy * Sd[None, :, 0])
+    a0, a1, b0, b1 = (t.astype(np.float64) for t in (a0, a1, b0, b1))
+    acc = np.zeros((Ci, Co), np.float32); u = np.zeros((Ci, Co), np.float32)
+    for p0_ in range(0, P, 16):
+        ps = slice(p0_, p0_ + 16)
+        acc = (acc.astype(np.float64) + (a0[ps].T @ b0[ps]).astype(np.float32)).astype(np.float32)
+        u = (u.astype(np.float64) + a0[ps].T @ b1[ps] + a1[ps].T @ b0[ps]).astype(np.float32)
+    got = (((acc.astype(np.float64) + u.astype(np.float64) / 2048.0) * Sx[:, 1:].astype(np.float64)) * Sd[None, :, 1].astype(np.float64)).astype(np.float32)
+    exact = x.astype(np.float64).T @ dy.astype(np.float64); mag = np.abs(x.astype(np.float64)).T @ np.abs(dy.astype(np.float64))
+    chain = np.zeros((Ci, Co), np.float32)
+    for p in range(P):
+        chain = (chain.astype(np.float64) + np.outer(x[p].astype(np.float64), dy[p].astype(np.float64))).astype(np.float32)
+    e16, e32 = np.abs(got - exact) / mag, np.abs(chain - exact) / mag
+    assert e16.max() <= 2.0 * e32.max() and e16.max() < 2.0 ** -21, (e16.max(), e32.max())
 
 
 def test_product_rule_and_dot_product_accuracy():

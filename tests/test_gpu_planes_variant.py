@@ -1,6 +1,6 @@
 """GPU: the piece forms of the forward / data-gradient / weight-gradient convolution (csrc/conv2d_mfma.hip conv_fwd_planes_kernel,
 conv_wgrad_planes_kernel) against fp64: three bf16 pieces / six products (IGAN_CONV_PLANES=1, the default of the first half of round 4) and two
-fp16 pieces under a per-tensor power-of-two scale / three products (IGAN_CONV_PLANES=2 or unset: the default now).  IGAN_CONV_PLANES=0 restores
+fp16 pieces under per-pixel / per-channel power-of-two scales / three products (IGAN_CONV_PLANES=2 or unset: the default).  IGAN_CONV_PLANES=0 restores
 the fp32 instruction everywhere.  The switch is read once per process, so the checks run in child processes with the
 switch stated explicitly.  Tolerances are those of the exact-fp32 path's own full-size tests
 (3e-6 relative to the output rms per element, tests/test_gpu_fullsize.py), plus the property that made the variant acceptable at
@@ -127,8 +127,8 @@ print('PLANES-VARIANT-OK')
 
 @pytest.mark.parametrize('form', ['1', '2'], ids=['bf16_x3_six_products', 'fp16_x2_three_products'])
 def test_piece_forms_against_fp64(cuda_device, form):
-    """IGAN_CONV_PLANES=1: three bf16 pieces, six products.  =2: two fp16 pieces under a per-tensor power-of-two scale, three products (the
-    default form) -- same kernels, same shapes, same tolerances."""
+    """IGAN_CONV_PLANES=1: three bf16 pieces, six products.  =2: two fp16 pieces under per-pixel / per-channel power-of-two scales, three products
+    (the default form; channel counts that are not powers of two stay on the fp32 kernels there) -- same shapes, same tolerances."""
     env = dict(os.environ, IGAN_CONV_PLANES=form)
     r = subprocess.run([sys.executable, '-c', CHILD % ROOT], env=env, capture_output=True, text=True, timeout=600)
     sys.stdout.write(r.stdout[-3000:])
@@ -191,9 +191,11 @@ sys.path.insert(0, %r)
 from inclusivegan_amd import hip_ops, _abi
 dev = torch.device('cuda', 0)
 lib = _abi.get_plugin()
-assert lib.igan_conv_piece_form() == (2 if int(sys.argv[1]) else 0)         # nothing in the environment = the two-piece fp16 form (ABI v7)
-assert lib.igan_conv_pieces_wanted(3, 3, 256, 256) == int(sys.argv[1]) and lib.igan_conv_pieces_wanted(1, 1, 256, 256) == 0 and lib.igan_conv_pieces_wanted(3, 3, 64, 256) == 0
-assert lib.igan_pieces_image_ok(4, 1024, 256) == int(sys.argv[1]) and lib.igan_pieces_image_ok(1, 1024, 256) == 0 and lib.igan_pieces_image_ok(4, 1024, 144) == 0
+form = {'1': 2, 'bf16': 1, '0': 0}[sys.argv[1]]
+assert lib.igan_conv_piece_form() == form         # nothing in the environment = the two-piece fp16 form (ABI v7)
+assert lib.igan_conv_pieces_wanted(3, 3, 256, 256) == int(form != 0) and lib.igan_conv_pieces_wanted(1, 1, 256, 256) == 0 and lib.igan_conv_pieces_wanted(3, 3, 64, 256) == 0
+# ABI v8: only the bf16 form takes caller-written images (the fp16 form scales a tensor per pixel for one kernel and per channel for the other)
+assert lib.igan_pieces_image_ok(4, 1024, 256) == int(form == 1) and lib.igan_pieces_image_ok(1, 1024, 256) == 0 and lib.igan_pieces_image_ok(4, 1024, 144) == 0
 p = _abi.Conv2DParams(x=1 << 20, w=1 << 20, y=1 << 20, in_scale=None, out_scale=None, workspace=None, workspace_floats=0, N=4, H=32, W=32, Cin=256, OH=32, OW=32,
                       Cout=256, KH=3, KW=3, stride=1, up=1, pad_y=1, pad_x=1, w_transposed=0, splits=1, alpha=1.0, bias=None, act=0, act_alpha=0.0, act_gain=1.0)
 buf = ctypes.create_string_buffer(128)
@@ -209,7 +211,19 @@ err = float((y.double().cpu() - want).abs().max() / want.abs().max())
 assert err < 3e-6, err
 # an image that is not the image of this tensor is refused, never read (ABI v6)
 xp = hip_ops.to_pieces(x)
-if int(sys.argv[1]):
+if form == 2:
+    assert xp is None
+    fake = hip_ops.PieceImage(torch.zeros(x.numel() * 6 // 4, device=dev), x.numel() * 6)
+    for call, word in ((lambda: hip_ops.conv2d_raw(x, w, geom, (32, 32), 256, x_pieces=fake), 'x_pieces'),
+                       (lambda: hip_ops.conv2d_wgrad_raw(x, x, geom, dy_pieces=fake), 'dy_pieces')):
+        try:
+            call()
+        except Exception as e:
+            assert word in str(e), e
+        else:
+            raise AssertionError('the fp16 form accepted a caller-written image')
+    assert lib.igan_to_pieces(None, x.data_ptr(), None, fake.data_ptr(), 4, 1024, 256) == 3       # IGAN_ERR_UNSUPPORTED
+elif form == 1:
     assert xp is not None and xp.nbytes == x.numel() * 6
     y2 = hip_ops.conv2d_raw(x, w, geom, (32, 32), 256, x_pieces=xp)
     assert torch.equal(y, y2)
@@ -235,15 +249,15 @@ print('SWITCH-OK')
 '''
 
 
-@pytest.mark.parametrize('on', ['1', '0'], ids=['default_piece_form', 'exact_fp32'])
+@pytest.mark.parametrize('on', ['1', 'bf16', '0'], ids=['default_piece_form', 'bf16_piece_form', 'exact_fp32'])
 def test_switch_selects_the_form_and_piece_images_are_size_checked(cuda_device, on):
     """Default (nothing in the environment) = the piece form for the large 3x3 layers; IGAN_CONV_PLANES=0 = the fp32 instruction
     everywhere (the labelled second bench line).  The library, not the host, decides which tensors get an image
     (igan_conv_pieces_wanted / igan_pieces_image_ok), and it refuses an image whose byte size is not that of the tensor."""
     env = {k: v for k, v in os.environ.items() if k != 'IGAN_CONV_PLANES'}
-    if on == '0':
-        env['IGAN_CONV_PLANES'] = '0'
+    if on != '1':
+        env['IGAN_CONV_PLANES'] = {'0': '0', 'bf16': '1'}[on]
     r = subprocess.run([sys.executable, '-c', FP32_CHILD % ROOT, on], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'SWITCH-OK' in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
     kernel = [l for l in r.stdout.splitlines() if l.startswith('KERNEL ')][-1]
-    assert ('planes' in kernel) == (on == '1'), kernel
+    assert ('planes' in kernel) == (on != '0'), kernel
