@@ -38,11 +38,11 @@ F32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (about 6.3 TB/s achievable)
 BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense" (v_mfma_f32_32x32x16_bf16, 1024 FLOP/clk/SIMD)
 # matrix instructions per fp32 product in a piece form (csrc/conv2d_mfma.hip): 1 = three bf16 pieces: a0b0, a0b1, a1b0, a0b2, a1b1, a2b0;
-# 2 = two fp16 pieces with a per-tensor power-of-two scale: p0p0, p0p1, p1p0.  fp32-equivalent peak = 2500 / products (fp16 and bf16 MFMA run at the same rate)
+# 2 = two fp16 pieces under per-pixel / per-channel power-of-two scales (no per-tensor window: DESIGN.md section 4): p0p0, p0p1, p1p0.  fp32-equivalent peak = 2500 / products (fp16 and bf16 MFMA run at the same rate)
 PIECE_PRODUCTS_BY_FORM = {1: 6, 2: 3}
 PIECE_DTYPE = {0: 'f32',
                1: 'f32 (3x3 convs: exact 3-piece bf16 split, fp32 sums)',
-               2: 'f32 (3x3 convs: 2-piece fp16 split under a per-tensor power-of-two scale, fp32 sums)'}
+               2: 'f32-equivalent (3x3 convs: 2-piece fp16 split, operands to <= 1 ulp of fp32, scales per pixel / per channel: no per-tensor window; fp32 sums)'}
 
 
 def piece_form():
@@ -393,7 +393,7 @@ def cpu_baseline_subprocess(resolution, batch, lpips_weight, timeout_s=600):
 FORM_LABEL = {
     0: 'exact fp32: every convolution on v_mfma_f32_32x32x2_f32 (IGAN_CONV_PLANES=0); everything else as in the headline',
     1: '3x3 convolutions (forward, data gradient, weight gradient) as 3 bf16 pieces x 6 products with fp32 sums (IGAN_CONV_PLANES=1)',
-    2: '3x3 convolutions as 2 fp16 pieces x 3 products under a per-tensor power-of-two scale, fp32 sums (IGAN_CONV_PLANES=2)',
+    2: '3x3 convolutions as 2 fp16 pieces x 3 products under per-pixel / per-channel power-of-two scales, fp32 sums (IGAN_CONV_PLANES=2)',
 }
 FORM_KEY = {0: 'second_line_exact_fp32', 1: 'line_bf16_pieces', 2: 'line_fp16_pairs'}
 

@@ -88,6 +88,7 @@ struct ConvArgs {
     const float* noise;     // [N or 1, OH, OW] or nullptr; strength = *noise_strength (device scalar)
     const float* noise_strength;
     int noise_bcast;        // noise has one sample, shared by the batch
+    int diag_mode;              // IGAN_DIAGNOSTIC builds only (tools/coresidency_probe.py): bit mask of parts of conv_fwd_planes_kernel<2> to leave out; 0 in the product
     const unsigned short* xp;   // bf16-piece form (conv_fwd_planes_kernel): x * in_scale as [pixel][Cin/16][3 pieces][16] bf16
     const unsigned short* wp;   //   and the filter as [tap][n][Cin/16][3][16] (the orientation is resolved when it is written)
 };
@@ -1085,6 +1086,16 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(ConvArgs a, int BM, int
 // The reduction runs 16-channel slice outermost, taps inside (the taps of a slice re-read the same shifted rows: L2 hits).
 // Tile list, slicing, fix-up and the whole epilogue are those of conv_fwd_dma_kernel (same accumulator layout).
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+// Round 5 (the multi-process mismatch of round 4, root-caused): the piece kernels prefetch two chunks ahead, so their last two iterations issue LDS-DMA
+// instructions for chunks past the end of the reduction, and nobody waits for those.  A wave that ends with such an instruction in flight gives its LDS
+// back before the data has landed: when another workgroup is placed on that LDS meanwhile, the late write lands in ITS data.  Inside one process that
+// is harmless (the next workgroup there is a tile of the same kernel, whose own chunks land later in the same stages; a following kernel does not start
+// before the launch has drained), but beside OTHER processes' kernels it is not: with eight ranks on one GPU a 98 KB dense_small_kernel workgroup of
+// another rank fits beside / behind a 55 KB fp16 tile (not beside the 74 KB bf16 or fp32 tiles -- which is why only the fp16 form showed it), and its
+// staged x rows were overwritten: tools/r5_trace8b.sh shows the FIRST call of an op whose output differs between two eager executions to be the first
+// mapping-network layer, with identical inputs (profiles/r05_replay_mismatch.txt).  Every wave therefore waits for its own LDS-DMA before it leaves
+// the main loop -- the instructions were issued to addresses outside the operand (zeros) or to a harmless slice, they return within a few hundred cycles.
+__device__ __forceinline__ void drain_lds_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 constexpr int PK = 16;                          // reduction depth of a stage
 constexpr int P_IMG = 3 * 128 * 32;             // bytes of one operand image: [3 pieces][128 rows][32 B]
 constexpr int P_STAGE = 2 * P_IMG;              // A + B
@@ -1236,6 +1247,9 @@ __device__ __forceinline__ float inv_scale_from_amax(float amax) {
     return __uint_as_float((unsigned)(e - 14) << 23);
 }
 __device__ __forceinline__ void count_window(int below) {      // per wave: one atomic when anything is to be counted (diagnostic)
+#ifdef IGAN_NO_WINDOW_COUNT
+    return;
+#endif
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) below += __shfl_xor(below, o);
     if ((threadIdx.x & 63) == 0 && below != 0) atomicAdd(&g_f16_below_window, (unsigned long long)below);
@@ -1307,7 +1321,9 @@ __global__ __launch_bounds__(256) void rows_f16_kernel(const float* __restrict__
         below += (mine && vs != 0.0f && fabsf(vs) < 0x1p-12f) ? 1 : 0;
     }
     count_window(below);
+#ifndef IGAN_NO_WINDOW_COUNT
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_f16_imaged, (unsigned long long)total * 16ull);
+#endif
     store_units(pc, stage, out, total);
 }
 
@@ -1385,7 +1401,9 @@ __global__ __launch_bounds__(256) void cols_f16_kernel(const float* __restrict__
         below += (mine && vs != 0.0f && fabsf(vs) < 0x1p-12f) ? 1 : 0;
     }
     count_window(below);
+#ifndef IGAN_NO_WINDOW_COUNT
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_f16_imaged, (unsigned long long)total * 16ull);
+#endif
     store_units(pc, stage, out, total);
 }
 
@@ -1472,12 +1490,22 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
     constexpr int IMG = NP * 128 * 32, STAGE = 2 * IMG;       // one operand's LDS image [NP pieces][128 rows][32 B]; a stage = A + B
     constexpr unsigned PB = NP * 32u;                          // bytes of one (pixel, 16-channel slice) in a piece image
     constexpr int TABS = (NP == 2) ? 9 * BM * 4 : 0;           // fp16 form: 1 / S of the input pixel each (tap, tile row) reads (at most 3x3 taps)
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[P_NSTAGE * STAGE + 3 * BM * 4 + TABS];
+#ifndef IGAN_F16_LDS_PAD
+#define IGAN_F16_LDS_PAD 0
+#endif
+    constexpr int LPAD = (NP == 2) ? IGAN_F16_LDS_PAD : 0;     // experiment: pad the fp16 tile's LDS footprint (co-residency with other kernels)
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[P_NSTAGE * STAGE + 3 * BM * 4 + TABS + LPAD];
     int* row_pix = reinterpret_cast<int*>(smem + P_NSTAGE * STAGE);
     int* row_n = row_pix + BM;
     float* row_nz = reinterpret_cast<float*>(row_n + BM);
     float* tab_s = row_nz + BM;
 
+#ifdef IGAN_DIAGNOSTIC
+    const int dm = a.diag_mode;
+    if (dm & 4) return;
+#else
+    constexpr int dm = 0;
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: kept in a scalar register
     const int l31 = lane & 31, h = lane >> 5;
@@ -1581,12 +1609,20 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
     unsigned offA = OOB, soffB = 0u;
     typedef __attribute__((address_space(3))) void lds_void;
     unsigned char* dA = nullptr;
+    bool dma_fresh = true;
+    const unsigned sliceB = (unsigned)(a.KH * a.KW * a.Cout) * PB;          // bytes between two 16-channel slices of the filter image
     auto dma_prep = [&](int stage) {        // addresses of the next chunk, then one step forward in (slice, tap) order
-        const unsigned disp = (unsigned)(ld_ta * a.W + ld_tb) * pixA + (unsigned)ld_cc * PB;                      // scalar
-        const unsigned bit = 1u << (ld_ta * nkx + ld_tb);                                                           // scalar
-        offA = (maskA & bit) ? baseA + disp : OOB;
-        const int ky = ky0 + (ld_ta << a.up_shift), kx = kx0 + (ld_tb << a.up_shift);
-        soffB = (unsigned)((ld_cc * (a.KH * a.KW) + ky * a.KW + kx) * a.Cout) * PB;                               // scalar
+        if (!TAPO || dma_fresh || ld_cc == 0) {     // (wave-uniform) TAPO: a full decode at the first chunk and at every tap start only
+            const unsigned disp = (unsigned)(ld_ta * a.W + ld_tb) * pixA + (unsigned)ld_cc * PB;                      // scalar
+            const unsigned bit = 1u << (ld_ta * nkx + ld_tb);                                                           // scalar
+            offA = (maskA & bit) ? baseA + disp : OOB;
+            const int ky = ky0 + (ld_ta << a.up_shift), kx = kx0 + (ld_tb << a.up_shift);
+            soffB = __builtin_amdgcn_readfirstlane((unsigned)((ld_cc * (a.KH * a.KW) + ky * a.KW + kx) * a.Cout) * PB);      // scalar
+            dma_fresh = false;
+        } else {        // the next slice of the same tap: both operands one slice further (an out-of-range marker stays out of range: OOB + 64 Cin / 16 < 2^32)
+            offA += PB;
+            soffB = __builtin_amdgcn_readfirstlane(soffB + sliceB);       // wave-uniform: it is the instruction's scalar offset (left to itself the compiler keeps it in a vector register and wraps the DMA in a waterfall loop)
+        }
         dA = smem + stage * STAGE + (wave & 3) * 1024;
         if constexpr (TAPO) {
             ++ld_cc;
@@ -1612,12 +1648,13 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
         // an out-of-range offset stays out of range with the piece offset added
         // (the piece displacement rides in the scalar offset: the instruction's immediate offset would also move the LDS address)
         if constexpr (NP == 2) {        // 16 wave instructions per stage, two per wave: waves 0-3 A piece 0 and B piece 1, waves 4-7 A piece 1 and B piece 0
+            const unsigned sB = __builtin_amdgcn_readfirstlane(soffB);      // the instruction's SCALAR offset (wave-uniform by construction; said so, or the compiler wraps the DMA in a waterfall loop)
             if (lowave) {
                 if (j == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)A, 16, offA, 0, 0, 0);
-                if (j == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(B + 4096), 16, voffB, soffB + 32u, 0, 0);
+                if (j == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(B + 4096), 16, voffB, sB + 32u, 0, 0);
             } else {
                 if (j == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(A + 4096), 16, offA, 32, 0, 0);
-                if (j == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)B, 16, voffB, soffB, 0, 0);
+                if (j == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)B, 16, voffB, sB, 0, 0);
             }
         } else
         if (lowave) {
@@ -1660,11 +1697,11 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
             }
         }
     }
-    if (c_begin < c_end) { dma_chunk(0); dma_chunk(1); }
+    if ((c_begin < c_end) && !(dm & 32)) { dma_chunk(0); dma_chunk(1); }
     if constexpr (NP == 2) {
 #pragma unroll
         for (int j = 0; j < 3; j++)
-            if (tid + 512 * j < 9 * BM) tab_s[tid + 512 * j] = tabv[j];
+            if (tid + 512 * j < 9 * BM && !(dm & 64)) tab_s[tid + 512 * j] = tabv[j];
     }
     // the epilogue's row tables, computed while the first chunks are in flight
     if (tid < BM) {
@@ -1707,7 +1744,7 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
             for (int tm = 0; tm < TM; tm++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) u[tm][r] = 0.0f;
-            for (int c = c_begin; c < c_end; c++) {
+            for (int c = (dm & 8) ? c_end : c_begin; c < c_end; c++) {
                 asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // as below
                 const int nst = st >= 1 ? st - 1 : P_NSTAGE - 1;
                 const unsigned char* S = smem + st * STAGE;
@@ -1727,7 +1764,7 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
                 u[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1, a0[0], u[0], 0, 0, 0);
                 u[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1, a0[1], u[1], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                dma_piece(0); dma_piece(1);             // chunk c + 2, issued inside the matrix cluster
+                if (!(dm & 32)) { dma_piece(0); dma_piece(1); }            // chunk c + 2, issued inside the matrix cluster
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[0][r] = __builtin_fmaf(t[r], sc0, acc[0][r]);        // vector ALU: round to nearest
                 __builtin_amdgcn_sched_barrier(0);
@@ -1787,7 +1824,9 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
             st = (st + 1 == P_NSTAGE) ? 0 : st + 1;
         }
         }
+        drain_lds_dma();
         stamp(2);
+        if (dm & 16) return;
         // ---- epilogue of the transposed tile: every register quad is four consecutive output channels of the lane's pixel ----
         // 1 / S_n of the filter's columns (exact: a power of two), then as in conv_fwd_dma_kernel
         const float* winv = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.wp) + (size_t)a.KH * a.KW * a.Cin * a.Cout * 4);
@@ -1874,6 +1913,7 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
         st = (st + 1 == P_NSTAGE) ? 0 : st + 1;
     }
     }
+    drain_lds_dma();
     stamp(2);
     // ---- epilogue (as conv_fwd_dma_kernel) ----
     if (sliced && nsplit > 1) {
@@ -2464,6 +2504,7 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_planes_kernel(WgradArgs a) 
         for (int tm = 0; tm < TM; tm++) acc[tm] += t[tm];
         st = (st + 1 == P_NSTAGE) ? 0 : st + 1;
     }
+    drain_lds_dma();
     // epilogue: rows = input channels, columns = output channels (contiguous across lanes)
     const size_t wsize = (size_t)a.KH * a.KW * a.Cin * a.Cout;
     float* out = a.out + (a.splits > 1 ? (size_t)split * wsize : (size_t)0) + (size_t)tap * a.Cin * a.Cout;
@@ -2694,6 +2735,20 @@ bool planes_shape_ok(const igan_conv2d_params* p, const FwdTile& t, int Mmax) {
     // fp16 form: the pixel's scale is shared by shuffles among the Cin / 16 threads of a pixel (a power of two within one wave), the kernel's scale
     // table holds nine taps, and the transposed tile stores four output channels per lane and register quad
     if (planes_mode() == 2 && (!pow2(p->Cin / PK) || p->Cin / PK > 64 || p->KH * p->KW > 9 || p->Cout % 4 != 0)) return false;
+#ifdef IGAN_DIAGNOSTIC      // bisecting by layer class (variant builds only: make variant VARIANT=diag DEFS=-DIGAN_DIAGNOSTIC)
+    {
+        static const int only_cin = getenv("IGAN_PLANES_ONLY_CIN") ? atoi(getenv("IGAN_PLANES_ONLY_CIN")) : 0;
+        static const int no_act = getenv("IGAN_PLANES_NO_ACT") ? atoi(getenv("IGAN_PLANES_NO_ACT")) : 0;            // 1: not with a fused epilogue; 2: only with one
+        static const int no_scale = getenv("IGAN_PLANES_NO_SCALE") ? atoi(getenv("IGAN_PLANES_NO_SCALE")) : 0;      // 1: not modulated; 2: only modulated
+        static const int kind = getenv("IGAN_PLANES_KIND") ? atoi(getenv("IGAN_PLANES_KIND")) : 0;                  // 1: stride 1 / up 1 only; 2: stride 2 only; 3: up 2 only
+        static const int wt = getenv("IGAN_PLANES_WT") ? atoi(getenv("IGAN_PLANES_WT")) : 0;                        // 1: forward calls only; 2: data gradients only
+        if (only_cin && p->Cin != only_cin) return false;
+        if ((no_act == 1 && p->act != 0) || (no_act == 2 && p->act == 0)) return false;
+        if ((no_scale == 1 && p->in_scale != nullptr) || (no_scale == 2 && p->in_scale == nullptr)) return false;
+        if ((kind == 1 && (p->stride != 1 || p->up != 1)) || (kind == 2 && p->stride != 2) || (kind == 3 && p->up != 2)) return false;
+        if ((wt == 1 && p->w_transposed) || (wt == 2 && !p->w_transposed)) return false;
+    }
+#endif
     return true;
 }
 bool use_planes_kernel(const igan_conv2d_params* p, const FwdTile& t, int Mmax) {
@@ -2893,6 +2948,10 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
     a.bias = p->bias; a.act = p->act; a.act_alpha = p->act_alpha; a.act_gain = p->act_gain;
     a.noise = p->act ? p->noise : nullptr; a.noise_strength = p->noise_strength; a.noise_bcast = p->noise_bcast;
     a.xp = nullptr; a.wp = nullptr;
+    a.diag_mode = 0;
+#ifdef IGAN_DIAGNOSTIC
+    a.diag_mode = getenv("IGAN_DIAG_MODE") ? atoi(getenv("IGAN_DIAG_MODE")) : 0;
+#endif
 
     dim3 grid(a.full_tiles + (l.T - a.full_tiles) * splits);
     const bool wt = p->w_transposed != 0;
@@ -2906,14 +2965,16 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
         const int cpp = p->Cin / PK;
         if (xp == nullptr) {         // no image from the caller: write it behind the partial tiles
             unsigned short* own = reinterpret_cast<unsigned short*>(p->workspace + partial_floats);
-            if (planes_mode() == 2) launch_row_image(stream, p->x, p->in_scale, own, p->N * p->H * p->W, p->H * p->W, p->Cin);
+            if (a.diag_mode & 1) {}      // DIAGNOSTIC: stale image
+            else if (planes_mode() == 2) launch_row_image(stream, p->x, p->in_scale, own, p->N * p->H * p->W, p->H * p->W, p->Cin);
             else launch_piece_image(stream, p->x, p->in_scale, own, p->N * p->H * p->W, p->H * p->W, p->Cin);
             xp = own;
         }
-        launch_filter_image(stream, p->w, wp, wt, p->KH * p->KW, p->KW, p->Cout, p->Cin);
+        if (!(a.diag_mode & 1)) launch_filter_image(stream, p->w, wp, wt, p->KH * p->KW, p->KW, p->Cout, p->Cin);
         a.xp = xp; a.wp = wp;
         a.cpt = cpp;
-        if (planes_mode() == 2) {
+        if (a.diag_mode & 2) {}          // DIAGNOSTIC: image kernels only
+        else if (planes_mode() == 2) {
             // reduction order of the fp16 form (see the kernel): tap outermost (the cross terms are folded once per tap); A/B switch IGAN_F16_TAP_OUTER=0:
             // slice outermost, every step folds its cross terms.  Measured (profiles/r05_f16_rowscale.txt): kernel 490.6 -> 457.2 us on G 128 Conv1
             // (Cin 128), 451.4 -> 428.0 us on G 32 Conv1 (Cin 512); whole layer list forward 186.0 -> 194.4, data gradient 189.2 -> 198.0 TFLOP/s.
@@ -3040,6 +3101,7 @@ int wgrad_splits(const igan_conv2d_wgrad_params* p) {
 bool wgrad_planes_shape_ok(const igan_conv2d_wgrad_params* p) {
     static const bool wg = !(getenv("IGAN_WGRAD_PLANES") && atoi(getenv("IGAN_WGRAD_PLANES")) == 0);      // A/B switch inside the piece form
     if (!planes_enabled() || !wg || p->KH * p->KW == 1 || p->Cin < 128 || p->Cout < 128 || p->Cin % 32 != 0 || p->Cout % 32 != 0) return false;
+#ifdef IGAN_DIAGNOSTIC
     {   // DIAGNOSTIC ONLY (bisecting by layer class): IGAN_WGRAD_PLANES_CIN=<n> keeps the piece form for weight gradients with Cin == n only,
         // IGAN_WGRAD_PLANES_KIND=plain|stride|up for stride 1 without up-sampling / stride 2 / up 2 only
         static const int only_cin = getenv("IGAN_WGRAD_PLANES_CIN") ? atoi(getenv("IGAN_WGRAD_PLANES_CIN")) : 0;
@@ -3049,6 +3111,7 @@ bool wgrad_planes_shape_ok(const igan_conv2d_wgrad_params* p) {
         if (kind && kind[0] == 's' && p->stride != 2) return false;
         if (kind && kind[0] == 'u' && p->up != 2) return false;
     }
+#endif
     if ((long long)p->N * p->OH * p->OW < 2048 * (long long)p->up * p->up) return false;
     if ((long long)p->N * p->H * p->W * p->Cin * 6 >= 0x7FFFFF00LL || (long long)p->N * p->OH * p->OW * p->Cout * 6 >= 0x7FFFFF00LL) return false;
     // fp16 form: the column-maximum pass gives every thread one channel quad (C / 4 a power of two <= 256)

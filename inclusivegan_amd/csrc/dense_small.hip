@@ -57,6 +57,19 @@ __global__ __launch_bounds__(256) void dense_small_kernel(DenseGroups G) {
     const bool jok = j < N;
     const float* __restrict__ w = a.w;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    // Round 5: every guarded load goes through a buffer descriptor (an out-of-range offset returns 0).  Written as `ok ? *p : zero` the compiler selected
+    // between the ADDRESSES -- the global one and that of a copy of `zero` in scratch -- and issued a flat load: every instantiation carried 32 bytes of
+    // scratch per lane and a flat path into it for no reason (profiles/r05_replay_mismatch.txt).
+    constexpr unsigned OOB = 0x7FFFFFF0u;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)(((unsigned)(M - 1) * (unsigned)a.ldx + (unsigned)K) * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x2 ? a.x2 : a.x), 0, a.x2 ? (int)((unsigned)M * (unsigned)K * 4u) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w), 0, (int)((unsigned)N * (unsigned)K * 4u), 0x00020000);
+    typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+    auto ld4 = [](__amdgpu_buffer_rsrc_t r, unsigned off) {
+        const u32x4_ v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    };
+    auto ld1 = [](__amdgpu_buffer_rsrc_t r, unsigned off) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0)); };
     float acc[MB];
 #pragma unroll
     for (int m = 0; m < MB; m++) acc[m] = 0.f;
@@ -67,13 +80,19 @@ __global__ __launch_bounds__(256) void dense_small_kernel(DenseGroups G) {
 #pragma unroll
         for (int it = 0; it < DS_NIT; it++) {
             const int k = k0 + (it * DS_GROUPS + g) * 4;
-            wv[it] = zero;
-            if (jok && k < K) {
-                if constexpr (WT) wv[it] = *reinterpret_cast<const float4*>(w + (size_t)j * K + k);
-                else {
-                    wv[it].x = w[(size_t)(k + 0) * N + j]; wv[it].y = w[(size_t)(k + 1) * N + j];
-                    wv[it].z = w[(size_t)(k + 2) * N + j]; wv[it].w = w[(size_t)(k + 3) * N + j];
-                }
+            const bool wok = jok && k < K;
+#ifndef IGAN_DENSE_WT_B128     // Round 5: the transposed form's weights as four 4-byte loads instead of one 16-byte load -- see the note at the top of the kernel
+            if constexpr (WT) {
+                const unsigned o = wok ? ((unsigned)j * (unsigned)K + (unsigned)k) * 4u : OOB;
+                wv[it].x = ld1(rw, o); wv[it].y = ld1(rw, o + 4u); wv[it].z = ld1(rw, o + 8u); wv[it].w = ld1(rw, o + 12u);
+            }
+#else
+            if constexpr (WT) wv[it] = ld4(rw, wok ? ((unsigned)j * (unsigned)K + (unsigned)k) * 4u : OOB);
+#endif
+            else {
+                const unsigned o = wok ? ((unsigned)k * (unsigned)N + (unsigned)j) * 4u : OOB;      // OOB + 3 N * 4 stays out of range (N * K * 4 < 2^31)
+                wv[it].x = ld1(rw, o); wv[it].y = ld1(rw, o + (unsigned)N * 4u);
+                wv[it].z = ld1(rw, o + (unsigned)N * 8u); wv[it].w = ld1(rw, o + (unsigned)N * 12u);
             }
         }
         // x super-tile [MB][DS_KS], prologue applied, rows >= M and columns >= K zero
@@ -84,8 +103,8 @@ __global__ __launch_bounds__(256) void dense_small_kernel(DenseGroups G) {
             const int m = v / (DS_KS / 4), kv = v - m * (DS_KS / 4);
             const int k = k0 + 4 * kv;
             const bool ok = (m < M) && (k < K);
-            xv[q] = ok ? *reinterpret_cast<const float4*>(a.x + (size_t)m * a.ldx + k) : zero;
-            xu[q] = (ok && a.prologue == IGAN_DENSE_PRO_DEMOD_GRAD) ? *reinterpret_cast<const float4*>(a.x2 + (size_t)m * K + k) : zero;
+            xv[q] = ld4(rx, ok ? ((unsigned)m * (unsigned)a.ldx + (unsigned)k) * 4u : OOB);
+            xu[q] = ld4(rx2, (ok && a.prologue == IGAN_DENSE_PRO_DEMOD_GRAD) ? ((unsigned)m * (unsigned)K + (unsigned)k) * 4u : OOB);
         }
         if (k0 > 0) __syncthreads();         // the previous super-tile's readers are done with xs
 #pragma unroll

@@ -49,6 +49,66 @@ def _one_stream():
     return os.environ.get('IGAN_GRAPH_ONE_STREAM', '1') != '0'      # A/B switch (0 = warm up on the default stream, capture on torch's own side stream)
 
 
+_trace_log = None
+_trace_saved = {}
+
+
+def _trace_begin():
+    """DIAGNOSTIC: wrap forward / backward of every autograd Function of hip_ops so that each tensor output leaves (label, [sum, sum of squares] in fp64, kept on
+    the device: no host synchronisation) in a list."""
+    global _trace_log
+    from ... import hip_ops
+    _trace_log = []
+    log = _trace_log
+
+    def wrap(cls, which):
+        fn = getattr(cls, which)
+        def wrapped(*args, **kw):
+            for j, t in enumerate(args):            # the inputs too: is it the kernel or what it was given?
+                if isinstance(t, torch.Tensor) and t.is_cuda and t.is_floating_point() and t.numel() > 0:
+                    d = t.detach().double()
+                    log.append(('%s.%s in[%d] %s' % (cls.__name__, which, j, tuple(t.shape)), torch.stack([d.sum(), (d * d).sum()])))
+            out = fn(*args, **kw)
+            outs = out if isinstance(out, (tuple, list)) else (out,)
+            for j, t in enumerate(outs):
+                if isinstance(t, torch.Tensor) and t.is_cuda and t.is_floating_point() and t.numel() > 0:
+                    d = t.detach().double()
+                    log.append(('%s.%s[%d] %s' % (cls.__name__, which, j, tuple(t.shape)), torch.stack([d.sum(), (d * d).sum()])))
+            return out
+        return staticmethod(wrapped)
+
+    src = tfutil.random_source()            # every random draw of the op
+    for meth in ('normal', 'uniform', 'normal_many'):
+        fn0 = getattr(src, meth)
+        def drawn(*args, _fn=fn0, _m=meth, **kw):
+            out = _fn(*args, **kw)
+            for t in (out if isinstance(out, (tuple, list)) else (out,)):
+                d = t.detach().double()
+                log.append(('draw %s %s' % (_m, tuple(t.shape)), torch.stack([d.sum(), (d * d).sum()])))
+            return out
+        _trace_saved[(src, meth)] = fn0
+        setattr(src, meth, drawn)
+    for name in dir(hip_ops):
+        cls = getattr(hip_ops, name)
+        if isinstance(cls, type) and issubclass(cls, torch.autograd.Function) and cls is not torch.autograd.Function:
+            _trace_saved[cls] = (cls.__dict__['forward'], cls.__dict__['backward'])
+            cls.forward = wrap(cls, 'forward')
+            cls.backward = wrap(cls, 'backward')
+    return log
+
+
+def _trace_end():
+    for key, val in _trace_saved.items():
+        if isinstance(key, tuple):
+            try:
+                delattr(key[0], key[1])        # the instance attribute that shadowed the class's method
+            except AttributeError:
+                pass
+        else:
+            key.forward, key.backward = val
+    _trace_saved.clear()
+
+
 class GraphedStep:
     _pool = None
     _stream = None
@@ -112,14 +172,19 @@ class GraphedStep:
             if other.graph is not None:
                 other.graph.replay()
         reset()
+        trace = os.environ.get('IGAN_GRAPH_CHECK_TRACE') == '1'       # DIAGNOSTIC (with EAGER_TWICE): a device-side checksum of every output of every hip_ops Function, both executions; the first ones that differ are printed
         if os.environ.get('IGAN_GRAPH_CHECK_EAGER_TWICE') == '1':      # DIAGNOSTIC: compare two EAGER executions instead (is the op itself reproducible here?)
+            log_a = _trace_begin() if trace else None
             a = snapshot(self._run_fn())
+            if trace:
+                _trace_end()
         else:
             self.graph.replay()
             a = snapshot(self.out)
         reset()
         src = tfutil.random_source()
         tapped = src.by_op.get(self.name) if hasattr(src, 'by_op') else None     # a TapRandom must keep pointing at the GRAPH's draws
+        log_b = _trace_begin() if (trace and os.environ.get('IGAN_GRAPH_CHECK_EAGER_TWICE') == '1') else None
         if _one_stream():       # the eager side runs where the warm-up calls and the capture ran (see side_stream)
             side, cur = GraphedStep.side_stream(), torch.cuda.current_stream()
             side.wait_stream(cur)
@@ -128,15 +193,29 @@ class GraphedStep:
             cur.wait_stream(side)
         else:
             b = snapshot(self._run_fn())
+        if log_b is not None:
+            _trace_end()
+            torch.cuda.synchronize()
+            shown = 0
+            for k, ((la, ta), (lb, tb)) in enumerate(zip(log_a, log_b)):
+                if la != lb or not torch.equal(ta, tb):
+                    print('TRACE-DIFF op %s call %d of %d: %s | %s: checksums %s vs %s' % (self.name, k, len(log_a), la, lb, ta.tolist(), tb.tolist()), flush=True)
+                    shown += 1
+                    if shown >= 6:
+                        break
         if tapped is not None:
             src.by_op[self.name] = tapped
         reset()
         torch.cuda.synchronize()
         bad = []
+        self.last_diff = []         # DIAGNOSTIC (IGAN_GRAPH_CHECK_VERBOSE=1): (index, flat positions that differ, replayed values, eager values) of the disagreeing tensors
         for i, (x, y) in enumerate(zip(a, b)):
             same = (x == y) | (torch.isnan(x) & torch.isnan(y)) if x.dtype.is_floating_point else (x == y)
             if x.shape != y.shape or not bool(same.all()):
                 bad.append((i, float((x.double() - y.double()).abs().nan_to_num(nan=float('inf')).max()) if x.shape == y.shape else float('inf')))
+                if os.environ.get('IGAN_GRAPH_CHECK_VERBOSE') == '1' and x.shape == y.shape:
+                    pos = (~same).reshape(-1).nonzero().reshape(-1)
+                    self.last_diff.append((i, pos.cpu(), x.reshape(-1)[pos].cpu(), y.reshape(-1)[pos].cpu()))
         return bad
 
     def __call__(self):

@@ -590,6 +590,18 @@ def training_loop(
                 ok = False
                 print('WARNING: hipGraph of training op %r does not reproduce its eager execution (%s; tensor index, max |diff|: %s); '
                       'running this op eagerly' % (step.name, reason, bad), flush=True)
+                for i, pos, xa, xb in getattr(step, 'last_diff', []):          # DIAGNOSTIC (IGAN_GRAPH_CHECK_VERBOSE=1): which variables' gradients differ
+                    if i == 1:
+                        names = {}
+                        for vn, (o, c) in net._offsets.items():
+                            sel = (pos >= o) & (pos < o + c)
+                            if bool(sel.any()):
+                                rel = ((xa[sel].double() - xb[sel].double()).abs().max() / xb[sel].double().abs().max().clamp_min(1e-300)).item()
+                                names[vn] = (int(sel.sum()), int(c), float('%.2e' % rel))
+                        print('REPLAY-DIFF rank %d op %s gradient bucket: %d of %d elements differ; by variable (differing, size, max diff / max |value|): %s' % (
+                            rank, step.name, pos.numel(), net.flat_grads.numel(), names), flush=True)
+                    else:
+                        print('REPLAY-DIFF rank %d op %s tensor %d: %d elements differ: replay %s eager %s' % (rank, step.name, i, pos.numel(), xa[:6].tolist(), xb[:6].tolist()), flush=True)
                 if os.environ.get('IGAN_GRAPH_STRESS') != '1':     # stress runs (bench.py --revalidate-every) keep checking the op instead of retiring its graph
                     step.enabled = False
         graph_checks.append(dict(when=reason, faithful=ok))

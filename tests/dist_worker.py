@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-RES, FMAP, B = 32, 512, 3
+RES, FMAP, B = int(os.environ.get('IGAN_TEST_RES', '32')), int(os.environ.get('IGAN_TEST_FMAP', '512')), 3
 
 
 def build(dev):
@@ -70,6 +70,37 @@ def mode_exchange(rank, world, outdir):
     ex = G_opt._state['exchange']
     torch.save(dict(G=G.flat_params.cpu(), D=D.flat_params.cpu(), g_avg=g_avg.cpu(), d_avg=d_avg.cpu(),
                     chunks=[int(c.numel()) for c in ex.chunks]), os.path.join(outdir, 'rank%d.pt' % rank))
+
+
+def mode_nonfinite(rank, world, outdir):
+    """The finite gate AFTER the exchange (dnnlib/tflib/optimizer.py:237 of the reference: `tf.reduce_all(tf.is_finite(g))` on the summed gradients):
+    rank 1's D loss is multiplied by inf, rank 0's is finite -- the averaged bucket is non-finite on BOTH ranks, NOBODY updates (weights, Adam
+    moments and beta powers untouched, one overflow counted on each rank); the next, finite step updates both ranks identically."""
+    from inclusivegan_amd.training.dataset import SyntheticDataset
+    from inclusivegan_amd.training import loss as PL
+    dev = torch.device('cuda', 0)
+    G, D, lp, G_opt, D_opt = build(dev)
+    ts = SyntheticDataset(resolution=RES, label_size=0, data_size=24, device=dev)
+    inp = rank_inputs(rank, dev)
+    lab = torch.zeros(2 * B, 0, device=dev)
+    rec = {}
+    D_opt._bind(D)        # the Adam slots exist from here on
+    for step, poison in (('poisoned', rank == 1), ('clean', False)):
+        before = D.flat_params.clone()
+        st0 = {k: D_opt._state[k].clone() for k in ('m', 'v', 'pow')}
+        torch.manual_seed(700 + rank)
+        G.requires_grad_(False)
+        loss, _ = PL.D_logistic_r1(G, D, ts, B, inp['reals'], lab, gamma=100, phase='loss')
+        G.requires_grad_(True)
+        l = torch.mean(loss) * (float('inf') if poison else 1.0)
+        D_opt.differentiate(l, D, overlap_exchange=True)
+        rec[step + '_bucket_finite'] = bool(torch.isfinite(D.flat_grads).all())
+        D_opt.mark_registered(D); D_opt.apply_updates()
+        rec[step + '_moved'] = not torch.equal(before, D.flat_params)
+        rec[step + '_state_moved'] = any(not torch.equal(st0[k], D_opt._state[k]) for k in st0)
+        rec[step + '_overflows'] = D_opt.overflow_count()
+        rec[step + '_params'] = D.flat_params.cpu()
+    torch.save(rec, os.path.join(outdir, 'rank%d.pt' % rank))
 
 
 def mode_loop(rank, world, outdir):
@@ -158,7 +189,7 @@ def main():
     torch.cuda.set_device(0)
     if world > 1:
         torch.distributed.init_process_group('gloo', rank=rank, world_size=world)
-    {'exchange': mode_exchange, 'loop': mode_loop, 'record': mode_record, 'record5': mode_record5, 'config5': mode_config5}[mode](rank, world, outdir)
+    {'exchange': mode_exchange, 'nonfinite': mode_nonfinite, 'loop': mode_loop, 'record': mode_record, 'record5': mode_record5, 'config5': mode_config5}[mode](rank, world, outdir)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -10,7 +10,7 @@ gradient bucket and the weights to the host.  The oracle then evaluates THE SAME
     loss value of the op                       2e-4 relative (regularisers 1e-3: built from fp32 gradients)
     gradient bucket after the op               5e-3 relative L2 per variable (lrelu kinks, see tests/test_gpu_networks.py)
     weights after the op                       == oracle SimpleAdam applied to the HIP gradient, 1e-6 relative
-    pl_mean, dlatent_avg, Gs, beta powers      3e-4 / 1e-5 / 1e-6 / 1e-6
+    pl_mean, dlatent_avg, Gs, beta powers      1e-4 / 1e-5 / 1e-6 / 1e-6
 
 Why not a free-running comparison over 20 iterations: with beta1 = 0 the first Adam steps move every weight by
 +-lr whatever the size of its gradient, so a gradient element whose fp32 value has the other sign than its fp64 twin
@@ -203,6 +203,10 @@ class TeacherForcedOracle:
                     continue
                 e = float(np.linalg.norm(gh - go) / np.linalg.norm(go))
                 self.worst['grad'] = max(self.worst['grad'], e)
+                if os.environ.get('IGAN_TEST_GRAD_REPORT') == '1':      # DIAGNOSTIC: list the largest per-variable deviations instead of stopping at the first
+                    self.report = sorted(getattr(self, 'report', []) + [(e, name, it, vn)], reverse=True)[:8]
+                    print('GRAD-REPORT', self.report[:4], flush=True)
+                    continue
                 assert e < 5e-3, (self.j, name, it, vn, e)
             if scal_o:
                 e = float(np.linalg.norm(np.concatenate(scal_h) - np.concatenate(scal_o)) / (np.linalg.norm(np.concatenate(scal_o)) + 1e-30))
@@ -212,7 +216,7 @@ class TeacherForcedOracle:
                     self.worst['pl_mean'] = max(self.worst['pl_mean'], abs(rec['pl_mean'] - float(ops.state[r]['pl_mean'])) / (abs(rec['pl_mean']) + 1e-30))
                     # 3e-4: the path-length VALUE itself sits 1.3e-4 from the fp64 oracle at 128x128 under every convolution form, the exact-fp32 instruction included
                     # (profiles/r04_f16_pairs_variant.txt section 9); config 5 at minibatch 3 read 4.9e-6 (bf16 x3) and 1.0e-4 (fp16 x2)
-                    assert abs(rec['pl_mean'] - float(ops.state[r]['pl_mean'])) <= 3e-4 * abs(rec['pl_mean']) + 1e-8, (self.j, rec['pl_mean'], float(ops.state[r]['pl_mean']))
+                    assert abs(rec['pl_mean'] - float(ops.state[r]['pl_mean'])) <= 1e-4 * abs(rec['pl_mean']) + 1e-8, (self.j, rec['pl_mean'], float(ops.state[r]['pl_mean']))
                 if name != 'D_reg':
                     assert rel_err(rec['dlatent_avg'], ops.state[r]['dlatent_avg'].numpy()) < 1e-5, (self.j, name, 'dlatent_avg')
             self.evaluated.append((self.j, name, it))

@@ -10,8 +10,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
-PIECE_FORM = os.environ.get('IGAN_CONV_PLANES', '1') != '0'      # the large 3x3 layers run in the bf16-piece form by default
-PEAK = 2500.0 / 6 if PIECE_FORM else 157.3                       # fp32-equivalent TFLOP/s: bf16 dense peak / 6 piece products, or the f32 matrix peak
+_FORM = {'0': 0, '1': 1}.get(os.environ.get('IGAN_CONV_PLANES', '2'), 2)      # as csrc/conv2d_mfma.hip planes_mode(): unset or 2 = two fp16 pieces (the default), 1 = three bf16 pieces, 0 = none
+PIECE_FORM = _FORM != 0
+# fp32-equivalent TFLOP/s each form is priced against (the same figures bench.py uses): the fp16 / bf16 dense peak over the form's piece products
+# per fp32 product -- 3 for the two-piece fp16 form, 6 for the three-piece bf16 form -- or the f32 matrix peak
+PEAK = {0: 157.3, 1: 2500.0 / 6, 2: 2500.0 / 3}[_FORM]
 PIECE_PEAK = PEAK
 
 from inclusivegan_amd import hip_ops  # noqa: E402

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Single-kernel microbenchmarks for roofline evidence (run bare, or under rocprofv3 --pmc ...).
-  python tools/kernel_bench.py conv     [batch] [reps]   modulated conv 128x128 (north-star GEMM shape) -> TFLOP/s vs the form's peak (416.7 fp32-equivalent for the default bf16-piece form, 157.3 with IGAN_CONV_PLANES=0)
+  python tools/kernel_bench.py conv     [batch] [reps]   modulated conv 128x128 (north-star GEMM shape) -> TFLOP/s vs the form's peak (833.3 fp32-equivalent for the default two-piece fp16 form, 416.7 with IGAN_CONV_PLANES=1, 157.3 with =0)
   python tools/kernel_bench.py upfirdn  [batch] [reps]   the three upfirdn2d call sites at 128x128     -> GB/s vs 8 TB/s
   python tools/kernel_bench.py epilogue [batch] [reps]   fused noise+bias+lrelu forward / backward      -> GB/s
 Algorithmic bytes = (numel_in + numel_out) * 4."""
@@ -12,8 +12,11 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-PIECE_FORM = os.environ.get('IGAN_CONV_PLANES', '1') != '0'      # the large 3x3 layers run in the bf16-piece form by default
-PEAK = 2500.0 / 6 if PIECE_FORM else 157.3                       # fp32-equivalent TFLOP/s: bf16 dense peak / 6 piece products, or the f32 matrix peak
+_FORM = {'0': 0, '1': 1}.get(os.environ.get('IGAN_CONV_PLANES', '2'), 2)      # as csrc/conv2d_mfma.hip planes_mode(): unset or 2 = two fp16 pieces (the default), 1 = three bf16 pieces, 0 = none
+PIECE_FORM = _FORM != 0
+# fp32-equivalent TFLOP/s each form is priced against (the same figures bench.py uses): the fp16 / bf16 dense peak over the form's piece products
+# per fp32 product -- 3 for the two-piece fp16 form, 6 for the three-piece bf16 form -- or the f32 matrix peak
+PEAK = {0: 157.3, 1: 2500.0 / 6, 2: 2500.0 / 3}[_FORM]
 PIECE_PEAK = PEAK
 
 from inclusivegan_amd import hip_ops  # noqa: E402

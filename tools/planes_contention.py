@@ -19,7 +19,7 @@ def child(rounds):
     import torch
     from inclusivegan_amd import hip_ops
     dev = torch.device('cuda', 0)
-    g = torch.Generator().manual_seed(5)
+    g = torch.Generator().manual_seed(5 + int(os.environ.get('CONTENTION_SEED', '0')))       # CONTENTION_DIFFERENT_DATA=1: every child its own data (same shapes, same addresses)
 
     def dig(t):
         return hashlib.sha1(t.detach().float().cpu().contiguous().numpy().tobytes()).hexdigest()[:12]
@@ -36,6 +36,8 @@ def child(rounds):
         cases.append((name, x, w, s, d, dy, hip_ops.ConvGeom(3, 3, stride, up, pad, pad), out, H, Cin, Cout))
     first = {}
     bad = {}
+    keep = {}
+    shown = []
     for r in range(rounds):
         for name, x, w, s, d, dy, geom, out, H, Cin, Cout in cases:
             xp = hip_ops.to_pieces(x, s)
@@ -49,10 +51,19 @@ def child(rounds):
                 h = dig(t)
                 if k not in first:
                     first[k] = h
+                    keep[k] = t.detach().clone()
                 elif first[k] != h:
                     bad[k] = bad.get(k, 0) + 1
+                    if len(shown) < 12:         # where and how large: bounding box of the differing elements in the logical [N, C, H, W] (or [KH, KW, Cin, Cout]) index space
+                        df = (t.detach() != keep[k])
+                        idx = df.nonzero()
+                        rel = float((t.detach().double() - keep[k].double()).abs().max() / keep[k].double().abs().max())
+                        shown.append('%s %s round %d: %d of %d elements differ, max diff / max |value| %.2e, index box lo %s hi %s' % (
+                            name, what, r, idx.shape[0], t.numel(), rel, idx.min(0).values.tolist(), idx.max(0).values.tolist()))
     print('FIRST ' + ' '.join('%s' % first[k] for k in sorted(first)))
     print('BAD %d %s' % (sum(bad.values()), sorted(bad.items())))
+    for line in shown:
+        print('DIFF ' + line)
 
 
 def child_graphs(rounds):
@@ -123,7 +134,9 @@ if __name__ == '__main__':
         sys.exit(0)
     procs = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 30
-    ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--child', str(rounds)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(procs)]
+    diff = os.environ.get('CONTENTION_DIFFERENT_DATA') == '1'
+    ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--child', str(rounds)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
+                           env=dict(os.environ, CONTENTION_SEED=str(i if diff else 0))) for i in range(procs)]
     outs = [p.communicate(timeout=1500)[0] for p in ps]
     firsts = set()
     for i, o in enumerate(outs):
@@ -132,4 +145,7 @@ if __name__ == '__main__':
         b = [ln for ln in lines if ln.startswith('BAD ')]
         firsts.add(f[0] if f else 'missing')
         print('child %d: %s' % (i, b[0] if b else 'no output'))
+        for ln in lines:
+            if ln.startswith('DIFF '):
+                print('    ' + ln)
     print('form %s, %d processes x %d rounds: children agree on the first round: %s' % (os.environ.get('IGAN_CONV_PLANES', 'default'), procs, rounds, len(firsts) == 1))
