@@ -588,12 +588,16 @@ def main():
         period = data_size * 10
         out['amortised_img_s'] = round(period / (period / out['value'] + state['refresh'][0]), 3)
     if piece_form() == 2:
-        # how often the two-piece fp16 form met an element outside the window in which its two pieces hold the operand to 2^-23 (more than 2^26 below its tensor's largest)
+        # how often the two-piece fp16 form met an element outside the window in which its two pieces hold the operand to 2^-23: more than 2^26 below the largest of its
+        # OWN scale group (round 5: a pixel's channel vector in the row images of the forward / data-gradient kernel; a channel's pixels -- the summed axis -- in the
+        # column images of the weight gradient; never a whole tensor)
         import ctypes
-        below, imaged = ctypes.c_ulonglong(0), ctypes.c_ulonglong(0)
-        _abi.check(_abi.get_plugin().igan_debug_f16_window(ctypes.byref(below), ctypes.byref(imaged), 0))
-        out['fp16_pairs_window'] = {'elements_imaged': imaged.value, 'nonzero_elements_below_exact_window': below.value,
-                                    'fraction': (below.value / imaged.value) if imaged.value else 0.0}
+        v = (ctypes.c_ulonglong * 4)()
+        _abi.check(_abi.get_plugin().igan_debug_f16_window_by_kind(v, 0))
+        frac = lambda b, n: (b / n) if n else 0.0
+        out['fp16_pairs_window'] = {'elements_imaged': v[1] + v[3], 'nonzero_elements_below_exact_window': v[0] + v[2], 'fraction': frac(v[0] + v[2], v[1] + v[3]),
+                                    'row_images': {'imaged': v[1], 'below': v[0], 'fraction': frac(v[0], v[1]), 'scale_group': 'pixel (channel vector)'},
+                                    'column_images': {'imaged': v[3], 'below': v[2], 'fraction': frac(v[2], v[3]), 'scale_group': 'channel (its pixels: the summed axis)'}}
     if args.op_times:
         torch.cuda.synchronize()
         out['op_ms'] = {k: round(sum(a.elapsed_time(b) for a, b in v[2:]) / max(len(v) - 2, 1), 3) for k, v in state['op_times'].items()}

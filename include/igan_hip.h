@@ -274,6 +274,10 @@ int igan_conv_piece_form(void);
 /* Diagnostic for form 2 (synchronises the device): non-zero elements imaged so far BELOW the exact window (|v S| < 2^-12: more than 2^26 below the
  * largest magnitude of the element's own scale group) and elements imaged in all; reset != 0 zeroes both counters. */
 int igan_debug_f16_window(unsigned long long* below, unsigned long long* imaged, int reset);
+/* ABI v8: the same counters by kind of image, out4 = {rows below, rows imaged, columns below, columns imaged}: a ROW image (forward / data gradient) scales a
+ * pixel's channel vector, a COLUMN image (weight gradient) a channel's pixels -- there the group runs along the summed axis, where an element 2^26 below the
+ * group's largest stands next to that largest element in every sum it enters. */
+int igan_debug_f16_window_by_kind(unsigned long long* out4, int reset);
 
 /* bf16-piece form (IGAN_CONV_PLANES=1) only -- IGAN_ERR_UNSUPPORTED in the other forms: the piece image of a channel-minor tensor
  * x [N, HW, C] (times scale [N, C] when given), `out` = N * HW * C * 6 bytes, 16-byte aligned, C % 16 == 0.  The convolution entry

@@ -146,6 +146,7 @@ SIGNATURES = {
     'igan_conv2d_wgrad_kernel_name': (_I, [ctypes.POINTER(Conv2DWgradParams), ctypes.c_char_p, _I]),
     'igan_conv2d_wgrad_plan': (_I, [ctypes.POINTER(Conv2DWgradParams), ctypes.POINTER(_I), ctypes.POINTER(_SZ)]),
     'igan_conv2d_wgrad': (_I, [_P, ctypes.POINTER(Conv2DWgradParams)]),
+    'igan_debug_f16_window_by_kind': (_I, [_P, _I]),
     'igan_to_pieces': (_I, [_P, _P, _P, _P, _I, _I, _I]),
     'igan_conv_pieces_wanted': (_I, [_I, _I, _I, _I]),
     'igan_pieces_image_ok': (_I, [_I, _I, _I]),

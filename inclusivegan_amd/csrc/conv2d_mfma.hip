@@ -1086,15 +1086,11 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(ConvArgs a, int BM, int
 // The reduction runs 16-channel slice outermost, taps inside (the taps of a slice re-read the same shifted rows: L2 hits).
 // Tile list, slicing, fix-up and the whole epilogue are those of conv_fwd_dma_kernel (same accumulator layout).
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-// Round 5 (the multi-process mismatch of round 4, root-caused): the piece kernels prefetch two chunks ahead, so their last two iterations issue LDS-DMA
-// instructions for chunks past the end of the reduction, and nobody waits for those.  A wave that ends with such an instruction in flight gives its LDS
-// back before the data has landed: when another workgroup is placed on that LDS meanwhile, the late write lands in ITS data.  Inside one process that
-// is harmless (the next workgroup there is a tile of the same kernel, whose own chunks land later in the same stages; a following kernel does not start
-// before the launch has drained), but beside OTHER processes' kernels it is not: with eight ranks on one GPU a 98 KB dense_small_kernel workgroup of
-// another rank fits beside / behind a 55 KB fp16 tile (not beside the 74 KB bf16 or fp32 tiles -- which is why only the fp16 form showed it), and its
-// staged x rows were overwritten: tools/r5_trace8b.sh shows the FIRST call of an op whose output differs between two eager executions to be the first
-// mapping-network layer, with identical inputs (profiles/r05_replay_mismatch.txt).  Every wave therefore waits for its own LDS-DMA before it leaves
-// the main loop -- the instructions were issued to addresses outside the operand (zeros) or to a harmless slice, they return within a few hundred cycles.
+// The piece kernels prefetch two chunks ahead, so their last two iterations issue LDS-DMA instructions for chunks past the end of the reduction (out-of-range
+// addresses: zeros, or a harmless slice) that nobody waits for.  Every wave waits for its own LDS-DMA before it leaves the main loop, so that no wave ends -- and
+// no workgroup gives its LDS back -- with a write to that LDS still in flight.  (Round 5 looked at this while chasing the multi-process mismatch of round 4; it
+// was NOT its cause -- the mismatch was unchanged with the drain, see profiles/r05_replay_mismatch.txt and dense_small.hip -- but an in-flight write into LDS that
+// may already belong to another workgroup is not something to leave to the hardware's goodwill; the instructions return within a few hundred cycles.)
 __device__ __forceinline__ void drain_lds_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 constexpr int PK = 16;                          // reduction depth of a stage
 constexpr int P_IMG = 3 * 128 * 32;             // bytes of one operand image: [3 pieces][128 rows][32 B]
@@ -1227,7 +1223,8 @@ constexpr int H_COLBLOCKS = 1024;    // partial rows of a column-maximum pass (a
 constexpr int H_KSK = 4;             // a filter's column maxima: partial rows per tap (HWIO orientation)
 // Diagnostic (igan_debug_f16_window): how many non-zero elements were imaged BELOW the window in which the two pieces hold the value to 2^-23
 // (|v S| < 2^-12, i.e. more than 2^26 below the largest magnitude of the element's scale group), and how many elements were imaged in all.
-__device__ unsigned long long g_f16_below_window = 0ull, g_f16_imaged = 0ull;
+__device__ unsigned long long g_f16_below_window = 0ull, g_f16_imaged = 0ull;            // row images (forward / data gradient): the scale group is a pixel's channel vector
+__device__ unsigned long long g_f16_below_window_cols = 0ull, g_f16_imaged_cols = 0ull;  // column images (weight gradient): the scale group is a channel's pixels -- the SUMMED axis
 
 __host__ __device__ inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 // bytes of a row image of [P][C] (image + 1 / S per pixel), of a column image (image + 1 / S, S per channel + partials) and of a filter image
@@ -1246,13 +1243,13 @@ __device__ __forceinline__ float inv_scale_from_amax(float amax) {
     e = max(15, min(e, 254));
     return __uint_as_float((unsigned)(e - 14) << 23);
 }
-__device__ __forceinline__ void count_window(int below) {      // per wave: one atomic when anything is to be counted (diagnostic)
+__device__ __forceinline__ void count_window(int below, unsigned long long* counter) {      // per wave: one atomic when anything is to be counted (diagnostic)
 #ifdef IGAN_NO_WINDOW_COUNT
     return;
 #endif
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) below += __shfl_xor(below, o);
-    if ((threadIdx.x & 63) == 0 && below != 0) atomicAdd(&g_f16_below_window, (unsigned long long)below);
+    if ((threadIdx.x & 63) == 0 && below != 0) atomicAdd(counter, (unsigned long long)below);
 }
 
 __device__ __forceinline__ void split2(float vs, unsigned short (&o)[2]) {        // vs = v * S
@@ -1320,7 +1317,7 @@ __global__ __launch_bounds__(256) void rows_f16_kernel(const float* __restrict__
         pc[0][i] = o[0]; pc[1][i] = o[1];
         below += (mine && vs != 0.0f && fabsf(vs) < 0x1p-12f) ? 1 : 0;
     }
-    count_window(below);
+    count_window(below, &g_f16_below_window);
 #ifndef IGAN_NO_WINDOW_COUNT
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_f16_imaged, (unsigned long long)total * 16ull);
 #endif
@@ -1400,9 +1397,9 @@ __global__ __launch_bounds__(256) void cols_f16_kernel(const float* __restrict__
         pc[0][i] = o[0]; pc[1][i] = o[1];
         below += (mine && vs != 0.0f && fabsf(vs) < 0x1p-12f) ? 1 : 0;
     }
-    count_window(below);
+    count_window(below, &g_f16_below_window_cols);
 #ifndef IGAN_NO_WINDOW_COUNT
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_f16_imaged, (unsigned long long)total * 16ull);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_f16_imaged_cols, (unsigned long long)total * 16ull);
 #endif
     store_units(pc, stage, out, total);
 }
@@ -3259,16 +3256,30 @@ extern "C" int igan_conv2d_wgrad(igan_stream_t stream_, const igan_conv2d_wgrad_
 }
 
 // Diagnostic (two-piece fp16 variant): elements imaged so far below the exact window / in all; synchronises the device.  reset != 0 zeroes both.
-extern "C" int igan_debug_f16_window(unsigned long long* below, unsigned long long* imaged, int reset) {
+static int f16_window_read(unsigned long long (&v)[4], int reset) {
     using namespace igan;
-    unsigned long long v[2] = {0ull, 0ull};
-    if (hipMemcpyFromSymbol(&v[0], HIP_SYMBOL(g_f16_below_window), 8) != hipSuccess || hipMemcpyFromSymbol(&v[1], HIP_SYMBOL(g_f16_imaged), 8) != hipSuccess) return IGAN_ERR_HIP;
-    if (below) *below = v[0];
-    if (imaged) *imaged = v[1];
+    if (hipMemcpyFromSymbol(&v[0], HIP_SYMBOL(g_f16_below_window), 8) != hipSuccess || hipMemcpyFromSymbol(&v[1], HIP_SYMBOL(g_f16_imaged), 8) != hipSuccess ||
+        hipMemcpyFromSymbol(&v[2], HIP_SYMBOL(g_f16_below_window_cols), 8) != hipSuccess || hipMemcpyFromSymbol(&v[3], HIP_SYMBOL(g_f16_imaged_cols), 8) != hipSuccess) return IGAN_ERR_HIP;
     if (reset) {
         const unsigned long long z = 0ull;
-        if (hipMemcpyToSymbol(HIP_SYMBOL(g_f16_below_window), &z, 8) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(g_f16_imaged), &z, 8) != hipSuccess) return IGAN_ERR_HIP;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_f16_below_window), &z, 8) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(g_f16_imaged), &z, 8) != hipSuccess ||
+            hipMemcpyToSymbol(HIP_SYMBOL(g_f16_below_window_cols), &z, 8) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(g_f16_imaged_cols), &z, 8) != hipSuccess) return IGAN_ERR_HIP;
     }
+    return IGAN_OK;
+}
+extern "C" int igan_debug_f16_window(unsigned long long* below, unsigned long long* imaged, int reset) {      // both kinds of image together
+    unsigned long long v[4] = {0ull, 0ull, 0ull, 0ull};
+    if (int rc = f16_window_read(v, reset)) return rc;
+    if (below) *below = v[0] + v[2];
+    if (imaged) *imaged = v[1] + v[3];
+    return IGAN_OK;
+}
+extern "C" int igan_debug_f16_window_by_kind(unsigned long long* out4, int reset) {      // ABI v8: {rows below, rows imaged, columns below, columns imaged}
+    using namespace igan;
+    IGAN_REQUIRE(out4 != nullptr, "debug_f16_window_by_kind: null argument");
+    unsigned long long v[4] = {0ull, 0ull, 0ull, 0ull};
+    if (int rc = f16_window_read(v, reset)) return rc;
+    for (int i = 0; i < 4; i++) out4[i] = v[i];
     return IGAN_OK;
 }
 

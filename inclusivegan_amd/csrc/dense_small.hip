@@ -57,9 +57,18 @@ __global__ __launch_bounds__(256) void dense_small_kernel(DenseGroups G) {
     const bool jok = j < N;
     const float* __restrict__ w = a.w;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    // Round 5: every guarded load goes through a buffer descriptor (an out-of-range offset returns 0).  Written as `ok ? *p : zero` the compiler selected
-    // between the ADDRESSES -- the global one and that of a copy of `zero` in scratch -- and issued a flat load: every instantiation carried 32 bytes of
-    // scratch per lane and a flat path into it for no reason (profiles/r05_replay_mismatch.txt).
+    // Round 5 (profiles/r05_replay_mismatch.txt: the multi-process mismatch of round 4).  With several PROCESSES on one GPU this kernel returned different
+    // results for identical inputs whenever a workgroup of another process's fp16 tile kernel (conv_fwd_planes_kernel<2>) shared its CU; never alone, never
+    // beside the bf16 / fp32 tiles, the fp16 weight gradient or itself (tools/coresidency_probe.py: up to 75 % of the calls, errors of 0.1).  What was hit were
+    // this kernel's LOADS, in two forms, and both are gone:
+    //   * written as `ok ? *p : zero` a guarded load was compiled as a select between two ADDRESSES -- the global one and that of a copy of `zero` in scratch --
+    //     and a FLAT load: every instantiation carried 32 bytes of scratch per lane and a flat path into it.  Every guarded load now goes through a buffer
+    //     descriptor (an out-of-range offset returns 0): no scratch, no flat instruction.  That alone made the forward form (!WT) reproducible;
+    //   * the transposed form's weights, one 16-byte load per lane whose wave request falls into four 256-byte runs 2 KiB apart, still came back wrong; as four
+    //     4-byte loads (below) they do not -- 0 of 1200 calls against 700-900 of 1000 (same probe).
+    // The aggressor needs nothing but its main loop (barrier, LDS reads, matrix and vector instructions: no LDS-DMA, no store, no atomics: the probe's bisect),
+    // so this is an interaction below the programming model, between co-resident waves of different processes; it cannot occur with one process per GPU, which
+    // is how the engine is deployed -- the eight-ranks-on-one-GPU runs are a test vehicle.  tests/test_gpu_dist.py::test_eight_rank_replay_stress guards it.
     constexpr unsigned OOB = 0x7FFFFFF0u;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)(((unsigned)(M - 1) * (unsigned)a.ldx + (unsigned)K) * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x2 ? a.x2 : a.x), 0, a.x2 ? (int)((unsigned)M * (unsigned)K * 4u) : 0, 0x00020000);

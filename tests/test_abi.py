@@ -92,7 +92,14 @@ def test_plans_are_host_only():
     # the large 3x3 layers run in the bf16-piece form by default: their plans add the piece images of x and of the filter (6 B per element)
     on = lib.igan_conv_pieces_wanted(3, 3, 128, 128)
     assert on == (0 if os.environ.get('IGAN_CONV_PLANES') == '0' else 1)
-    img = lambda p: on * (p.N * p.H * p.W * p.Cin * 6 // 4 + p.KH * p.KW * p.Cin * p.Cout * 6 // 4)
+    form = lib.igan_conv_piece_form()
+    a256 = lambda b: (b + 255) // 256 * 256
+    if form == 2:       # fp16 form: a row image of x (4 B per element + 1 / S per pixel) and a filter image (4 B per element + 1 / S per output channel + column-maximum partials)
+        img = lambda p: (a256(4 * p.N * p.H * p.W * p.Cin + 4 * p.N * p.H * p.W) + a256(4 * p.KH * p.KW * p.Cin * p.Cout + 4 * p.Cout + 4 * p.KH * p.KW * 4 * p.Cout)) // 4
+        wimg = lambda P, C: a256(4 * P * C + 8 * C + 4 * 1024 * C) // 4      # weight gradient: a column image per operand (+ 1 / S and S per channel, 1024 rows of partials)
+    else:
+        img = lambda p: on * (p.N * p.H * p.W * p.Cin * 6 // 4 + p.KH * p.KW * p.Cin * p.Cout * 6 // 4)
+        wimg = lambda P, C: on * (P * C * 6 // 4)
     assert lib.igan_conv2d_plan(ctypes.byref(small), ctypes.byref(s), ctypes.byref(sl), ctypes.byref(ws)) == 0
     assert s.value > 1 and sl.value == 4 and ws.value == 4 * s.value * 128 * 128
     assert lib.igan_conv2d_plan(ctypes.byref(big), ctypes.byref(s), ctypes.byref(sl), ctypes.byref(ws)) == 0
@@ -101,7 +108,7 @@ def test_plans_are_host_only():
     assert s.value > 1 and sl.value in (32, 288) and ws.value == sl.value * s.value * 128 * 128 + img(mid)
     wg = _abi.Conv2DWgradParams(x=16, dy=16, dw=16, N=6, H=128, W=128, Cin=128, OH=128, OW=128, Cout=128, KH=3, KW=3, stride=1, up=1, pad_y=1, pad_x=1)
     assert lib.igan_conv2d_wgrad_plan(ctypes.byref(wg), ctypes.byref(s), ctypes.byref(ws)) == 0
-    assert s.value > 1 and ws.value == s.value * 9 * 128 * 128 + on * 2 * (6 * 128 * 128 * 128 * 6 // 4)
+    assert s.value > 1 and ws.value == s.value * 9 * 128 * 128 + 2 * wimg(6 * 128 * 128, 128)
 
 
 def test_no_cpu_fallback():
