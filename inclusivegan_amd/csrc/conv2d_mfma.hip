@@ -1220,7 +1220,7 @@ __global__ __launch_bounds__(256) void filter_planes_kernel(const float* __restr
 // column-maximum partials.  No host involvement, no atomics in the data path (max is order-independent: bit-reproducible).
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr int H_COLBLOCKS = 1024;    // partial rows of a column-maximum pass (as many blocks stream the tensor)
-constexpr int H_KSK = 4;             // a filter's column maxima: partial rows per tap (HWIO orientation)
+constexpr int H_KSK = 2;             // a filter's column maxima: partial rows per tap (HWIO orientation)
 // Diagnostic (igan_debug_f16_window): how many non-zero elements were imaged BELOW the window in which the two pieces hold the value to 2^-23
 // (|v S| < 2^-12, i.e. more than 2^26 below the largest magnitude of the element's scale group), and how many elements were imaged in all.
 __device__ unsigned long long g_f16_below_window = 0ull, g_f16_imaged = 0ull;            // row images (forward / data gradient): the scale group is a pixel's channel vector
@@ -1444,7 +1444,17 @@ __global__ __launch_bounds__(256) void filter_planes_f16_kernel(const float* __r
     if constexpr (WT) { c = idx % cpk; const int r = idx / cpk; n = r % Nn; tap = r / Nn; }
     else { n = idx % Nn; const int r = idx / Nn; c = r % cpk; tap = r / cpk; }
     float amax = 0.0f;
-    for (int r = 0; r < prow; r++) amax = fmaxf(amax, partial[(size_t)r * Nn + n]);
+    {   // independent loads, six in flight (a serial loop over the partial rows is `prow` dependent L2 round trips in front of every thread's work)
+        float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f, m5 = 0.f;
+        int r = 0;
+        for (; r + 6 <= prow; r += 6) {
+            const float* q = partial + (size_t)r * Nn + n;
+            const float v0 = q[0], v1 = q[Nn], v2 = q[2 * (size_t)Nn], v3 = q[3 * (size_t)Nn], v4 = q[4 * (size_t)Nn], v5 = q[5 * (size_t)Nn];
+            m0 = fmaxf(m0, v0); m1 = fmaxf(m1, v1); m2 = fmaxf(m2, v2); m3 = fmaxf(m3, v3); m4 = fmaxf(m4, v4); m5 = fmaxf(m5, v5);
+        }
+        for (; r < prow; r++) m0 = fmaxf(m0, partial[(size_t)r * Nn + n]);
+        amax = fmaxf(fmaxf(fmaxf(m0, m1), fmaxf(m2, m3)), fmaxf(m4, m5));
+    }
     const float S = scale_from_amax(amax);
     if (tap == 0 && c == 0) inv[n] = inv_scale_from_amax(amax);
     float v[16];

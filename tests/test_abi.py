@@ -95,7 +95,7 @@ def test_plans_are_host_only():
     form = lib.igan_conv_piece_form()
     a256 = lambda b: (b + 255) // 256 * 256
     if form == 2:       # fp16 form: a row image of x (4 B per element + 1 / S per pixel) and a filter image (4 B per element + 1 / S per output channel + column-maximum partials)
-        img = lambda p: (a256(4 * p.N * p.H * p.W * p.Cin + 4 * p.N * p.H * p.W) + a256(4 * p.KH * p.KW * p.Cin * p.Cout + 4 * p.Cout + 4 * p.KH * p.KW * 4 * p.Cout)) // 4
+        img = lambda p: (a256(4 * p.N * p.H * p.W * p.Cin + 4 * p.N * p.H * p.W) + a256(4 * p.KH * p.KW * p.Cin * p.Cout + 4 * p.Cout + 4 * p.KH * p.KW * 2 * p.Cout)) // 4
         wimg = lambda P, C: a256(4 * P * C + 8 * C + 4 * 1024 * C) // 4      # weight gradient: a column image per operand (+ 1 / S and S per channel, 1024 rows of partials)
     else:
         img = lambda p: on * (p.N * p.H * p.W * p.Cin * 6 // 4 + p.KH * p.KW * p.Cin * p.Cout * 6 // 4)
