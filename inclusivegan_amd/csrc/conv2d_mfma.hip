@@ -1746,6 +1746,8 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
         if constexpr (TAPO) {
             int ct = (c_begin < c_end) ? c_begin / a.cpt : 0;                       // tap of the chunk being consumed
             int cs = (c_begin < c_end) ? c_begin - ct * a.cpt : 0;                  // its slice
+            bool cs_new = true;
+            float sc0 = 0.0f, sc1 = 0.0f;
             f32x16 u[TM];       // the cross terms p0a p1b + p1a p0b of the current tap, chained in the matrix pipe (2^-11 of the tap's sum)
 #pragma unroll
             for (int tm = 0; tm < TM; tm++)
@@ -1763,7 +1765,7 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
                     a0[tm] = __builtin_bit_cast(f16x8, *reinterpret_cast<const bf16x8*>(S + fa[tm]));
                     a1[tm] = __builtin_bit_cast(f16x8, *reinterpret_cast<const bf16x8*>(S + fa[tm] + 4096));
                 }
-                const float sc0 = tab_row[ct * BM], sc1 = tab_row[ct * BM + 32];
+                if (cs_new) { sc0 = tab_row[ct * BM]; sc1 = tab_row[ct * BM + 32]; cs_new = false; }      // the rows' scales change with the tap only
                 dma_prep(nst);
                 f32x16 t;           // one set of registers for the main term of both tiles
                 __builtin_amdgcn_sched_barrier(0);
@@ -1788,7 +1790,7 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
                         acc[0][r] = __builtin_fmaf(u[0][r], f0, acc[0][r]); acc[1][r] = __builtin_fmaf(u[1][r], f1, acc[1][r]);
                         u[0][r] = 0.0f; u[1][r] = 0.0f;
                     }
-                    cs = 0; ++ct;
+                    cs = 0; ++ct; cs_new = true;
                 }
                 st = (st + 1 == P_NSTAGE) ? 0 : st + 1;
             }
