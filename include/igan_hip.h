@@ -37,7 +37,7 @@ extern "C" {
 /* Bumped whenever a struct layout, a signature or the set of exports changes (2: fused conv epilogue fields, fp64 nearest-neighbour state;
  * 5 / 6: piece images and their sizes; 7: igan_conv_piece_form, igan_debug_f16_window; 8: the two-piece fp16 form scales every tensor per
  * pixel (forward / data gradient) or per channel (weight gradient) and writes its own images -- caller-written images (igan_to_pieces, x_pieces,
- * dy_pieces) belong to the bf16-piece form only; no struct changed since 6). */
+ * dy_pieces) belong to the bf16-piece form only; igan_conv2d_params gains x_colmax, igan_conv2d_wgrad_params x_colmax / dy_colmax at their ends). */
 #define IGAN_ABI_VERSION 8
 
 typedef void* igan_stream_t; /* hipStream_t */
@@ -218,6 +218,9 @@ typedef struct igan_conv2d_params {
                              * the fp16 form rejects a non-NULL image (ABI v8: its images are scaled per pixel here and per channel in
                              * the weight gradient, so no image serves two calls), form 0 ignores it */
     size_t x_pieces_bytes;  /* its size, N * H * W * Cin * 6 (ABI v6): an image of any other size is rejected, never read */
+    float* x_colmax;        /* ABI v8, fp16 form, optional OUTPUT (igan_colmax_floats(N, H * W, Cin) floats, 16-byte aligned; NULL = none): the per-channel maxima of
+                             * |x * in_scale| -- a by-product of the row image this call writes of x (a pass of its own when the call takes another path), which a later
+                             * igan_conv2d_wgrad() of the SAME tensor takes as x_colmax / dy_colmax instead of a pass of its own over it */
 } igan_conv2d_params;
 
 int igan_conv2d_plan(const igan_conv2d_params* p, int* splits, int* sliced_tiles, size_t* workspace_floats);
@@ -252,6 +255,8 @@ typedef struct igan_conv2d_wgrad_params {
     const void* dy_pieces;
     size_t x_pieces_bytes;  /* N * H * W * Cin * 6 and N * OH * OW * Cout * 6 (ABI v6): checked before an image is read */
     size_t dy_pieces_bytes;
+    const float* x_colmax;  /* ABI v8, fp16 form, optional INPUTS (NULL = none): the buffers an igan_conv2d() call on the same x * in_scale / dy * out_scale filled (x_colmax there); */
+    const float* dy_colmax; /* the column image of that operand then skips its maxima pass.  Bit-identical results either way (a maximum does not depend on the order). */
 } igan_conv2d_wgrad_params;
 
 int igan_conv2d_wgrad_plan(const igan_conv2d_wgrad_params* p, int* splits, size_t* workspace_floats);
@@ -271,6 +276,8 @@ int igan_pieces_image_ok(int N, int HW, int C);
  * channel's pixels in the weight gradient -- never a whole tensor), three products; the operand to 2^-23 (exactly in three cases of four) for every
  * element within 2^26 of the largest of its own group. */
 int igan_conv_piece_form(void);
+/* ABI v8: size in floats of an x_colmax / dy_colmax buffer for a tensor [N, HW, C]; 0 = none is taken (not the fp16 form, or a channel count outside it). */
+size_t igan_colmax_floats(int N, int HW, int C);
 /* Diagnostic for form 2 (synchronises the device): non-zero elements imaged so far BELOW the exact window (|v S| < 2^-12: more than 2^26 below the
  * largest magnitude of the element's own scale group) and elements imaged in all; reset != 0 zeroes both counters. */
 int igan_debug_f16_window(unsigned long long* below, unsigned long long* imaged, int reset);

@@ -60,6 +60,7 @@ class Conv2DParams(ctypes.Structure):
         ('bias', ctypes.c_void_p), ('act', ctypes.c_int), ('act_alpha', ctypes.c_float), ('act_gain', ctypes.c_float),
         ('noise', ctypes.c_void_p), ('noise_strength', ctypes.c_void_p), ('noise_bcast', ctypes.c_int),
         ('x_pieces', ctypes.c_void_p), ('x_pieces_bytes', ctypes.c_size_t),
+        ('x_colmax', ctypes.c_void_p),
     ]
 
     def __init__(self, *args, **kwargs):
@@ -79,6 +80,7 @@ class Conv2DWgradParams(ctypes.Structure):
         ('pad_y', ctypes.c_int), ('pad_x', ctypes.c_int),
         ('splits', ctypes.c_int), ('alpha', ctypes.c_float),
         ('x_pieces', ctypes.c_void_p), ('dy_pieces', ctypes.c_void_p), ('x_pieces_bytes', ctypes.c_size_t), ('dy_pieces_bytes', ctypes.c_size_t),
+        ('x_colmax', ctypes.c_void_p), ('dy_colmax', ctypes.c_void_p),
     ]
 
     def __init__(self, *args, **kwargs):
@@ -147,6 +149,7 @@ SIGNATURES = {
     'igan_conv2d_wgrad_plan': (_I, [ctypes.POINTER(Conv2DWgradParams), ctypes.POINTER(_I), ctypes.POINTER(_SZ)]),
     'igan_conv2d_wgrad': (_I, [_P, ctypes.POINTER(Conv2DWgradParams)]),
     'igan_debug_f16_window_by_kind': (_I, [_P, _I]),
+    'igan_colmax_floats': (ctypes.c_size_t, [_I, _I, _I]),
     'igan_to_pieces': (_I, [_P, _P, _P, _P, _I, _I, _I]),
     'igan_conv_pieces_wanted': (_I, [_I, _I, _I, _I]),
     'igan_pieces_image_ok': (_I, [_I, _I, _I]),

@@ -1271,7 +1271,7 @@ __device__ __forceinline__ void load_unit16(const float* __restrict__ x, const f
     }
 }
 // the block's 256 units (16 KiB of contiguous image) go through LDS so that every store instruction of a wave writes one contiguous KiB
-__device__ __forceinline__ void store_units(const unsigned short (&pc)[2][16], uint4* stage, unsigned short* __restrict__ out, int total) {
+__device__ __forceinline__ void store_units(const unsigned short (&pc)[2][16], uint4* stage, unsigned short* __restrict__ out, int total, int chunk) {
 #pragma unroll
     for (int q = 0; q < 2; q++)
 #pragma unroll
@@ -1282,8 +1282,8 @@ __device__ __forceinline__ void store_units(const unsigned short (&pc)[2][16], u
             stage[threadIdx.x * 4 + 2 * q + hh] = u;
         }
     __syncthreads();
-    const int units = min(256, total - (int)blockIdx.x * 256);
-    uint4* dst = reinterpret_cast<uint4*>(out + (size_t)blockIdx.x * 256 * 32);
+    const int units = min(256, total - chunk * 256);
+    uint4* dst = reinterpret_cast<uint4*>(out + (size_t)chunk * 256 * 32);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int j = k * 256 + threadIdx.x;
@@ -1293,41 +1293,68 @@ __device__ __forceinline__ void store_units(const unsigned short (&pc)[2][16], u
 
 // ROW image: x [P][C] fp32 (times scale[p / HW][C] when given) -> [P][C/16][2][16] fp16, one scale per pixel, 1 / S to rowinv[P].  One thread per
 // (pixel, 16 channels); the cpp = C / 16 threads of a pixel (a power of two <= 64: they sit in one wave) share the pixel's maximum by shuffles.  ONE pass.
+// A block takes chunks of 256 units blockIdx.x, blockIdx.x + gridDim.x, ...: its threads keep their 16-channel slice, so that -- when `colmax` is given -- the
+// per-CHANNEL maxima of the block's share fall out of the same pass: colmax = [rows (as a float), 0, 0, 0][gridDim.x rows of C maxima], what the weight gradient's
+// column image of the same tensor needs (cols_finalize_kernel) instead of a pass of its own over the tensor.
 __global__ __launch_bounds__(256) void rows_f16_kernel(const float* __restrict__ x, const float* __restrict__ scale, unsigned short* __restrict__ out,
-                                                        float* __restrict__ rowinv, int total, int cpp, int lcpp, int C, int HW) {
+                                                        float* __restrict__ rowinv, float* __restrict__ colmax, int total, int cpp, int lcpp, int C, int HW) {
     __shared__ uint4 stage[256 * 4];
-    const bool mine = (int)(blockIdx.x * 256 + threadIdx.x) < total;
-    const int idx = min((int)(blockIdx.x * 256 + threadIdx.x), total - 1);      // the last block's spare threads repeat its last unit (not stored)
-    const int p = idx >> lcpp, c = idx & (cpp - 1);
-    float v[16];
-    load_unit16(x, scale, p, c, C, HW, v);
-    float m = 0.0f;
+    const int c = threadIdx.x & (cpp - 1);
+    float cm[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) m = fmaxf(m, fabsf(v[i]));
-    for (int o = 1; o < cpp; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
-    const float S = scale_from_amax(m);
-    if (mine && c == 0) rowinv[p] = inv_scale_from_amax(m);
-    unsigned short pc[2][16];
+    for (int i = 0; i < 16; i++) cm[i] = 0.0f;
     int below = 0;
+    const int nchunks = (total + 255) >> 8;
+    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const bool mine = chunk * 256 + (int)threadIdx.x < total;
+        const int idx = min(chunk * 256 + (int)threadIdx.x, total - 1);      // the last chunk's spare threads repeat its last unit (not stored)
+        const int p = idx >> lcpp;
+        float v[16];
+        load_unit16(x, scale, p, c, C, HW, v);
+        float m = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        unsigned short o[2];
-        const float vs = v[i] * S;
-        split2(vs, o);
-        pc[0][i] = o[0]; pc[1][i] = o[1];
-        below += (mine && vs != 0.0f && fabsf(vs) < 0x1p-12f) ? 1 : 0;
+        for (int i = 0; i < 16; i++) { const float av = fabsf(v[i]); m = fmaxf(m, av); if (mine) cm[i] = fmaxf(cm[i], av); }
+        for (int o = 1; o < cpp; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+        const float S = scale_from_amax(m);
+        if (mine && c == 0) rowinv[p] = inv_scale_from_amax(m);
+        unsigned short pc[2][16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            unsigned short o[2];
+            const float vs = v[i] * S;
+            split2(vs, o);
+            pc[0][i] = o[0]; pc[1][i] = o[1];
+            below += (mine && vs != 0.0f && fabsf(vs) < 0x1p-12f) ? 1 : 0;
+        }
+        if (chunk != (int)blockIdx.x) __syncthreads();      // the previous chunk's copy out of `stage` is done
+        store_units(pc, stage, out, total, chunk);
     }
     count_window(below, &g_f16_below_window);
 #ifndef IGAN_NO_WINDOW_COUNT
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_f16_imaged, (unsigned long long)total * 16ull);
 #endif
-    store_units(pc, stage, out, total);
+    if (colmax != nullptr) {        // wave-uniform
+        __syncthreads();
+        float* sm = reinterpret_cast<float*>(stage);            // [256 threads][16]
+#pragma unroll
+        for (int i = 0; i < 16; i++) sm[threadIdx.x * 16 + i] = cm[i];
+        __syncthreads();
+        const int groups = 256 >> lcpp;                          // threads that hold the same slice
+        for (int ch = threadIdx.x; ch < C; ch += 256) {
+            const int cc = ch >> 4, i = ch & 15;
+            float m = 0.0f;
+            for (int j = 0; j < groups; j++) m = fmaxf(m, sm[(j * cpp + cc) * 16 + i]);
+            colmax[4 + (size_t)blockIdx.x * C + ch] = m;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) colmax[0] = (float)gridDim.x;
+    }
 }
 
 // Column maxima of |x scale| over a [P][C] tensor: partial[block][C].  A thread owns one channel quad (C4 = C / 4, a power of two <= 256) and
 // every (256 / C4)-th pixel of the block's share; two loads in flight per lane.
 __global__ __launch_bounds__(256) void cols_amax_kernel(const float* __restrict__ x, const float* __restrict__ scale, float* __restrict__ partial,
-                                                         int P_, int C4, int lC4, int HW) {
+                                                         int P_, int C4, int lC4, int HW, float* __restrict__ header) {
+    if (header != nullptr && blockIdx.x == 0 && threadIdx.x == 0) header[0] = (float)gridDim.x;      // the partial rows' count travels with a caller-held buffer
     __shared__ float4 red[256];
     const int q = threadIdx.x & (C4 - 1), pl = threadIdx.x >> lC4, ppi = 256 >> lC4;
     const int step = gridDim.x * ppi;
@@ -1355,8 +1382,9 @@ __global__ __launch_bounds__(256) void cols_amax_kernel(const float* __restrict_
 }
 // partial[rows][C] -> inv[C] = 1 / S, sc[C] = S.  grid = C / 8 blocks of 32 row lanes x 8 channels (a thread takes every 32nd row: the
 // partials are a latency chain otherwise -- four row lanes over 1024 rows took 44 us).
-__global__ __launch_bounds__(256) void cols_finalize_kernel(const float* __restrict__ partial, float* __restrict__ inv, float* __restrict__ sc, int rows, int C) {
+__global__ __launch_bounds__(256) void cols_finalize_kernel(const float* __restrict__ partial, float* __restrict__ inv, float* __restrict__ sc, int rows, int C, const float* __restrict__ header) {
     __shared__ float red[256];
+    if (header != nullptr) rows = (int)header[0];       // maxima handed over by the call that wrote the tensor's row image (wave-uniform)
     const int c = blockIdx.x * 8 + (threadIdx.x & 7), rl = threadIdx.x >> 3;
     float m0 = 0.0f, m1 = 0.0f, m2 = 0.0f, m3 = 0.0f;
     if (c < C) {
@@ -1401,7 +1429,7 @@ __global__ __launch_bounds__(256) void cols_f16_kernel(const float* __restrict__
 #ifndef IGAN_NO_WINDOW_COUNT
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_f16_imaged_cols, (unsigned long long)total * 16ull);
 #endif
-    store_units(pc, stage, out, total);
+    store_units(pc, stage, out, total, (int)blockIdx.x);
 }
 
 // Column maxima of a filter: the largest |W(tap, k, n)| over k per (tap [, k quarter], n).  The image kernel below takes the maximum over the partial rows.
@@ -2695,21 +2723,34 @@ void launch_piece_image(hipStream_t stream, const float* x, const float* scale, 
     hipLaunchKernelGGL(to_planes_kernel, dim3(igan::ceil_div(total, 256)), dim3(256), 0, stream, x, scale, out, total, cpp, C, HW);
 }
 // fp16 form, forward / data gradient: the ROW image (one scale per pixel) of x [P][C]; `out` holds rows_part_bytes(P, C).  C / 16 a power of two <= 64.
-void launch_row_image(hipStream_t stream, const float* x, const float* scale, unsigned short* out, int P_, int HW, int C) {
+// `colmax` (optional, IGAN_COLMAX_FLOATS(C) floats): the tensor's per-channel maxima as a by-product, for the weight gradient's column image of the same tensor
+void launch_row_image(hipStream_t stream, const float* x, const float* scale, unsigned short* out, int P_, int HW, int C, float* colmax) {
     const int cpp = C / PK, total = P_ * cpp;
     float* rowinv = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(out) + (size_t)P_ * C * 4);
-    hipLaunchKernelGGL(rows_f16_kernel, dim3(igan::ceil_div(total, 256)), dim3(256), 0, stream, x, scale, out, rowinv, total, cpp, ilog2(cpp), C, HW);
+    const int nchunks = igan::ceil_div(total, 256);
+    const int grid = colmax ? std::min(nchunks, H_COLBLOCKS) : nchunks;
+    hipLaunchKernelGGL(rows_f16_kernel, dim3(grid), dim3(256), 0, stream, x, scale, out, rowinv, colmax, total, cpp, ilog2(cpp), C, HW);
+}
+// the same maxima from a pass of their own (a call that was asked for them but does not write a row image)
+void launch_colmax_only(hipStream_t stream, const float* x, const float* scale, float* colmax, int P_, int HW, int C) {
+    const int C4 = C / 4, ppi = 256 / C4;
+    const int blocks = std::min(H_COLBLOCKS, igan::ceil_div(P_, ppi));
+    hipLaunchKernelGGL(cols_amax_kernel, dim3(blocks), dim3(256), 0, stream, x, scale, colmax + 4, P_, C4, ilog2(C4), HW, colmax);
 }
 // fp16 form, weight gradient: the COLUMN image (one scale per channel) of x [P][C]; `out` holds cols_part_bytes(P, C).  C / 4 a power of two <= 256.
-void launch_col_image(hipStream_t stream, const float* x, const float* scale, unsigned short* out, int P_, int HW, int C) {
+// `colmax` (optional): the channel maxima the caller holds from the call that wrote this tensor's row image -- the pass over the tensor is skipped
+void launch_col_image(hipStream_t stream, const float* x, const float* scale, unsigned short* out, int P_, int HW, int C, const float* colmax) {
     const int cpp = C / PK, total = P_ * cpp, C4 = C / 4;
     float* inv = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(out) + (size_t)P_ * C * 4);
     float* sc = inv + C;
     float* partial = sc + C;
     const int ppi = 256 / C4;
     const int blocks = std::min(H_COLBLOCKS, igan::ceil_div(P_, ppi));
-    hipLaunchKernelGGL(cols_amax_kernel, dim3(blocks), dim3(256), 0, stream, x, scale, partial, P_, C4, ilog2(C4), HW);
-    hipLaunchKernelGGL(cols_finalize_kernel, dim3(igan::ceil_div(C, 8)), dim3(256), 0, stream, (const float*)partial, inv, sc, blocks, C);
+    if (colmax == nullptr) {
+        hipLaunchKernelGGL(cols_amax_kernel, dim3(blocks), dim3(256), 0, stream, x, scale, partial, P_, C4, ilog2(C4), HW, (float*)nullptr);
+        hipLaunchKernelGGL(cols_finalize_kernel, dim3(igan::ceil_div(C, 8)), dim3(256), 0, stream, (const float*)partial, inv, sc, blocks, C, (const float*)nullptr);
+    } else
+        hipLaunchKernelGGL(cols_finalize_kernel, dim3(igan::ceil_div(C, 8)), dim3(256), 0, stream, colmax + 4, inv, sc, 0, C, colmax);
     hipLaunchKernelGGL(cols_f16_kernel, dim3(igan::ceil_div(total, 256)), dim3(256), 0, stream, x, scale, out, (const float*)sc, total, cpp, C, HW);
 }
 void launch_filter_image(hipStream_t stream, const float* w, unsigned short* wp, bool wt, int taps, int KW_, int Nn, int K) {
@@ -2891,13 +2932,20 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
     hipStream_t stream = (hipStream_t)stream_;
     IGAN_REQUIRE(p != nullptr, "conv2d: null params");
     if (int rc = fwd_geometry_check(p)) return rc;
+    if (p->x_colmax != nullptr) {       // the by-product of the fp16 form's row image; any other path of this call computes it by a pass of its own, so that the buffer is always valid
+        IGAN_REQUIRE(igan_colmax_floats(p->N, p->H * p->W, p->Cin) != 0, "conv2d: x_colmax given, but igan_colmax_floats() says this process / tensor takes none");
+        IGAN_REQUIRE((((uintptr_t)p->x_colmax | (uintptr_t)p->x | (uintptr_t)p->in_scale) & 15) == 0, "conv2d: x_colmax, x and in_scale must be 16-byte aligned");
+    }
+    auto colmax_own_pass = [&]() { if (p->x_colmax) launch_colmax_only(stream, p->x, p->in_scale, p->x_colmax, p->N * p->H * p->W, p->H * p->W, p->Cin); };
     if (is_small_dense(p)) {
+        colmax_own_pass();
         IGAN_REQUIRE(p->noise == nullptr, "conv2d: the fused noise epilogue is not offered on the small dense path");
         dense_small(stream, p->x, p->w, p->y, p->N, p->Cin, p->Cout, p->w_transposed != 0, p->alpha);
         IGAN_LAUNCH_CHECK("conv2d dense launch");
         return IGAN_OK;
     }
     if (const int kind = thin_conv_kind(p)) {
+        colmax_own_pass();
         IGAN_REQUIRE(p->noise == nullptr, "conv2d: the fused noise epilogue is not offered on the thin-channel path");
         thin_conv(stream, p, kind);
         IGAN_LAUNCH_CHECK("conv2d thin-channel launch");
@@ -2966,7 +3014,8 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
     const bool wt = p->w_transposed != 0;
     const bool vec = a.vecA && a.vecB && (a.in_scale == nullptr || a.vecS);
     bool launched = false;
-    if (planes) {       // bf16-piece form: write the two piece images, then the tile kernel
+    if (!planes) colmax_own_pass();
+    if (planes) {       // piece form: write the two piece images, then the tile kernel
         IGAN_REQUIRE(p->x_pieces == nullptr || planes_mode() == 1, "conv2d: the two-piece fp16 form writes its own images (one scale per pixel here, per channel in the weight gradient): x_pieces must be NULL");
         IGAN_REQUIRE(p->x_pieces == nullptr || p->x_pieces_bytes == planes_x_floats(p) * 4, "conv2d: x_pieces is not the image of this x (x_pieces_bytes != N*H*W*Cin*6)");
         const unsigned short* xp = reinterpret_cast<const unsigned short*>(p->x_pieces);
@@ -2975,7 +3024,7 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
         if (xp == nullptr) {         // no image from the caller: write it behind the partial tiles
             unsigned short* own = reinterpret_cast<unsigned short*>(p->workspace + partial_floats);
             if (a.diag_mode & 1) {}      // DIAGNOSTIC: stale image
-            else if (planes_mode() == 2) launch_row_image(stream, p->x, p->in_scale, own, p->N * p->H * p->W, p->H * p->W, p->Cin);
+            else if (planes_mode() == 2) launch_row_image(stream, p->x, p->in_scale, own, p->N * p->H * p->W, p->H * p->W, p->Cin, p->x_colmax);
             else launch_piece_image(stream, p->x, p->in_scale, own, p->N * p->H * p->W, p->H * p->W, p->Cin);
             xp = own;
         }
@@ -3192,6 +3241,8 @@ extern "C" int igan_conv2d_wgrad(igan_stream_t stream_, const igan_conv2d_wgrad_
         IGAN_REQUIRE(p->workspace != nullptr, "conv2d_wgrad: splits > 1 needs a workspace");
         IGAN_REQUIRE(p->workspace_floats >= (size_t)splits * wsize, "conv2d_wgrad: workspace too small");
     }
+    if (p->x_colmax != nullptr) IGAN_REQUIRE(igan_colmax_floats(p->N, p->H * p->W, p->Cin) != 0 && (((uintptr_t)p->x_colmax) & 15) == 0, "conv2d_wgrad: x_colmax is not a buffer igan_colmax_floats() sized for this x");
+    if (p->dy_colmax != nullptr) IGAN_REQUIRE(igan_colmax_floats(p->N, p->OH * p->OW, p->Cout) != 0 && (((uintptr_t)p->dy_colmax) & 15) == 0, "conv2d_wgrad: dy_colmax is not a buffer igan_colmax_floats() sized for this dy");
     WgradArgs a;
     a.x = p->x; a.dy = p->dy;
     a.out = (splits > 1) ? p->workspace : p->dw;
@@ -3227,13 +3278,13 @@ extern "C" int igan_conv2d_wgrad(igan_stream_t stream_, const igan_conv2d_wgrad_
         const unsigned short* dyp = reinterpret_cast<const unsigned short*>(p->dy_pieces);
         if (xp == nullptr) {
             unsigned short* own = reinterpret_cast<unsigned short*>(p->workspace + partial_floats);
-            if (planes_mode() == 2) launch_col_image(stream, p->x, p->in_scale, own, p->N * p->H * p->W, p->H * p->W, p->Cin);
+            if (planes_mode() == 2) launch_col_image(stream, p->x, p->in_scale, own, p->N * p->H * p->W, p->H * p->W, p->Cin, p->x_colmax);
             else launch_piece_image(stream, p->x, p->in_scale, own, p->N * p->H * p->W, p->H * p->W, p->Cin);
             xp = own;
         }
         if (dyp == nullptr) {
             unsigned short* own = reinterpret_cast<unsigned short*>(p->workspace + partial_floats + wgrad_planes_x_floats(p));
-            if (planes_mode() == 2) launch_col_image(stream, p->dy, p->out_scale, own, p->N * p->OH * p->OW, p->OH * p->OW, p->Cout);
+            if (planes_mode() == 2) launch_col_image(stream, p->dy, p->out_scale, own, p->N * p->OH * p->OW, p->OH * p->OW, p->Cout, p->dy_colmax);
             else launch_piece_image(stream, p->dy, p->out_scale, own, p->N * p->OH * p->OW, p->OH * p->OW, p->Cout);
             dyp = own;
         }
@@ -3296,6 +3347,14 @@ extern "C" int igan_debug_f16_window_by_kind(unsigned long long* out4, int reset
 }
 
 extern "C" int igan_conv_piece_form(void) { return planes_mode(); }
+
+// ABI v8: floats of the buffer a caller passes as x_colmax (igan_conv2d) and hands on as x_colmax / dy_colmax (igan_conv2d_wgrad) for a tensor [N, HW, C]; 0 = this
+// process / tensor has no use for one (not the fp16 form; a channel count the column image does not take).
+extern "C" size_t igan_colmax_floats(int N, int HW, int C) {
+    using namespace igan;
+    if (planes_mode() != 2 || N < 1 || HW < 1 || C < 16 || C > 1024 || (C & (C - 1)) != 0) return 0;
+    return 4 + (size_t)H_COLBLOCKS * C;
+}
 
 extern "C" int igan_conv_pieces_wanted(int KH, int KW, int Cin, int Cout) {
     using namespace igan;

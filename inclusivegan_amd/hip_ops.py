@@ -618,7 +618,27 @@ def to_pieces(x, scale=None):
     return PieceImage(out, n * h * w * c * 6)
 
 
-def conv2d_raw(x, w, geom, out_hw, cout, w_transposed=False, in_scale=None, out_scale=None, bias=None, act=None, noise=None, strength=None, x_pieces=None):
+_colmax_floats = {}
+COLMAX_SHARE = os.environ.get('IGAN_COLMAX_SHARE', '1') != '0'      # A/B switch: 0 = the weight gradient finds its operands' channel maxima by passes of its own
+
+
+def colmax_buffer(x, want=True):
+    """fp16 form: the buffer a convolution call fills with the per-channel maxima of the tensor it images per pixel (igan_conv2d_params.x_colmax), to be handed to
+    the weight gradient of the same tensor (x_colmax / dy_colmax) -- its column image then needs no pass of its own for them.  None when the library takes none
+    for this tensor (igan_colmax_floats() == 0: another form, another channel count) or `want` is false."""
+    if not (want and COLMAX_SHARE) or _is_meta(x) or x.dim() != 4:
+        return None
+    n, c, h, w = x.shape
+    key = (int(n), int(h * w), int(c))
+    fl = _colmax_floats.get(key)
+    if fl is None:
+        fl = _colmax_floats[key] = int(_abi.get_plugin().igan_colmax_floats(*key))
+    if fl == 0:
+        return None
+    return torch.empty((fl,), device=x.device, dtype=torch.float32)
+
+
+def conv2d_raw(x, w, geom, out_hw, cout, w_transposed=False, in_scale=None, out_scale=None, bias=None, act=None, noise=None, strength=None, x_pieces=None, colmax=None):
     """x: logical [N,Cin,H,W] (channels_last).  w: HWIO [KH,KW,Cin,Cout] (or the forward layer's
     [KH,KW,Cout,Cin] when w_transposed).  Returns logical [N,Cout,OH,OW] channels_last.
     act = (act_idx, alpha, gain) fuses y = act(y + bias) * gain into the kernel's epilogue (bias may be None)."""
@@ -651,6 +671,8 @@ def conv2d_raw(x, w, geom, out_hw, cout, w_transposed=False, in_scale=None, out_
     if x_pieces is not None:    # bf16-piece form: the image of x * in_scale, written once by to_pieces() for several consumers
         p.x_pieces = x_pieces.data_ptr()
         p.x_pieces_bytes = x_pieces.nbytes
+    if colmax is not None:      # fp16 form: the channel maxima of x * in_scale as a by-product (colmax_buffer)
+        p.x_colmax = colmax.data_ptr()
     if noise is not None:       # epilogue noise: [N or 1, 1, OH, OW] contiguous + device scalar strength (needs act)
         noise = noise.contiguous()
         _require_cuda_f32(noise, strength)
@@ -701,7 +723,7 @@ def conv2d_raw(x, w, geom, out_hw, cout, w_transposed=False, in_scale=None, out_
     return y
 
 
-def conv2d_wgrad_raw(x, dy, geom, in_scale=None, out_scale=None, x_pieces=None, dy_pieces=None):
+def conv2d_wgrad_raw(x, dy, geom, in_scale=None, out_scale=None, x_pieces=None, dy_pieces=None, x_colmax=None, dy_colmax=None):
     """dw[KH,KW,Cin,Cout] for y = conv(x, w) with geometry `geom`."""
     lib = _abi.get_plugin()
     _require_cuda_f32(x, dy, in_scale, out_scale)
@@ -730,6 +752,10 @@ def conv2d_wgrad_raw(x, dy, geom, in_scale=None, out_scale=None, x_pieces=None, 
     if dy_pieces is not None:
         p.dy_pieces = dy_pieces.data_ptr()
         p.dy_pieces_bytes = dy_pieces.nbytes
+    if x_colmax is not None:    # fp16 form: channel maxima written by the calls that imaged the same x * in_scale / dy * out_scale per pixel
+        p.x_colmax = x_colmax.data_ptr()
+    if dy_colmax is not None:
+        p.dy_colmax = dy_colmax.data_ptr()
     key = (n, h, wd, cin, oh, ow, cout, geom, in_scale is not None, out_scale is not None)
     plan = _wplan_cache.get(key)
     if plan is None:
@@ -837,10 +863,12 @@ class ConvBiasActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, geom, out_hw, act_idx, alpha, gain):
-        xp = to_pieces(x) if (pieces_wanted(geom, x.shape[1], w.shape[3]) and ctx.needs_input_grad[1]) else None      # variant: one piece image for the forward pass and the weight gradient
-        y = conv2d_raw(x, w, geom, out_hw, w.shape[3], bias=b, act=(act_idx, alpha, gain), x_pieces=xp)
+        share = pieces_wanted(geom, x.shape[1], w.shape[3]) and ctx.needs_input_grad[1]
+        xp = to_pieces(x) if share else None      # bf16 form: one piece image for the forward pass and the weight gradient
+        xcm = colmax_buffer(x, share)             # fp16 form: the forward call's row image leaves the channel maxima the weight gradient's column image needs
+        y = conv2d_raw(x, w, geom, out_hw, w.shape[3], bias=b, act=(act_idx, alpha, gain), x_pieces=xp, colmax=xcm)
         ctx.save_for_backward(x, w, y)
-        ctx.xp = xp
+        ctx.xp, ctx.xcm = xp, xcm
         ctx.geom, ctx.cfg = geom, (act_idx, alpha, gain)
         ctx.in_hw = (x.shape[2], x.shape[3])
         ctx.has_b = b is not None
@@ -864,11 +892,13 @@ class ConvBiasActFn(torch.autograd.Function):
                 dw = ConvWgradFn.apply(x, dxp, ctx.geom)
             return dx, dw, db, None, None, None, None, None
         dxp, db, _ = bias_act_noise_bwd_raw(dy, y, None, act_idx, alpha, gain, need_b)
-        dyp = to_pieces(dxp) if (pieces_wanted(ctx.geom, x.shape[1], y.shape[1]) and need_x and need_w) else None                # variant: one image of dy for both gradients
+        share = pieces_wanted(ctx.geom, x.shape[1], y.shape[1]) and need_x and need_w
+        dyp = to_pieces(dxp) if share else None                # bf16 form: one image of dy for both gradients
+        dycm = colmax_buffer(dxp, share)
         if need_x:
-            dx = conv2d_raw(dxp, w, dgrad_geom(ctx.geom), ctx.in_hw, w.shape[2], w_transposed=True, x_pieces=dyp)
+            dx = conv2d_raw(dxp, w, dgrad_geom(ctx.geom), ctx.in_hw, w.shape[2], w_transposed=True, x_pieces=dyp, colmax=dycm)
         if need_w:
-            dw = conv2d_wgrad_raw(x, dxp, ctx.geom, x_pieces=ctx.xp, dy_pieces=dyp)
+            dw = conv2d_wgrad_raw(x, dxp, ctx.geom, x_pieces=ctx.xp, dy_pieces=dyp, x_colmax=ctx.xcm, dy_colmax=dycm)
         return dx, dw, (db if need_b else None), None, None, None, None, None
 
 
@@ -922,10 +952,12 @@ class ModConv2dFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, s, d, geom, out_hw):
-        xp = to_pieces(x, s) if (pieces_wanted(geom, x.shape[1], w.shape[3]) and ctx.needs_input_grad[1]) else None   # variant: one piece image of x * s for the forward pass and the weight gradient
-        y = conv2d_raw(x, w, geom, out_hw, w.shape[3], in_scale=s, out_scale=d, x_pieces=xp)
+        share = pieces_wanted(geom, x.shape[1], w.shape[3]) and ctx.needs_input_grad[1]
+        xp = to_pieces(x, s) if share else None   # bf16 form: one piece image of x * s for the forward pass and the weight gradient
+        xcm = colmax_buffer(x, share)             # fp16 form: channel maxima of x * s for the weight gradient's column image
+        y = conv2d_raw(x, w, geom, out_hw, w.shape[3], in_scale=s, out_scale=d, x_pieces=xp, colmax=xcm)
         ctx.save_for_backward(x, w, s, d, y)
-        ctx.xp = xp
+        ctx.xp, ctx.xcm = xp, xcm
         ctx.geom = geom
         ctx.out_hw = out_hw
         return y
@@ -964,10 +996,12 @@ class ModConv2dFn(torch.autograd.Function):
             return dx, dw, ds, dd, None, None
         dx = dw = ds = dd = None
         dy = nhwc(dy)
-        dyp = to_pieces(dy, d) if (pieces_wanted(geom, x.shape[1], y.shape[1]) and (need_x or need_s) and need_w) else None  # variant: one image of dy * d for both gradients
+        share = pieces_wanted(geom, x.shape[1], y.shape[1]) and (need_x or need_s) and need_w
+        dyp = to_pieces(dy, d) if share else None  # bf16 form: one image of dy * d for both gradients
+        dycm = colmax_buffer(dy, share)
         if need_x or need_s:
             # dxs = dgrad(dy * d, w)   (un-modulated input gradient)
-            dxs = conv2d_raw(dy, w, dgrad_geom(geom), in_hw, w.shape[2], w_transposed=True, in_scale=d, x_pieces=dyp)
+            dxs = conv2d_raw(dy, w, dgrad_geom(geom), in_hw, w.shape[2], w_transposed=True, in_scale=d, x_pieces=dyp, colmax=dycm)
             if x.shape[1] % 4 == 0:
                 # one pass: ds = sum_hw x * dxs, and dx = dxs * s written in place over dxs
                 ds, dx = scale_dot_raw(x, dxs, s, want_scaled=need_x)
@@ -979,7 +1013,7 @@ class ModConv2dFn(torch.autograd.Function):
                 if need_x:
                     dx = dxs * s[:, :, None, None]
         if need_w:
-            dw = conv2d_wgrad_raw(x, dy, geom, in_scale=s, out_scale=d, x_pieces=ctx.xp, dy_pieces=dyp)
+            dw = conv2d_wgrad_raw(x, dy, geom, in_scale=s, out_scale=d, x_pieces=ctx.xp, dy_pieces=dyp, x_colmax=ctx.xcm, dy_colmax=dycm)
         if need_d and d is not None:
             if y.shape[1] % 4 == 0:
                 dd = scale_dot_raw(dy, y)[0] / d
@@ -1086,10 +1120,12 @@ class ModConvBanFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, s, d, b, noise, strength, geom, out_hw, act_idx, alpha, gain):
         _mark_inputs(ctx, x, w, s, d, b, noise, strength, geom, out_hw, act_idx, alpha, gain)
-        xp = to_pieces(x, s) if (pieces_wanted(geom, x.shape[1], w.shape[3]) and ctx.needs_input_grad[1]) else None   # variant: as ModConv2dFn
-        y = conv2d_raw(x, w, geom, out_hw, w.shape[3], in_scale=s, out_scale=d, bias=b, act=(act_idx, alpha, gain), noise=noise, strength=strength, x_pieces=xp)
+        share = pieces_wanted(geom, x.shape[1], w.shape[3]) and ctx.needs_input_grad[1]
+        xp = to_pieces(x, s) if share else None   # as ModConv2dFn
+        xcm = colmax_buffer(x, share)
+        y = conv2d_raw(x, w, geom, out_hw, w.shape[3], in_scale=s, out_scale=d, bias=b, act=(act_idx, alpha, gain), noise=noise, strength=strength, x_pieces=xp, colmax=xcm)
         ctx.save_for_backward(x, w, s, d, b, noise, strength, y)
-        ctx.xp = xp
+        ctx.xp, ctx.xcm = xp, xcm
         ctx.geom, ctx.out_hw, ctx.cfg = geom, out_hw, (act_idx, alpha, gain)
         return y
 
@@ -1105,14 +1141,16 @@ class ModConvBanFn(torch.autograd.Function):
         dxp, db, dst, dd = bias_act_noise_bwd_dd_raw(dy, y, noise, strength, b, d, act_idx, alpha, gain)
         dx = dw = ds = None
         in_hw = (x.shape[2], x.shape[3])
-        dyp = to_pieces(dxp, d) if (pieces_wanted(geom, x.shape[1], y.shape[1]) and (need_x or need_s) and need_w) else None
+        share = pieces_wanted(geom, x.shape[1], y.shape[1]) and (need_x or need_s) and need_w
+        dyp = to_pieces(dxp, d) if share else None
+        dycm = colmax_buffer(dxp, share)
         if need_x or need_s:
-            dxs = conv2d_raw(dxp, w, dgrad_geom(geom), in_hw, w.shape[2], w_transposed=True, in_scale=d, x_pieces=dyp)
+            dxs = conv2d_raw(dxp, w, dgrad_geom(geom), in_hw, w.shape[2], w_transposed=True, in_scale=d, x_pieces=dyp, colmax=dycm)
             ds, dx = scale_dot_raw(x, dxs, s, want_scaled=need_x)
             if not need_s:
                 ds = None
         if need_w:
-            dw = conv2d_wgrad_raw(x, dxp, geom, in_scale=s, out_scale=d, x_pieces=ctx.xp, dy_pieces=dyp)
+            dw = conv2d_wgrad_raw(x, dxp, geom, in_scale=s, out_scale=d, x_pieces=ctx.xp, dy_pieces=dyp, x_colmax=ctx.xcm, dy_colmax=dycm)
         return dx, dw, ds, (dd if need_d else None), (db if need_b else None), None, (dst if need_st else None), None, None, None, None, None
 
 

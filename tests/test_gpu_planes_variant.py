@@ -173,11 +173,13 @@ print('DIGESTS ' + ' '.join(out))
 
 @pytest.mark.parametrize('form', ['1', '2'], ids=['bf16_x3', 'fp16_x2'])
 def test_shared_piece_images_change_nothing(cuda_device, form):
-    """The piece images written once per layer (hip_ops.to_pieces -> x_pieces / dy_pieces, ABI v5) against every convolution call
-    writing its own (IGAN_PIECES_SHARE=0): the same arithmetic on the same images, so outputs and all gradients are bit-identical."""
+    """What the calls of a layer hand each other must change nothing: the bf16 form's piece images written once per layer (hip_ops.to_pieces -> x_pieces / dy_pieces,
+    ABI v5) against every convolution call writing its own (IGAN_PIECES_SHARE=0); the fp16 form's channel maxima left by the forward / data-gradient call's row image
+    (x_colmax, ABI v8) against the weight gradient finding them by passes of its own (IGAN_COLMAX_SHARE=0) -- the same arithmetic on the same images and the same scales
+    (a maximum does not depend on the order), so outputs and all gradients are bit-identical."""
     digs = []
     for share in ('1', '0'):
-        env = dict(os.environ, IGAN_CONV_PLANES=form, IGAN_PIECES_SHARE=share)
+        env = dict(os.environ, IGAN_CONV_PLANES=form, IGAN_PIECES_SHARE=share, IGAN_COLMAX_SHARE=share)
         r = subprocess.run([sys.executable, '-c', SHARE_CHILD % ROOT], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
         digs.append([l for l in r.stdout.splitlines() if l.startswith('DIGESTS ')][-1])
@@ -223,6 +225,21 @@ if form == 2:
         else:
             raise AssertionError('the fp16 form accepted a caller-written image')
     assert lib.igan_to_pieces(None, x.data_ptr(), None, fake.data_ptr(), 4, 1024, 256) == 3       # IGAN_ERR_UNSUPPORTED
+    # ABI v8: the channel maxima a convolution call leaves (x_colmax) and the weight gradient takes: bit-identical to its own passes, also when the
+    # call that was asked for them does not write a row image itself (a 1x1 convolution: the maxima come from a pass of their own)
+    assert lib.igan_colmax_floats(4, 1024, 256) == 4 + 1024 * 256 and lib.igan_colmax_floats(4, 1024, 144) == 0
+    dy = torch.randn(4, 256, 32, 32, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    xcm, dycm = hip_ops.colmax_buffer(x), hip_ops.colmax_buffer(dy)
+    y3 = hip_ops.conv2d_raw(x, w, geom, (32, 32), 256, colmax=xcm)
+    hip_ops.conv2d_raw(dy, w, hip_ops.dgrad_geom(geom), (32, 32), 256, w_transposed=True, colmax=dycm)
+    assert torch.equal(y, y3) and int(xcm[0]) == 256 and float(xcm[4:4 + 256 * 256].reshape(256, 256).max()) == float(x.abs().max())
+    dw0 = hip_ops.conv2d_wgrad_raw(x, dy, geom)
+    dw1 = hip_ops.conv2d_wgrad_raw(x, dy, geom, x_colmax=xcm, dy_colmax=dycm)
+    assert torch.equal(dw0, dw1)
+    w1 = (torch.randn(1, 1, 256, 256, generator=g) / 16.0).to(dev)
+    xcm2 = hip_ops.colmax_buffer(x)
+    hip_ops.conv2d_raw(x, w1, hip_ops.ConvGeom(1, 1, 1, 1, 0, 0), (32, 32), 256, colmax=xcm2)
+    assert torch.equal(hip_ops.conv2d_wgrad_raw(x, dy, geom, x_colmax=xcm2, dy_colmax=dycm), dw0)
 elif form == 1:
     assert xp is not None and xp.nbytes == x.numel() * 6
     y2 = hip_ops.conv2d_raw(x, w, geom, (32, 32), 256, x_pieces=xp)
