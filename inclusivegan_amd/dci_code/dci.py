@@ -215,17 +215,19 @@ class DCI(object):
                 todo = todo[bad]
                 m = max(4 * m, 8)
                 if k + m > max_keep:         # stop widening: threshold selection against the exact k-th distance found so far
-                    self._threshold_rerank(qs_all, todo, q0, e_k[bad][:, -1] + slack[bad], k, out_i, out_d)
+                    self._threshold_rerank(qs_all, todo, q0, e_k[bad][:, -1] + slack[bad], k, out_i, out_d, i_k[bad])
                     self.last_threshold_queries += int(todo.numel())
                     break
         return out_i, out_d
 
-    def _threshold_rerank(self, qs_all, todo, q0, limit, k, out_i, out_d):
+    def _threshold_rerank(self, qs_all, todo, q0, limit, k, out_i, out_d, short):
         """For each listed query: every candidate whose screening distance is <= limit (the exact k-th distance of a valid short
-        list plus the screening slack -- the true k nearest are among them), measured exactly slab by slab, best k kept."""
+        list plus the screening slack -- the true k nearest are among them), measured exactly slab by slab, best k kept.  `short`
+        [len(todo), k]: the short list the limit came from; its members are always measured too, so that at least k candidates are (the
+        one-row screening product below may round differently from the batched one that chose them: ADVICE r04)."""
         n = self.num_points
         step = max(1, self.rerank_bytes // (self.dim * 8))
-        for t, lim in zip(todo.tolist(), limit.tolist()):
+        for row, (t, lim) in enumerate(zip(todo.tolist(), limit.tolist())):
             qrow = qs_all[t:t + 1]
             qn = hip_ops.row_sqnorm_raw(qrow).double()
             sel = []
@@ -234,8 +236,8 @@ class DCI(object):
                 dots = hip_ops.conv2d_raw(qrow.reshape(1, self.dim, 1, 1), cs.reshape(1, 1, cs.shape[0], self.dim),
                                           hip_ops.ConvGeom(1, 1, 1, 1, 0, 0), (1, 1), cs.shape[0], w_transposed=True).reshape(-1)
                 d2 = qn[0] + self._norms[c0:c0 + self.cand_chunk].double() - 2.0 * dots.double()
-                sel.append(torch.nonzero(~(d2 > lim)).reshape(-1) + c0)        # NaN / inf screening values stay in (measured exactly below)
-            ii = torch.cat(sel)
+                sel.append(torch.nonzero(~(d2 > lim)).reshape(-1) + c0)        # a NaN screening value stays in (measured exactly below); +inf is out -- unless the short list holds it
+            ii = torch.unique(torch.cat(sel + [short[row].to(torch.int64).reshape(-1)]))      # sorted ascending: ties go to the lower index
             qq = qrow[0].double()
             e = torch.cat([((self._data[ii[c0:c0 + step]].double() - qq[None, :]) ** 2).sum(dim=1) for c0 in range(0, ii.numel(), step)])
             e = torch.where(torch.isfinite(e), e, torch.full_like(e, float('inf')))

@@ -275,6 +275,33 @@ def _with_random_source(fn):
     return wrapper
 
 
+_f16_window_seen = [0, 0]
+
+
+def _f16_window_warning(bound=1e-4):
+    """The two-piece fp16 form holds an operand to 2^-23 inside a window of 2^26 below the largest of its scale group.  In the row images of
+    the forward / data-gradient kernel the group is a pixel's channel vector and elements below the window should be chance near-zeros (1e-6 on random-init
+    networks); a fraction above `bound` since the last call says the activations of single pixels span more than 2^26 -- worth a line in the log.  (Column images
+    are not judged: their group runs along the summed axis.)  None when there is nothing to say."""
+    import ctypes
+    from .. import _abi
+    lib = _abi.get_plugin()
+    if lib.igan_conv_piece_form() != 2:
+        return None
+    v = (ctypes.c_ulonglong * 4)()
+    if lib.igan_debug_f16_window_by_kind(v, 0) != 0:        # the counters are left alone (bench.py reports their totals): the difference to the last call is judged
+        return None
+    below, imaged = v[0] - _f16_window_seen[0], v[1] - _f16_window_seen[1]
+    _f16_window_seen[0], _f16_window_seen[1] = v[0], v[1]
+    if imaged <= 0 or below < 0:
+        return None
+    frac = below / imaged
+    if frac <= bound:
+        return None
+    return ('WARNING: fp16 convolution form: %.2e of the row-image elements since the last tick lay more than 2^26 below their own pixel\'s largest channel '
+            '(bound %.0e); IGAN_CONV_PLANES=1 runs the exact three-piece bf16 form' % (frac, bound))
+
+
 class SubmitThread:
     """A second host thread that owns the per-iteration device submissions (input copies, graph replays, optimizer updates), fed in
     order through a queue.  With the HIP runtime's graph packet capture off (inclusivegan_amd/__init__.py) `CUDAGraph.replay()` blocks its
@@ -304,6 +331,8 @@ class SubmitThread:
         sys.setswitchinterval(float(os.environ.get('IGAN_ASYNC_SWITCH_S', '1e-4')))
         self.thread = threading.Thread(target=self._run, name='igan-submit', daemon=True)
         self.thread.start()
+        self.closed = False
+        SubmitThread.live.add(self)
 
     def _run(self):
         torch.cuda.set_device(self.device)
@@ -344,15 +373,35 @@ class SubmitThread:
         self.q.join()
         self._check()
 
-    def close(self):
+    live = set()        # submitters that have not been closed: training_loop closes them on EVERY way out (an exception used to leave the thread and the switch interval behind)
+
+    def close(self, check=True):
         import sys
+        if self.closed:
+            return
+        self.closed = True
+        SubmitThread.live.discard(self)
         self.q.put(None)
         self.thread.join()
         sys.setswitchinterval(self._switch)
-        self._check()
+        if check:
+            self._check()
+
+
+def _closing_submitters(fn):
+    """Whatever way training_loop() ends, no submission thread and no altered GIL switch interval outlive it."""
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        try:
+            return fn(*args, **kwargs)
+        finally:
+            for sub in list(SubmitThread.live):
+                sub.close(check=False)
+    return wrapper
 
 
 @_with_random_source
+@_closing_submitters
 def training_loop(
     G_args                  = {},
     D_args                  = {},
@@ -405,6 +454,8 @@ def training_loop(
     ):
 
     hooks = hooks or {}
+    from .. import hostaffinity
+    hostaffinity.limit_host_threads()       # every entry into the loop, not only run_training / bench.py: PyTorch's CPU pool sized to the affinity mask stalls the submissions
 
     # Initialize (tflib.init_tf: rnd.np_random_seed, tfutil.py:122-147).
     rank, world = _dist_info()
@@ -714,6 +765,8 @@ def training_loop(
         assert data_size % (sched.minibatch_size * 2) == 0
         training_set.configure(sched.minibatch_size * 2, sched.lod)
         training_set_rec.configure(sched.minibatch_size * 2, sched.lod)
+        if sched.G_lrate != cur_lrate[0] or sched.minibatch_size != minibatch_size_holder[0]:
+            drain()         # queued iterations read these lazily (learning rate, Gs beta): they must have run before the schedule's next values are set
         cur_lrate[0] = sched.G_lrate
         minibatch_size_holder[0] = sched.minibatch_size
         mb = sched.minibatch_size
@@ -802,6 +855,9 @@ def training_loop(
             tick_time = now - tick_start_time
             total_time = now - start_time + resume_time
             sums = autosummary_mod.flush()
+            window_warning = _f16_window_warning()     # fp16 form: row-image elements outside their pixel's exact window, since the last tick (watched at run time)
+            if rank == 0 and window_warning:
+                print(window_warning, flush=True)
             if rank == 0:
                 lines = ['tick %-5d kimg %-8.1f lod %-5.2f minibatch %-4d time %-12s sec/tick %-7.1f sec/kimg %-7.2f maintenance %-6.1f gpumem %.1f' % (
                     cur_tick, cur_nimg / 1000.0, sched.lod, sched.minibatch_size, dnnlib.util.format_time(total_time),
