@@ -1528,9 +1528,14 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
 #ifndef IGAN_F16_LDS_PAD
 #define IGAN_F16_LDS_PAD 0
 #endif
+#ifndef IGAN_F16_NSTAGE
+#define IGAN_F16_NSTAGE 3
+#endif
+    constexpr int NS = (NP == 2) ? IGAN_F16_NSTAGE : P_NSTAGE;  // depth of the LDS ring: chunk c + NS - 1 is fetched while chunk c is consumed
+    static_assert(NS == 3 || NS == 4, "ring depth");
     constexpr int LPAD = (NP == 2) ? IGAN_F16_LDS_PAD : 0;     // experiment: pad the fp16 tile's LDS footprint (co-residency with other kernels)
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[P_NSTAGE * STAGE + 3 * BM * 4 + TABS + LPAD];
-    int* row_pix = reinterpret_cast<int*>(smem + P_NSTAGE * STAGE);
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGE + 3 * BM * 4 + TABS + LPAD];
+    int* row_pix = reinterpret_cast<int*>(smem + NS * STAGE);
     int* row_n = row_pix + BM;
     float* row_nz = reinterpret_cast<float*>(row_n + BM);
     float* tab_s = row_nz + BM;
@@ -1732,7 +1737,7 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
             }
         }
     }
-    if ((c_begin < c_end) && !(dm & 32)) { dma_chunk(0); dma_chunk(1); }
+    if ((c_begin < c_end) && !(dm & 32)) { dma_chunk(0); dma_chunk(1); if constexpr (NS == 4) dma_chunk(2); }
     if constexpr (NP == 2) {
 #pragma unroll
         for (int j = 0; j < 3; j++)
@@ -1772,6 +1777,77 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
         // and tile, and the epilogue stores 16 B per register quad.
         const float* tab_row = tab_s + wm * 64 + l31;
         if constexpr (TAPO) {
+#ifdef IGAN_F16_NESTED
+            // Taps outside, the tap's 16-channel slices inside: everything that changes with the tap only (the rows' scales, the fold of the cross terms) sits
+            // between the inner loops, and a step is straight-line code -- its two LDS-DMA instructions take their piece and LDS displacements from
+            // wave-uniform scalars instead of a branch per wave half.
+            int ct = (c_begin < c_end) ? c_begin / a.cpt : 0;                       // tap of the chunk being consumed
+            int cs = (c_begin < c_end) ? c_begin - ct * a.cpt : 0;                  // its first slice (non-zero only where a slice of the reduction starts inside a tap)
+            f32x16 u[TM];       // the cross terms p0a p1b + p1a p0b of the current tap, chained in the matrix pipe (2^-11 of the tap's sum)
+#pragma unroll
+            for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) u[tm][r] = 0.0f;
+            const unsigned pcA = lowave ? 0u : 32u, pcB = lowave ? 32u : 0u;                                  // the piece each wave half fetches: bytes inside the (row, slice) unit
+            const unsigned ldA = (unsigned)(wave & 3) * 1024u + (lowave ? 0u : 4096u);                         // where it goes inside a stage
+            const unsigned ldB = (unsigned)IMG + (unsigned)(wave & 3) * 1024u + (lowave ? 4096u : 0u);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");         // the scale table is published (no wait for the chunks in flight)
+            int c = (dm & 8) ? c_end : c_begin;
+            while (c < c_end) {
+                const int n_in = min(a.cpt - cs, c_end - c);
+                const float sc0 = tab_row[ct * BM], sc1 = tab_row[ct * BM + 32];
+                for (int i = 0; i < n_in; i++) {
+                    if (dm & 128) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");        // diagnostic: no barrier
+                    else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // chunk c landed (two younger instructions: chunk c + 1); stage st + 2 is free
+                    const int nst = st >= 1 ? st - 1 : NS - 1;
+                    const unsigned char* S = smem + st * STAGE;
+                    f16x8 a0[TM], a1[TM];
+                    const f16x8 b0 = __builtin_bit_cast(f16x8, *reinterpret_cast<const bf16x8*>(S + fb));
+                    const f16x8 b1 = __builtin_bit_cast(f16x8, *reinterpret_cast<const bf16x8*>(S + fb + 4096));
+#pragma unroll
+                    for (int tm = 0; tm < TM; tm++) {
+                        a0[tm] = __builtin_bit_cast(f16x8, *reinterpret_cast<const bf16x8*>(S + fa[tm]));
+                        a1[tm] = __builtin_bit_cast(f16x8, *reinterpret_cast<const bf16x8*>(S + fa[tm] + 4096));
+                    }
+                    dma_prep(nst);
+                    unsigned char* D = smem + nst * STAGE;
+                    const unsigned sB = __builtin_amdgcn_readfirstlane(soffB) + pcB;
+                    f32x16 t;           // one set of registers for the main term of both tiles
+                    const int nfold = (dm & 256) ? 1 : 16;          // diagnostic: one register of sixteen folded
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (dm & 512) t = zero;                         // diagnostic: no matrix instructions
+                    else {
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a0[0], zero, 0, 0, 0);       // main term: from an exact zero
+                    u[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1, a0[0], u[0], 0, 0, 0);
+                    u[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1, a0[1], u[1], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!(dm & 32)) {            // chunk c + 2, issued inside the matrix cluster
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(D + ldA), 16, offA, pcA, 0, 0);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(D + ldB), 16, voffB, sB, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; r++) if (r < nfold) acc[0][r] = __builtin_fmaf(t[r], sc0, acc[0][r]);        // vector ALU: round to nearest
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!(dm & 512)) {
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a0[1], zero, 0, 0, 0);
+                    u[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a1[0], u[0], 0, 0, 0);
+                    u[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a1[1], u[1], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; r++) if (r < nfold) acc[1][r] = __builtin_fmaf(t[r], sc1, acc[1][r]);
+                    st = (st + 1 == NS) ? 0 : st + 1;
+                }
+                // the tap (or this slice of the reduction) ends: its cross terms join the sum under the tap's scale
+                const float f0 = sc0 * (1.0f / 2048.0f), f1 = sc1 * (1.0f / 2048.0f);
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    acc[0][r] = __builtin_fmaf(u[0][r], f0, acc[0][r]); acc[1][r] = __builtin_fmaf(u[1][r], f1, acc[1][r]);
+                    u[0][r] = 0.0f; u[1][r] = 0.0f;
+                }
+                c += n_in; cs = 0; ++ct;
+            }
+#else
             int ct = (c_begin < c_end) ? c_begin / a.cpt : 0;                       // tap of the chunk being consumed
             int cs = (c_begin < c_end) ? c_begin - ct * a.cpt : 0;                  // its slice
             bool cs_new = true;
@@ -1782,8 +1858,9 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) u[tm][r] = 0.0f;
             for (int c = (dm & 8) ? c_end : c_begin; c < c_end; c++) {
-                asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // as below
-                const int nst = st >= 1 ? st - 1 : P_NSTAGE - 1;
+                if (dm & 128) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");        // diagnostic: no barrier
+                else if constexpr (NS == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // as below
+                const int nst = st >= 1 ? st - 1 : NS - 1;
                 const unsigned char* S = smem + st * STAGE;
                 f16x8 a0[TM], a1[TM];
                 const f16x8 b0 = __builtin_bit_cast(f16x8, *reinterpret_cast<const bf16x8*>(S + fb));
@@ -1796,20 +1873,26 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
                 if (cs_new) { sc0 = tab_row[ct * BM]; sc1 = tab_row[ct * BM + 32]; cs_new = false; }      // the rows' scales change with the tap only
                 dma_prep(nst);
                 f32x16 t;           // one set of registers for the main term of both tiles
+                const int nfold = (dm & 256) ? 1 : 16;          // diagnostic: one register of sixteen folded
                 __builtin_amdgcn_sched_barrier(0);
+                if (dm & 512) t = zero;                         // diagnostic: no matrix instructions
+                else {
                 t = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a0[0], zero, 0, 0, 0);       // main term: from an exact zero
                 u[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1, a0[0], u[0], 0, 0, 0);
                 u[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1, a0[1], u[1], 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
-                if (!(dm & 32)) { dma_piece(0); dma_piece(1); }            // chunk c + 2, issued inside the matrix cluster
+                if (!(dm & 32)) { dma_piece(0); dma_piece(1); }            // chunk c + NS - 1, issued inside the matrix cluster
 #pragma unroll
-                for (int r = 0; r < 16; r++) acc[0][r] = __builtin_fmaf(t[r], sc0, acc[0][r]);        // vector ALU: round to nearest
+                for (int r = 0; r < 16; r++) if (r < nfold) acc[0][r] = __builtin_fmaf(t[r], sc0, acc[0][r]);        // vector ALU: round to nearest
                 __builtin_amdgcn_sched_barrier(0);
+                if (!(dm & 512)) {
                 t = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a0[1], zero, 0, 0, 0);
                 u[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a1[0], u[0], 0, 0, 0);
                 u[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a1[1], u[1], 0, 0, 0);
+                }
 #pragma unroll
-                for (int r = 0; r < 16; r++) acc[1][r] = __builtin_fmaf(t[r], sc1, acc[1][r]);
+                for (int r = 0; r < 16; r++) if (r < nfold) acc[1][r] = __builtin_fmaf(t[r], sc1, acc[1][r]);
                 ++cs;
                 if (cs == a.cpt || c + 1 == c_end) {        // the tap (or this slice of the reduction) ends: its cross terms join the sum under the tap's scale
                     const float f0 = sc0 * (1.0f / 2048.0f), f1 = sc1 * (1.0f / 2048.0f);
@@ -1820,15 +1903,16 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
                     }
                     cs = 0; ++ct; cs_new = true;
                 }
-                st = (st + 1 == P_NSTAGE) ? 0 : st + 1;
+                st = (st + 1 == NS) ? 0 : st + 1;
             }
+#endif
         } else {
         int ct = (c_begin < c_end) ? c_begin - (c_begin / ntap) * ntap : 0;      // tap of the chunk being consumed (the reduction runs slice outermost, taps inside)
         for (int c = c_begin; c < c_end; c++) {
             // chunk c landed (two younger instructions: chunk c+1); stage st+2 is free.  lgkmcnt(0): the first barrier also publishes the scale table
             // (every wave's ds_write has completed before it arrives); later iterations have no LDS operation in flight at this point.
-            asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            const int nst = st >= 1 ? st - 1 : P_NSTAGE - 1;
+            if constexpr (NS == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            const int nst = st >= 1 ? st - 1 : NS - 1;
             const unsigned char* S = smem + st * STAGE;
             f16x8 a0[TM], a1[TM];
             const f16x8 b0 = __builtin_bit_cast(f16x8, *reinterpret_cast<const bf16x8*>(S + fb));
@@ -1858,7 +1942,7 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
             v = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a1[1], v, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[1][r] = __builtin_fmaf(__builtin_fmaf(v[r], 1.0f / 2048.0f, t[r]), sc1, acc[1][r]);
-            st = (st + 1 == P_NSTAGE) ? 0 : st + 1;
+            st = (st + 1 == NS) ? 0 : st + 1;
         }
         }
         drain_lds_dma();
@@ -1917,7 +2001,7 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
         // chunk c: issued two iterations ago (three instructions of this wave are younger: chunk c+1)
         asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
         // everyone has chunk c in stage st, and has finished reading stage st + 2 (chunk c-1): it is refilled with chunk c+2
-        const int nst = st >= 1 ? st - 1 : P_NSTAGE - 1;
+        const int nst = st >= 1 ? st - 1 : NS - 1;
         const unsigned char* S = smem + st * STAGE;
         bf16x8 af[TM][3], bfr[3];
         const unsigned char* S0 = S;
@@ -1947,7 +2031,7 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
             }
 #pragma unroll
         for (int tm = 0; tm < TM; tm++) acc[tm] += t[tm];
-        st = (st + 1 == P_NSTAGE) ? 0 : st + 1;
+        st = (st + 1 == NS) ? 0 : st + 1;
     }
     }
     drain_lds_dma();

@@ -1,4 +1,4 @@
-// Sustained rate of the two exact-f32 matrix instructions of gfx950 in bare register loops (no memory traffic
+// Sustained rate of the two exact-f32 matrix instructions of gfx950 (and of the fp16 / bf16 32x32x16 instructions of the piece products) in bare register loops (no memory traffic
 // inside the loop), on random operands, with the in-kernel clock: what the matrix pipe delivers when nothing
 // else competes for power.  The conv kernels are priced against this ceiling.
 //   build: hipcc -O3 --offload-arch=gfx950 tools/mfma_rate.hip -o tools/mfma_rate
@@ -11,10 +11,13 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
-// MODE 0: v_mfma_f32_32x32x2_f32, 4 independent accumulators (64 regs); MODE 1: v_mfma_f32_16x16x4_f32, 8 accumulators (32 regs)
+// MODE 0: v_mfma_f32_32x32x2_f32, 4 independent accumulators (64 regs); MODE 1: v_mfma_f32_16x16x4_f32, 8 accumulators (32 regs);
+// MODE 2 / 3: v_mfma_f32_32x32x16_f16 / _bf16 (the piece products of the 3x3 convolutions), 4 accumulators, operands = random values rounded to the type
 template <int MODE>
 __global__ __launch_bounds__(256) void mfma_loop(const float* __restrict__ in, float* __restrict__ out, int iters,
                                                   unsigned long long* __restrict__ stamps) {
@@ -37,6 +40,35 @@ __global__ __launch_bounds__(256) void mfma_loop(const float* __restrict__ in, f
 #pragma unroll
                 for (int t = 0; t < 4; t++)
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[(j + t) & 7], b[j], acc[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) sum += acc[t][r];
+    } else if constexpr (MODE >= 2) {
+        f32x16 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+        f16x8 ha[4], hb[2];
+        bf16x8 ba[4], bb[2];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const float v = in[(tid * 64 + 8 * i + k) & 0xFFFFF]; ha[i][k] = (_Float16)v; ba[i][k] = (__bf16)v; }
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const float v = in[(tid * 64 + 32 + 8 * i + k) & 0xFFFFF]; hb[i][k] = (_Float16)v; bb[i][k] = (__bf16)v; }
+        for (int it = 0; it < iters; it++) {
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    if constexpr (MODE == 2) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[(j + t) & 3], hb[j & 1], acc[t], 0, 0, 0);
+                    else acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ba[(j + t) & 3], bb[j & 1], acc[t], 0, 0, 0);
+                }
         }
 #pragma unroll
         for (int t = 0; t < 4; t++)
@@ -70,8 +102,8 @@ __global__ __launch_bounds__(256) void mfma_loop(const float* __restrict__ in, f
 template <int MODE>
 void run(const char* name, int blocks, double seconds, const float* in, float* out, unsigned long long* stamps) {
     // per wave and iteration: MODE 0: 32 MFMAs x 4096 FLOP; MODE 1: 64 MFMAs x 2048 FLOP
-    const double flop_iter = 131072.0 * 4 * blocks;
-    const int iters = 20000;
+    const double flop_iter = (MODE >= 2 ? 8.0 : 1.0) * 131072.0 * 4 * blocks;         // MODE 2 / 3: 32 MFMAs x 32768 FLOP
+    const int iters = MODE >= 2 ? 10000 : 20000;
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 2; i++) hipLaunchKernelGGL(mfma_loop<MODE>, dim3(blocks), dim3(256), 0, 0, in, out, iters, stamps);
@@ -117,5 +149,9 @@ int main(int argc, char** argv) {
     run<0>("mfma_f32_32x32x2  2 waves/SIMD", 512, seconds, in, out, stamps);
     run<1>("mfma_f32_16x16x4  1 wave/SIMD", 256, seconds, in, out, stamps);
     run<1>("mfma_f32_16x16x4  2 waves/SIMD", 512, seconds, in, out, stamps);
+    run<2>("mfma_f32_32x32x16_f16  1 wave/SIMD", 256, seconds, in, out, stamps);
+    run<2>("mfma_f32_32x32x16_f16  2 waves/SIMD", 512, seconds, in, out, stamps);
+    run<3>("mfma_f32_32x32x16_bf16 1 wave/SIMD", 256, seconds, in, out, stamps);
+    run<3>("mfma_f32_32x32x16_bf16 2 waves/SIMD", 512, seconds, in, out, stamps);
     return 0;
 }
