@@ -1452,8 +1452,17 @@ __global__ __launch_bounds__(256) void filter_amax_kernel(const float* __restric
         const int n = blockIdx.y * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
         const int k0 = (int)(((long long)j * K) / H_KSK), k1 = (int)(((long long)(j + 1) * K) / H_KSK);
         float m = 0.0f;
-        if (n < Nn)
-            for (int k = k0 + rl; k < k1; k += 4) m = fmaxf(m, fabsf(w[((size_t)tap * K + k) * Nn + n]));
+        if (n < Nn) {
+            const float* src = w + (size_t)tap * K * Nn + n;
+            int k = k0 + rl;
+            for (; k + 28 < k1; k += 32) {          // eight rows in flight per thread (a row of 64 channels is one 256-byte request of the wave)
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) v[i] = fabsf(src[(size_t)(k + 4 * i) * Nn]);
+                m = fmaxf(m, fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7]))));
+            }
+            for (; k < k1; k += 4) m = fmaxf(m, fabsf(src[(size_t)k * Nn]));
+        }
         red[threadIdx.x] = m;
         __syncthreads();
         if (rl == 0 && n < Nn) partial[(size_t)blockIdx.x * Nn + n] = fmaxf(fmaxf(m, red[64 + threadIdx.x]), fmaxf(red[128 + threadIdx.x], red[192 + threadIdx.x]));
@@ -1528,14 +1537,9 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
 #ifndef IGAN_F16_LDS_PAD
 #define IGAN_F16_LDS_PAD 0
 #endif
-#ifndef IGAN_F16_NSTAGE
-#define IGAN_F16_NSTAGE 3
-#endif
-    constexpr int NS = (NP == 2) ? IGAN_F16_NSTAGE : P_NSTAGE;  // depth of the LDS ring: chunk c + NS - 1 is fetched while chunk c is consumed
-    static_assert(NS == 3 || NS == 4, "ring depth");
     constexpr int LPAD = (NP == 2) ? IGAN_F16_LDS_PAD : 0;     // experiment: pad the fp16 tile's LDS footprint (co-residency with other kernels)
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGE + 3 * BM * 4 + TABS + LPAD];
-    int* row_pix = reinterpret_cast<int*>(smem + NS * STAGE);
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[P_NSTAGE * STAGE + 3 * BM * 4 + TABS + LPAD];
+    int* row_pix = reinterpret_cast<int*>(smem + P_NSTAGE * STAGE);
     int* row_n = row_pix + BM;
     float* row_nz = reinterpret_cast<float*>(row_n + BM);
     float* tab_s = row_nz + BM;
@@ -1737,7 +1741,7 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
             }
         }
     }
-    if ((c_begin < c_end) && !(dm & 32)) { dma_chunk(0); dma_chunk(1); if constexpr (NS == 4) dma_chunk(2); }
+    if ((c_begin < c_end) && !(dm & 32)) { dma_chunk(0); dma_chunk(1); }
     if constexpr (NP == 2) {
 #pragma unroll
         for (int j = 0; j < 3; j++)
@@ -1777,77 +1781,6 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
         // and tile, and the epilogue stores 16 B per register quad.
         const float* tab_row = tab_s + wm * 64 + l31;
         if constexpr (TAPO) {
-#ifdef IGAN_F16_NESTED
-            // Taps outside, the tap's 16-channel slices inside: everything that changes with the tap only (the rows' scales, the fold of the cross terms) sits
-            // between the inner loops, and a step is straight-line code -- its two LDS-DMA instructions take their piece and LDS displacements from
-            // wave-uniform scalars instead of a branch per wave half.
-            int ct = (c_begin < c_end) ? c_begin / a.cpt : 0;                       // tap of the chunk being consumed
-            int cs = (c_begin < c_end) ? c_begin - ct * a.cpt : 0;                  // its first slice (non-zero only where a slice of the reduction starts inside a tap)
-            f32x16 u[TM];       // the cross terms p0a p1b + p1a p0b of the current tap, chained in the matrix pipe (2^-11 of the tap's sum)
-#pragma unroll
-            for (int tm = 0; tm < TM; tm++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) u[tm][r] = 0.0f;
-            const unsigned pcA = lowave ? 0u : 32u, pcB = lowave ? 32u : 0u;                                  // the piece each wave half fetches: bytes inside the (row, slice) unit
-            const unsigned ldA = (unsigned)(wave & 3) * 1024u + (lowave ? 0u : 4096u);                         // where it goes inside a stage
-            const unsigned ldB = (unsigned)IMG + (unsigned)(wave & 3) * 1024u + (lowave ? 4096u : 0u);
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");         // the scale table is published (no wait for the chunks in flight)
-            int c = (dm & 8) ? c_end : c_begin;
-            while (c < c_end) {
-                const int n_in = min(a.cpt - cs, c_end - c);
-                const float sc0 = tab_row[ct * BM], sc1 = tab_row[ct * BM + 32];
-                for (int i = 0; i < n_in; i++) {
-                    if (dm & 128) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");        // diagnostic: no barrier
-                    else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // chunk c landed (two younger instructions: chunk c + 1); stage st + 2 is free
-                    const int nst = st >= 1 ? st - 1 : NS - 1;
-                    const unsigned char* S = smem + st * STAGE;
-                    f16x8 a0[TM], a1[TM];
-                    const f16x8 b0 = __builtin_bit_cast(f16x8, *reinterpret_cast<const bf16x8*>(S + fb));
-                    const f16x8 b1 = __builtin_bit_cast(f16x8, *reinterpret_cast<const bf16x8*>(S + fb + 4096));
-#pragma unroll
-                    for (int tm = 0; tm < TM; tm++) {
-                        a0[tm] = __builtin_bit_cast(f16x8, *reinterpret_cast<const bf16x8*>(S + fa[tm]));
-                        a1[tm] = __builtin_bit_cast(f16x8, *reinterpret_cast<const bf16x8*>(S + fa[tm] + 4096));
-                    }
-                    dma_prep(nst);
-                    unsigned char* D = smem + nst * STAGE;
-                    const unsigned sB = __builtin_amdgcn_readfirstlane(soffB) + pcB;
-                    f32x16 t;           // one set of registers for the main term of both tiles
-                    const int nfold = (dm & 256) ? 1 : 16;          // diagnostic: one register of sixteen folded
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (dm & 512) t = zero;                         // diagnostic: no matrix instructions
-                    else {
-                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a0[0], zero, 0, 0, 0);       // main term: from an exact zero
-                    u[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1, a0[0], u[0], 0, 0, 0);
-                    u[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1, a0[1], u[1], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (!(dm & 32)) {            // chunk c + 2, issued inside the matrix cluster
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(D + ldA), 16, offA, pcA, 0, 0);
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(D + ldB), 16, voffB, sB, 0, 0);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 16; r++) if (r < nfold) acc[0][r] = __builtin_fmaf(t[r], sc0, acc[0][r]);        // vector ALU: round to nearest
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (!(dm & 512)) {
-                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a0[1], zero, 0, 0, 0);
-                    u[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a1[0], u[0], 0, 0, 0);
-                    u[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a1[1], u[1], 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 16; r++) if (r < nfold) acc[1][r] = __builtin_fmaf(t[r], sc1, acc[1][r]);
-                    st = (st + 1 == NS) ? 0 : st + 1;
-                }
-                // the tap (or this slice of the reduction) ends: its cross terms join the sum under the tap's scale
-                const float f0 = sc0 * (1.0f / 2048.0f), f1 = sc1 * (1.0f / 2048.0f);
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    acc[0][r] = __builtin_fmaf(u[0][r], f0, acc[0][r]); acc[1][r] = __builtin_fmaf(u[1][r], f1, acc[1][r]);
-                    u[0][r] = 0.0f; u[1][r] = 0.0f;
-                }
-                c += n_in; cs = 0; ++ct;
-            }
-#else
             int ct = (c_begin < c_end) ? c_begin / a.cpt : 0;                       // tap of the chunk being consumed
             int cs = (c_begin < c_end) ? c_begin - ct * a.cpt : 0;                  // its slice
             bool cs_new = true;
@@ -1858,9 +1791,8 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) u[tm][r] = 0.0f;
             for (int c = (dm & 8) ? c_end : c_begin; c < c_end; c++) {
-                if (dm & 128) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");        // diagnostic: no barrier
-                else if constexpr (NS == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // as below
-                const int nst = st >= 1 ? st - 1 : NS - 1;
+                asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // as below
+                const int nst = st >= 1 ? st - 1 : P_NSTAGE - 1;
                 const unsigned char* S = smem + st * STAGE;
                 f16x8 a0[TM], a1[TM];
                 const f16x8 b0 = __builtin_bit_cast(f16x8, *reinterpret_cast<const bf16x8*>(S + fb));
@@ -1873,26 +1805,20 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
                 if (cs_new) { sc0 = tab_row[ct * BM]; sc1 = tab_row[ct * BM + 32]; cs_new = false; }      // the rows' scales change with the tap only
                 dma_prep(nst);
                 f32x16 t;           // one set of registers for the main term of both tiles
-                const int nfold = (dm & 256) ? 1 : 16;          // diagnostic: one register of sixteen folded
                 __builtin_amdgcn_sched_barrier(0);
-                if (dm & 512) t = zero;                         // diagnostic: no matrix instructions
-                else {
                 t = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a0[0], zero, 0, 0, 0);       // main term: from an exact zero
                 u[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1, a0[0], u[0], 0, 0, 0);
                 u[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1, a0[1], u[1], 0, 0, 0);
-                }
                 __builtin_amdgcn_sched_barrier(0);
-                if (!(dm & 32)) { dma_piece(0); dma_piece(1); }            // chunk c + NS - 1, issued inside the matrix cluster
+                if (!(dm & 32)) { dma_piece(0); dma_piece(1); }            // chunk c + 2, issued inside the matrix cluster
 #pragma unroll
-                for (int r = 0; r < 16; r++) if (r < nfold) acc[0][r] = __builtin_fmaf(t[r], sc0, acc[0][r]);        // vector ALU: round to nearest
+                for (int r = 0; r < 16; r++) acc[0][r] = __builtin_fmaf(t[r], sc0, acc[0][r]);        // vector ALU: round to nearest
                 __builtin_amdgcn_sched_barrier(0);
-                if (!(dm & 512)) {
                 t = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a0[1], zero, 0, 0, 0);
                 u[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a1[0], u[0], 0, 0, 0);
                 u[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a1[1], u[1], 0, 0, 0);
-                }
 #pragma unroll
-                for (int r = 0; r < 16; r++) if (r < nfold) acc[1][r] = __builtin_fmaf(t[r], sc1, acc[1][r]);
+                for (int r = 0; r < 16; r++) acc[1][r] = __builtin_fmaf(t[r], sc1, acc[1][r]);
                 ++cs;
                 if (cs == a.cpt || c + 1 == c_end) {        // the tap (or this slice of the reduction) ends: its cross terms join the sum under the tap's scale
                     const float f0 = sc0 * (1.0f / 2048.0f), f1 = sc1 * (1.0f / 2048.0f);
@@ -1903,16 +1829,15 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
                     }
                     cs = 0; ++ct; cs_new = true;
                 }
-                st = (st + 1 == NS) ? 0 : st + 1;
+                st = (st + 1 == P_NSTAGE) ? 0 : st + 1;
             }
-#endif
         } else {
         int ct = (c_begin < c_end) ? c_begin - (c_begin / ntap) * ntap : 0;      // tap of the chunk being consumed (the reduction runs slice outermost, taps inside)
         for (int c = c_begin; c < c_end; c++) {
             // chunk c landed (two younger instructions: chunk c+1); stage st+2 is free.  lgkmcnt(0): the first barrier also publishes the scale table
             // (every wave's ds_write has completed before it arrives); later iterations have no LDS operation in flight at this point.
-            if constexpr (NS == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            const int nst = st >= 1 ? st - 1 : NS - 1;
+            asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            const int nst = st >= 1 ? st - 1 : P_NSTAGE - 1;
             const unsigned char* S = smem + st * STAGE;
             f16x8 a0[TM], a1[TM];
             const f16x8 b0 = __builtin_bit_cast(f16x8, *reinterpret_cast<const bf16x8*>(S + fb));
@@ -1942,7 +1867,7 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
             v = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a1[1], v, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[1][r] = __builtin_fmaf(__builtin_fmaf(v[r], 1.0f / 2048.0f, t[r]), sc1, acc[1][r]);
-            st = (st + 1 == NS) ? 0 : st + 1;
+            st = (st + 1 == P_NSTAGE) ? 0 : st + 1;
         }
         }
         drain_lds_dma();
@@ -2001,7 +1926,7 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
         // chunk c: issued two iterations ago (three instructions of this wave are younger: chunk c+1)
         asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
         // everyone has chunk c in stage st, and has finished reading stage st + 2 (chunk c-1): it is refilled with chunk c+2
-        const int nst = st >= 1 ? st - 1 : NS - 1;
+        const int nst = st >= 1 ? st - 1 : P_NSTAGE - 1;
         const unsigned char* S = smem + st * STAGE;
         bf16x8 af[TM][3], bfr[3];
         const unsigned char* S0 = S;
@@ -2031,7 +1956,7 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_planes_kernel(ConvArgs a) {
             }
 #pragma unroll
         for (int tm = 0; tm < TM; tm++) acc[tm] += t[tm];
-        st = (st + 1 == NS) ? 0 : st + 1;
+        st = (st + 1 == P_NSTAGE) ? 0 : st + 1;
     }
     }
     drain_lds_dma();
@@ -2348,6 +2273,368 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_wgr
 }
 
 // ------------------------------------------------------------------------------
+// The fp16 form's tile on FOUR waves (a wave owns 64 pixels x 64 channels: 2 x 2 matrix-instruction tiles, twelve products per 16-channel chunk), tap
+// outermost as conv_fwd_planes_kernel<2, true>, same images, same LDS stage layout, same products and folds per output element.  What changes is the
+// schedule: with 256 registers per lane the fragments of chunk c + 1 are read from LDS into a second register set right after the barrier that frees
+// chunk c's stage, while the matrix instructions of chunk c run from the set read one step earlier -- no LDS latency between a barrier and the first
+// product, the stage is free one step sooner (three chunks in flight behind the one consumed in a ring of three), eight fragment reads per twelve
+// products instead of six per six, and the per-step scalar work is shared by twice the products.  The fragment reads are written as instructions
+// (the compiler does not count them: the step's one `s_waitcnt lgkmcnt(0)` ahead of the barrier covers them, and it names the fragment registers as
+// its outputs so that no product moves above it).
+__global__ __launch_bounds__(256, 2) void conv_fwd_planes_w4_kernel(ConvArgs a) {
+    constexpr int BM = 128, BN = 128, NS = 3;
+    constexpr int IMG = 2 * 128 * 32, STAGE = 2 * IMG;          // one operand's LDS image [2 pieces][128 rows][32 B]; a stage = A + B
+    constexpr unsigned PB = 64u;                                // bytes of one (pixel, 16-channel slice) in a piece image
+    constexpr int TABS = 9 * BM * 4;                            // 1 / S of the input pixel each (tap, tile row) reads
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGE + 3 * BM * 4 + TABS];
+    int* row_pix = reinterpret_cast<int*>(smem + NS * STAGE);
+    int* row_n = row_pix + BM;
+    float* row_nz = reinterpret_cast<float*>(row_n + BM);
+    float* tab_s = row_nz + BM;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int up = 1 << a.up_shift;
+    auto stamp = [&](int k) {       // diagnostic only, as in conv_fwd_dma_kernel
+        if (a.diag != nullptr && (threadIdx.x >> 6) == 0) {
+            const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+            if ((threadIdx.x & 63) == 0) a.diag[(size_t)blockIdx.x * 4 + k] = t;
+        }
+    };
+    stamp(0);
+    int bid = blockIdx.x;
+    if (a.xcd_remap && bid < a.full_tiles) {        // placement as in conv_fwd_planes_kernel
+        const int per_class = a.nx * a.ny;
+        const int lo = (bid / per_class) * per_class;
+        const int cnt = min(per_class, a.full_tiles - lo);
+        bid = lo + remap_xcd(bid - lo, cnt);
+        if (cnt == per_class && a.ny > 1 && a.stride > 1) {
+            const int j = bid - lo;
+            bid = lo + (j % a.ny) * a.nx + j / a.ny;
+        }
+    }
+    const bool sliced = bid >= a.full_tiles;
+    const int tail = bid - a.full_tiles;
+    const int tile = sliced ? a.full_tiles + tail / a.splits : bid;
+    const int split = sliced ? tail % a.splits : 0;
+    const int nsplit = sliced ? a.splits : 1;
+    const int mt = tile % a.nx, nt = (tile / a.nx) % a.ny, cls = tile / (a.nx * a.ny);
+    const int py = cls >> a.up_shift, px = cls & (up - 1);
+    const int QH = (a.OH - py + up - 1) >> a.up_shift;
+    const int QW = (a.OW - px + up - 1) >> a.up_shift;
+    const int Mcls = a.N * QH * QW;
+    const int m0 = mt * BM;
+    if (m0 >= Mcls) return;
+    const int n0 = nt * BN;
+    const int ky0 = (a.pad_y - py * a.stride) & (up - 1);
+    const int kx0 = (a.pad_x - px * a.stride) & (up - 1);
+    const int nky = (ky0 < a.KH) ? ((a.KH - ky0 + up - 1) >> a.up_shift) : 0;
+    const int nkx = (kx0 < a.KW) ? ((a.KW - kx0 + up - 1) >> a.up_shift) : 0;
+    const int chunks = nky * nkx * a.cpt;                 // a.cpt = Cin / 16
+    const int c_begin = sliced ? (int)(((long long)split * chunks) / nsplit) : 0;
+    const int c_end = sliced ? (int)(((long long)(split + 1) * chunks) / nsplit) : chunks;
+    const bool any = c_begin < c_end;
+
+    const float inv_hw = 1.0f / (float)(QH * QW), inv_w = 1.0f / (float)QW;
+    // DMA lane geometry: a wave instruction fills 32 rows x 32 B of one piece image; wave w fetches rows 32 w .. 32 w + 31 of both pieces of both operands
+    // (four instructions per chunk); lane -> row 32 w + lane / 2, half (lane & 1) ^ ((row >> 3) & 1)
+    const int drow = 32 * wave + (lane >> 1);
+    const int dhalf = (lane & 1) ^ ((drow >> 3) & 1);
+    const int ntap = nky * nkx;
+    int ld_t0 = any ? c_begin / a.cpt : 0;
+    int ld_cc = any ? c_begin - ld_t0 * a.cpt : 0;
+    int ld_ta = any ? ld_t0 / nkx : 0;
+    int ld_tb = any ? ld_t0 - ld_ta * nkx : 0;
+    const unsigned xbytes = (unsigned)a.N * a.H * a.W * a.Cin * 4u, wbytes = (unsigned)a.KH * a.KW * a.Cin * a.Cout * 4u;   // host: both < OOB
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.xp), 0, (int)xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.wp), 0, (int)wbytes, 0x00020000);
+    const unsigned pixA = (unsigned)a.Cin * 4u;           // bytes per pixel
+    unsigned baseA, maskA = 0u, voffB;
+    {
+        const int m = m0 + drow;
+        const bool rok = m < Mcls;
+        const int mm = rok ? m : 0;
+        const int nn = div_small(mm, QH * QW, inv_hw);
+        const int r = mm - nn * (QH * QW);
+        const int qy = div_small(r, QW, inv_w), qx = r - qy * QW;
+        const int vy0 = (qy * up + py) * a.stride - a.pad_y + ky0, vx0 = (qx * up + px) * a.stride - a.pad_x + kx0;
+        const int iy0 = vy0 >> a.up_shift, ix0 = vx0 >> a.up_shift;
+        baseA = (unsigned)((nn * a.H + iy0) * a.W + ix0) * pixA + (unsigned)dhalf * 16u;     // modulo 2^32; exact for every valid tap
+        for (int ta = 0; ta < nky; ta++)
+            for (int tb = 0; tb < nkx; tb++) {
+                const int iy = iy0 + ta, ix = ix0 + tb;
+                const bool ok = rok & (iy >= 0) & (ix >= 0) & (iy < a.H) & (ix < a.W);
+                maskA |= ok ? (1u << (ta * nkx + tb)) : 0u;
+            }
+        const int co = n0 + drow;
+        voffB = (co < a.Cout) ? (unsigned)co * PB + (unsigned)dhalf * 16u : OOB;
+    }
+    unsigned offA = OOB, soffB = 0u;
+    typedef __attribute__((address_space(3))) void lds_void;
+    bool dma_fresh = true;
+    const unsigned sliceB = (unsigned)(a.KH * a.KW * a.Cout) * PB;          // bytes between two 16-channel slices of the filter image
+    auto dma_prep = [&]() {        // addresses of the next chunk, then one step forward in (tap, slice) order
+        if (dma_fresh || ld_cc == 0) {     // (wave-uniform) a full decode at the first chunk and at every tap start only
+            const unsigned disp = (unsigned)(ld_ta * a.W + ld_tb) * pixA + (unsigned)ld_cc * PB;
+            const unsigned bit = 1u << (ld_ta * nkx + ld_tb);
+            offA = (maskA & bit) ? baseA + disp : OOB;
+            const int ky = ky0 + (ld_ta << a.up_shift), kx = kx0 + (ld_tb << a.up_shift);
+            soffB = __builtin_amdgcn_readfirstlane((unsigned)((ld_cc * (a.KH * a.KW) + ky * a.KW + kx) * a.Cout) * PB);
+            dma_fresh = false;
+        } else {        // the next slice of the same tap: both operands one slice further (an out-of-range marker stays out of range)
+            offA += PB;
+            soffB = __builtin_amdgcn_readfirstlane(soffB + sliceB);
+        }
+        ++ld_cc;
+        const int w1 = (ld_cc == a.cpt) ? 1 : 0;
+        ld_cc = w1 ? 0 : ld_cc;
+        ld_tb += w1;
+        const int w2 = (ld_tb == nkx) ? 1 : 0;
+        ld_tb = w2 ? 0 : ld_tb;
+        ld_ta += w2;
+    };
+    auto dma_pair = [&](int stage, int which) {       // which 0: the A pieces, 1: the B pieces of the chunk prepared last (the piece displacement rides in the scalar offset)
+        unsigned char* D = smem + stage * STAGE + wave * 1024;
+        if (which == 0) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)D, 16, offA, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(D + 4096), 16, offA, 32, 0, 0);
+        } else {
+            const unsigned sB = __builtin_amdgcn_readfirstlane(soffB);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(D + IMG), 16, voffB, sB, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(D + IMG + 4096), 16, voffB, sB + 32u, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+    // 1 / S of the input pixel that tile row r reads under tap t, fetched BEFORE the first DMA instructions (vmcnt counts in order) and stored to LDS behind them
+    float tabv[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    {
+        const float* rowinv = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.xp) + (size_t)a.N * a.H * a.W * a.Cin * 4);
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            const int i = tid + 256 * j;
+            const int t = i >> 7, r = i & 127;
+            if (t < ntap) {
+                const int ta = t / nkx, tb = t - ta * nkx;
+                const int m = m0 + r;
+                const bool rok = m < Mcls;
+                const int mm = rok ? m : 0;
+                const int nn = div_small(mm, QH * QW, inv_hw);
+                const int rr = mm - nn * (QH * QW);
+                const int qy = div_small(rr, QW, inv_w), qx = rr - qy * QW;
+                const int iy = (((qy * up + py) * a.stride - a.pad_y + ky0) >> a.up_shift) + ta, ix = (((qx * up + px) * a.stride - a.pad_x + kx0) >> a.up_shift) + tb;
+                if (rok & (iy >= 0) & (ix >= 0) & (iy < a.H) & (ix < a.W)) tabv[j] = rowinv[(nn * a.H + iy) * a.W + ix];
+            }
+        }
+    }
+    if (any) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) { dma_prep(); dma_pair(j, 0); dma_pair(j, 1); }      // chunks 0, 1, 2 of this tile's range
+    }
+#pragma unroll
+    for (int j = 0; j < 5; j++)
+        if (tid + 256 * j < 9 * BM) tab_s[tid + 256 * j] = tabv[j];
+    if (tid < BM) {     // the epilogue's row tables, computed while the first chunks are in flight
+        const int m = m0 + tid;
+        int pix = -1, nn = 0;
+        if (m < Mcls) {
+            nn = div_small(m, QH * QW, inv_hw);
+            const int r = m - nn * (QH * QW);
+            const int qy = div_small(r, QW, inv_w), qx = r - qy * QW;
+            pix = (nn * a.OH + (qy * up + py)) * a.OW + (qx * up + px);
+        }
+        row_pix[tid] = pix;
+        row_n[tid] = nn;
+        row_nz[tid] = noise_term(a, pix);
+    }
+    // fragment addresses (LDS bytes): row r of an image sits at [piece][2 r + (half ^ ((r >> 3) & 1))] x 16 B; the second tile of a wave is 32 rows = 1 KiB further
+    const unsigned lds0 = (unsigned)(unsigned long long)(lds_void*)smem;
+    const int ra = wm * 64 + l31, rb = wn * 64 + l31;
+    const unsigned fa = lds0 + (unsigned)(2 * ra + (h ^ ((ra >> 3) & 1))) * 16u;
+    const unsigned fb = lds0 + (unsigned)IMG + (unsigned)(2 * rb + (h ^ ((rb >> 3) & 1))) * 16u;
+    stamp(1);
+
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    struct Frag { f16x8 a0[2], a1[2], b0[2], b1[2]; };       // pieces 0 / 1 of the wave's two pixel tiles and two channel tiles
+    auto read_frags = [&](Frag& f, int stage) {              // eight 16-byte LDS reads, not waited for here
+        const unsigned va = fa + (unsigned)(stage * STAGE), vb = fb + (unsigned)(stage * STAGE);
+        asm volatile("ds_read_b128 %0, %1" : "=v"(f.b0[0]) : "v"(vb));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(f.a0[0]) : "v"(va));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(f.b1[0]) : "v"(vb));
+        asm volatile("ds_read_b128 %0, %1 offset:5120" : "=v"(f.b1[1]) : "v"(vb));
+        asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(f.a0[1]) : "v"(va));
+        asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(f.b0[1]) : "v"(vb));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(f.a1[0]) : "v"(va));
+        asm volatile("ds_read_b128 %0, %1 offset:5120" : "=v"(f.a1[1]) : "v"(va));
+    };
+    // The accumulators hold the tile transposed (the FILTER fragment is the matrix instruction's first operand): a lane owns ONE pixel row (l31) of each
+    // of its two pixel tiles, its 16 registers of a tile are output channels (r & 3) + 8 (r >> 2) + 4 h of the tile's 32.
+    const float* tab_row = tab_s + wm * 64 + l31;
+    f32x16 u[2][2];     // the cross terms p0a p1b + p1a p0b of the current tap, chained in the matrix pipe (2^-11 of the tap's sum)
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) u[i][j][r] = 0.0f;
+    int st = 0;                                       // stage of the chunk being consumed
+    int ct = any ? c_begin / a.cpt : 0;               // its tap
+    int cs = any ? c_begin - ct * a.cpt : 0;          // its slice
+    float sc0 = 0.0f, sc1 = 0.0f;
+    Frag F0, F1;
+    auto fold = [&](f32x16& dst, const f32x16& t, float s) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) dst[r] = __builtin_fmaf(t[r], s, dst[r]);        // vector ALU: round to nearest
+    };
+    // TAIL: the last chunk of an odd count -- nothing is fetched behind it (a read into registers that nothing uses afterwards would land in whatever the
+    // compiler keeps there by then: every fragment read here is into a set that a later `s_waitcnt` names)
+    auto step = [&](Frag& cur, Frag& nxt, int c, auto tail) {
+        constexpr bool TAIL = decltype(tail)::value;
+        int st1 = st;
+        if constexpr (TAIL) {
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(cur.a0[0]), "+v"(cur.a0[1]), "+v"(cur.a1[0]), "+v"(cur.a1[1]), "+v"(cur.b0[0]), "+v"(cur.b0[1]), "+v"(cur.b1[0]), "+v"(cur.b1[1]) :: "memory");
+        } else {
+            // chunk c + 1 has landed (one younger chunk of four instructions in flight); this wave's reads of chunk c (issued one step ago) are in `cur`;
+            // behind the barrier every wave has read chunk c: its stage takes chunk c + 3
+            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier"
+                         : "+v"(cur.a0[0]), "+v"(cur.a0[1]), "+v"(cur.a1[0]), "+v"(cur.a1[1]), "+v"(cur.b0[0]), "+v"(cur.b0[1]), "+v"(cur.b1[0]), "+v"(cur.b1[1]) :: "memory");
+            st1 = (st + 1 == NS) ? 0 : st + 1;
+            read_frags(nxt, st1);
+            dma_prep();
+        }
+        // Twelve products; the main term of a tile starts from an exact zero in one of two register sets and is folded by the vector ALU while the NEXT
+        // main term runs in the matrix pipe (its own instruction has had two cross-term products to finish by then).
+        f32x16 tA, tB;
+        const auto SB = [] { __builtin_amdgcn_sched_barrier(0); };
+        SB();
+        tA = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.b0[0], cur.a0[0], zero, 0, 0, 0);          // tile (0, 0)
+        SB();
+        u[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.b1[0], cur.a0[0], u[0][0], 0, 0, 0);
+        u[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.b1[1], cur.a0[0], u[0][1], 0, 0, 0);
+        SB();
+        if constexpr (!TAIL) dma_pair(st, 0);
+        SB();
+        tB = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.b0[1], cur.a0[0], zero, 0, 0, 0);          // (0, 1)
+        SB();
+        fold(acc[0][0], tA, sc0);
+        SB();
+        u[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.b1[0], cur.a0[1], u[1][0], 0, 0, 0);
+        u[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.b1[1], cur.a0[1], u[1][1], 0, 0, 0);
+        SB();
+        if constexpr (!TAIL) dma_pair(st, 1);
+        SB();
+        tA = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.b0[0], cur.a0[1], zero, 0, 0, 0);          // (1, 0)
+        SB();
+        fold(acc[0][1], tB, sc0);
+        SB();
+        u[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.b0[0], cur.a1[0], u[0][0], 0, 0, 0);
+        u[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.b0[1], cur.a1[0], u[0][1], 0, 0, 0);
+        SB();
+        tB = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.b0[1], cur.a0[1], zero, 0, 0, 0);          // (1, 1)
+        SB();
+        fold(acc[1][0], tA, sc1);
+        SB();
+        u[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.b0[0], cur.a1[1], u[1][0], 0, 0, 0);
+        u[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.b0[1], cur.a1[1], u[1][1], 0, 0, 0);
+        SB();
+        fold(acc[1][1], tB, sc1);
+        ++cs;
+        if (cs == a.cpt || c + 1 == c_end) {        // the tap (or this slice of the reduction) ends: its cross terms join the sum under the tap's scale
+            const float f0 = sc0 * (1.0f / 2048.0f), f1 = sc1 * (1.0f / 2048.0f);
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                fold(acc[0][j], u[0][j], f0); fold(acc[1][j], u[1][j], f1);
+#pragma unroll
+                for (int r = 0; r < 16; r++) { u[0][j][r] = 0.0f; u[1][j][r] = 0.0f; }
+            }
+            cs = 0; ++ct;
+            const int tn_ = min(ct, ntap - 1);
+            sc0 = tab_row[tn_ * BM]; sc1 = tab_row[tn_ * BM + 32];       // the next tap's scales (behind the barriers that published the table)
+        }
+        st = st1;
+    };
+    if (any) {
+        // chunk 0 has landed (two younger chunks in flight), the scale table is stored: publish both, then the first fragments and scales
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        read_frags(F0, 0);
+        sc0 = tab_row[ct * BM]; sc1 = tab_row[ct * BM + 32];
+        int c = c_begin;
+        for (; c + 1 < c_end; c += 2) { step(F0, F1, c, std::false_type()); step(F1, F0, c + 1, std::false_type()); }
+        if (c < c_end) step(F0, F1, c, std::true_type());
+        else            // an even count: the set read behind the last chunk stays named until its reads have landed
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(F0.a0[0]), "+v"(F0.a0[1]), "+v"(F0.a1[0]), "+v"(F0.a1[1]), "+v"(F0.b0[0]), "+v"(F0.b0[1]), "+v"(F0.b1[0]), "+v"(F0.b1[1]) :: "memory");
+    }
+    drain_lds_dma();
+    stamp(2);
+    // ---- epilogue of the transposed tiles: every register quad is four consecutive output channels of the lane's pixel ----
+    const float* winv = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.wp) + (size_t)a.KH * a.KW * a.Cin * a.Cout * 4);
+    if (sliced && nsplit > 1) {
+        float* wst = a.y + ((size_t)(tile - a.full_tiles) * a.splits + split) * (BM * BN);
+#pragma unroll
+        for (int tn = 0; tn < 2; tn++) {
+            const int cq = n0 + wn * 64 + tn * 32 + 4 * h;
+            float4 wi[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) wi[q] = (cq + 8 * q < a.Cout) ? *reinterpret_cast<const float4*>(winv + cq + 8 * q) : f4zero();
+#pragma unroll
+            for (int tm = 0; tm < 2; tm++) {
+                const int row = wm * 64 + tm * 32 + l31;
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    *reinterpret_cast<float4*>(wst + row * BN + wn * 64 + tn * 32 + 8 * q + 4 * h) =
+                        make_float4(acc[tm][tn][4 * q] * wi[q].x, acc[tm][tn][4 * q + 1] * wi[q].y, acc[tm][tn][4 * q + 2] * wi[q].z, acc[tm][tn][4 * q + 3] * wi[q].w);
+            }
+        }
+        return;
+    }
+    __syncthreads();        // the row tables
+    const bool scale = a.out_scale != nullptr;
+    const float alpha = a.alpha;
+#pragma unroll
+    for (int tn = 0; tn < 2; tn++) {
+        const int cq = n0 + wn * 64 + tn * 32 + 4 * h;        // channel of register quad q: cq + 8 q
+        float4 wi[4], bia[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            wi[q] = (cq + 8 * q < a.Cout) ? *reinterpret_cast<const float4*>(winv + cq + 8 * q) : f4zero();     // Cout % 4 == 0 (host)
+            bia[q] = (a.act && a.bias && cq + 8 * q < a.Cout) ? *reinterpret_cast<const float4*>(a.bias + cq + 8 * q) : f4zero();
+        }
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++) {
+            const int row = wm * 64 + tm * 32 + l31;
+            const int pix = row_pix[row];
+            if (pix < 0) continue;
+            const float* osc = a.out_scale + (size_t)row_n[row] * a.Cout;
+            const float nz = row_nz[row];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int co = cq + 8 * q;
+                if (co >= a.Cout) continue;
+                float4 o = make_float4(acc[tm][tn][4 * q] * wi[q].x, acc[tm][tn][4 * q + 1] * wi[q].y, acc[tm][tn][4 * q + 2] * wi[q].z, acc[tm][tn][4 * q + 3] * wi[q].w);
+                o.x *= alpha; o.y *= alpha; o.z *= alpha; o.w *= alpha;
+                if (scale) { const float4 d = *reinterpret_cast<const float4*>(osc + co); o.x *= d.x; o.y *= d.y; o.z *= d.z; o.w *= d.w; }
+                if (a.act) {
+                    o.x = epi_act(a.act, o.x + nz + bia[q].x, a.act_alpha) * a.act_gain; o.y = epi_act(a.act, o.y + nz + bia[q].y, a.act_alpha) * a.act_gain;
+                    o.z = epi_act(a.act, o.z + nz + bia[q].z, a.act_alpha) * a.act_gain; o.w = epi_act(a.act, o.w + nz + bia[q].w, a.act_alpha) * a.act_gain;
+                }
+                *reinterpret_cast<float4*>(a.out + (size_t)pix * a.Cout + co) = o;
+            }
+        }
+    }
+    stamp(3);
+}
+
 // Weight gradient in bf16-piece form (IGAN_CONV_PLANES=1; the arithmetic of conv_fwd_planes_kernel).  GEMM view as in
 // conv_wgrad_kernel: M = 128 input channels, N = 128 output channels, K = the pixels of the tap's parity class, 16 per step.
 // Both operands are read ALONG the pixel axis, which the piece images ([pixel][C/16][piece][16]) do not have contiguous: a stage
@@ -2857,13 +3144,16 @@ void launch_filter_image(hipStream_t stream, const float* w, unsigned short* wp,
 
 // Does this launch take the bf16-piece form (conv_fwd_planes_kernel)?  the form switched on, the 128x128 tile, Cin % 32 == 0, both
 // piece images addressable with 32-bit offsets below the out-of-range marker -- and a reduction deep enough to pay for writing
-// the piece images: 3x3 taps on at least 128 channels (taps * Cin >= 1152) over at least 2048 output rows.  Measured per layer
-// (tools/conv_layers.py): the 1x1 Skip convolutions and the 4x4 / 8x8 layers lose (D 128 Skip 77 -> 220 us), everything from
-// 16x16 Conv1 up gains.  planes_shape_ok() is what the PLAN sizes the workspace by (shapes only: plans are cached per shape);
-// the launch also needs 16 B aligned operands.
+// the piece images: 3x3 taps on at least 128 channels (taps * Cin >= 1152) over at least 1024 output rows.  Measured per layer
+// (tools/conv_layers.py): the 1x1 Skip convolutions and the 4x4 layers lose (D 128 Skip 77 -> 220 us), everything from 8x8 Conv1 at 24 samples
+// (1536 rows) up gains.  Round 5 (fp16 form, three products and a quicker filter image): the 8x8 layers at 24 samples forward 78 -> 70, data
+// gradient 78 -> 58, weight gradient 93 -> 71 us, G 16 Conv0_up forward 153 -> 92 us, 384-row layers (4x4, 8 -> 4) lose 33 -> 53 us; bench +1.2 %
+// at 1024 rows, the same at 512 (profiles/r05_small_layers.txt).  IGAN_PLANES_MIN_ROWS / IGAN_WGRAD_PLANES_MIN_ROWS move the two thresholds.
+// planes_shape_ok() is what the PLAN sizes the workspace by (shapes only: plans are cached per shape); the launch also needs 16 B aligned operands.
 bool planes_shape_ok(const igan_conv2d_params* p, const FwdTile& t, int Mmax) {
     if (!planes_enabled() || t.BM != 128 || t.BN != 128 || p->Cin % BK != 0) return false;
-    if (p->KH * p->KW == 1 || (long long)p->KH * p->KW * p->Cin < 1152 || Mmax < 2048) return false;      // 1x1: the Skip layers and the nearest-neighbour distance GEMM stay on the fp32 instruction
+    static const int min_rows = getenv("IGAN_PLANES_MIN_ROWS") ? atoi(getenv("IGAN_PLANES_MIN_ROWS")) : 1024;
+    if (p->KH * p->KW == 1 || (long long)p->KH * p->KW * p->Cin < 1152 || Mmax < min_rows) return false;      // 1x1: the Skip layers and the nearest-neighbour distance GEMM stay on the fp32 instruction
     if ((long long)p->N * p->OH * p->OW >= (1LL << 24)) return false;
     if ((long long)p->N * p->H * p->W * p->Cin * 6 >= 0x7FFFFF00LL || (long long)p->KH * p->KW * p->Cin * p->Cout * 6 >= 0x7FFFFF00LL) return false;
     // fp16 form: the pixel's scale is shared by shuffles among the Cin / 16 threads of a pixel (a power of two within one wave), the kernel's scale
@@ -3122,7 +3412,9 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
             // (Cin 128), 451.4 -> 428.0 us on G 32 Conv1 (Cin 512); whole layer list forward 186.0 -> 194.4, data gradient 189.2 -> 198.0 TFLOP/s.
             static const int force = getenv("IGAN_F16_TAP_OUTER") ? atoi(getenv("IGAN_F16_TAP_OUTER")) : 1;
             const bool tapo = force != 0;
-            if (tapo) hipLaunchKernelGGL((conv_fwd_planes_kernel<2, true>), grid, dim3(512), 0, stream, a);
+            static const int w4 = getenv("IGAN_F16_W4") ? atoi(getenv("IGAN_F16_W4")) : 1;       // the four-wave tile (register-pipelined fragments); 0: the eight-wave tile
+            if (tapo && w4) hipLaunchKernelGGL(conv_fwd_planes_w4_kernel, grid, dim3(256), 0, stream, a);
+            else if (tapo) hipLaunchKernelGGL((conv_fwd_planes_kernel<2, true>), grid, dim3(512), 0, stream, a);
             else hipLaunchKernelGGL((conv_fwd_planes_kernel<2, false>), grid, dim3(512), 0, stream, a);
         } else hipLaunchKernelGGL((conv_fwd_planes_kernel<3>), grid, dim3(512), 0, stream, a);
         IGAN_LAUNCH_CHECK("conv2d (piece form) launch");
@@ -3254,7 +3546,8 @@ bool wgrad_planes_shape_ok(const igan_conv2d_wgrad_params* p) {
         if (kind && kind[0] == 'u' && p->up != 2) return false;
     }
 #endif
-    if ((long long)p->N * p->OH * p->OW < 2048 * (long long)p->up * p->up) return false;
+    static const int wmin_rows = getenv("IGAN_WGRAD_PLANES_MIN_ROWS") ? atoi(getenv("IGAN_WGRAD_PLANES_MIN_ROWS")) : 1024;
+    if ((long long)p->N * p->OH * p->OW < wmin_rows * (long long)p->up * p->up) return false;
     if ((long long)p->N * p->H * p->W * p->Cin * 6 >= 0x7FFFFF00LL || (long long)p->N * p->OH * p->OW * p->Cout * 6 >= 0x7FFFFF00LL) return false;
     // fp16 form: the column-maximum pass gives every thread one channel quad (C / 4 a power of two <= 256)
     if (planes_mode() == 2 && (!pow2(p->Cin) || !pow2(p->Cout) || p->Cin > 1024 || p->Cout > 1024)) return false;
