@@ -3124,6 +3124,9 @@ void launch_col_image(hipStream_t stream, const float* x, const float* scale, un
         hipLaunchKernelGGL(cols_finalize_kernel, dim3(igan::ceil_div(C, 8)), dim3(256), 0, stream, colmax + 4, inv, sc, 0, C, colmax);
     hipLaunchKernelGGL(cols_f16_kernel, dim3(igan::ceil_div(total, 256)), dim3(256), 0, stream, x, scale, out, (const float*)sc, total, cpp, C, HW);
 }
+// A/B switches inside the fp16 form's forward / data-gradient tile: IGAN_F16_TAP_OUTER=0 the slice-outermost reduction, IGAN_F16_W4=0 the eight-wave tile
+bool f16_tap_outer() { static const int v = getenv("IGAN_F16_TAP_OUTER") ? atoi(getenv("IGAN_F16_TAP_OUTER")) : 1; return v != 0; }
+bool f16_w4() { static const int v = getenv("IGAN_F16_W4") ? atoi(getenv("IGAN_F16_W4")) : 1; return v != 0; }
 void launch_filter_image(hipStream_t stream, const float* w, unsigned short* wp, bool wt, int taps, int KW_, int Nn, int K) {
     const int wtotal = taps * Nn * (K / PK);
     if (planes_mode() == 2) {
@@ -3282,7 +3285,7 @@ extern "C" int igan_conv2d_kernel_name(const igan_conv2d_params* p, char* buf, i
     const bool vecB = ((wt ? p->Cin : p->Cout) % 4 == 0) && (((uintptr_t)p->w & 15) == 0);
     const bool vec = vecA && vecB && (p->in_scale == nullptr || vecS);
     if (use_planes_kernel(p, t, Mmax)) {
-        snprintf(buf, (size_t)buflen, "conv_fwd_planes_kernel");
+        snprintf(buf, (size_t)buflen, (planes_mode() == 2 && f16_tap_outer() && f16_w4()) ? "conv_fwd_planes_w4_kernel" : "conv_fwd_planes_kernel");
         return IGAN_OK;
     }
     if (use_dma_kernel(p, t, walk_ok(p))) {
@@ -3402,6 +3405,8 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
             else launch_piece_image(stream, p->x, p->in_scale, own, p->N * p->H * p->W, p->H * p->W, p->Cin);
             xp = own;
         }
+        // (the filter image beside the x image on a second stream, forked and joined by events -- two branches inside the captured graphs -- is correct and
+        // 5.6 % SLOWER in the bench: 333.9 -> 315.1 img/s, profiles/r05_small_layers.txt section 3)
         if (!(a.diag_mode & 1)) launch_filter_image(stream, p->w, wp, wt, p->KH * p->KW, p->KW, p->Cout, p->Cin);
         a.xp = xp; a.wp = wp;
         a.cpt = cpp;
@@ -3410,10 +3415,8 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
             // reduction order of the fp16 form (see the kernel): tap outermost (the cross terms are folded once per tap); A/B switch IGAN_F16_TAP_OUTER=0:
             // slice outermost, every step folds its cross terms.  Measured (profiles/r05_f16_rowscale.txt): kernel 490.6 -> 457.2 us on G 128 Conv1
             // (Cin 128), 451.4 -> 428.0 us on G 32 Conv1 (Cin 512); whole layer list forward 186.0 -> 194.4, data gradient 189.2 -> 198.0 TFLOP/s.
-            static const int force = getenv("IGAN_F16_TAP_OUTER") ? atoi(getenv("IGAN_F16_TAP_OUTER")) : 1;
-            const bool tapo = force != 0;
-            static const int w4 = getenv("IGAN_F16_W4") ? atoi(getenv("IGAN_F16_W4")) : 1;       // the four-wave tile (register-pipelined fragments); 0: the eight-wave tile
-            if (tapo && w4) hipLaunchKernelGGL(conv_fwd_planes_w4_kernel, grid, dim3(256), 0, stream, a);
+            const bool tapo = f16_tap_outer();
+            if (tapo && f16_w4()) hipLaunchKernelGGL(conv_fwd_planes_w4_kernel, grid, dim3(256), 0, stream, a);       // the four-wave tile (fragments of the next chunk prefetched into registers): whole calls 4-5 % shorter, bench +1.1 % (profiles/r05_w4_tile.txt)
             else if (tapo) hipLaunchKernelGGL((conv_fwd_planes_kernel<2, true>), grid, dim3(512), 0, stream, a);
             else hipLaunchKernelGGL((conv_fwd_planes_kernel<2, false>), grid, dim3(512), 0, stream, a);
         } else hipLaunchKernelGGL((conv_fwd_planes_kernel<3>), grid, dim3(512), 0, stream, a);

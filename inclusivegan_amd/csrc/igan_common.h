@@ -29,6 +29,12 @@ inline int check_hip(hipError_t e, const char* what) {
         if (e__ != hipSuccess) return ::igan::check_hip(e__, what); \
     } while (0)
 
+#define IGAN_HIP_CHECK(call, what)                                \
+    do {                                                          \
+        hipError_t e__ = (call);                                  \
+        if (e__ != hipSuccess) return ::igan::check_hip(e__, what); \
+    } while (0)
+
 // dense_small.hip: small-batch (M <= 32 rows) dense layers, dispatched from igan_conv2d / igan_conv2d_wgrad
 bool dense_small_ok(int M, int K, const void* x, const void* w, bool wt);
 int dense_small_rows(int M);
