@@ -157,8 +157,12 @@ def headline_shape_roofline(device, batch, reps=40, warm_s=0.4):
     flops = 2.0 * batch * res * res * cout * cin * 9
     achieved = flops / (ms * 1e-3) / 1e12
     peak = piece_form_peak() if piece_form_on() else F32_MATRIX_PEAK_TFLOPS
+    hip_ops.launch_log = names = []          # the tile kernel this call runs, as the library names it (igan_conv2d_kernel_name)
+    hip_ops.conv2d_raw(x, w, geom, (res, res), cout, in_scale=s, out_scale=d)
+    hip_ops.launch_log = None
+    tile_kernel = names[0][0]
     out = dict(shape='modulated conv 128x128 3x3 Cin=Cout=128 batch %d (M=%d N=128 K=1152)' % (batch, batch * res * res),
-               kernel='conv_fwd_planes_kernel (whole call: x image + filter image + tile kernel)' if piece_form_on() else 'conv_fwd_dma_kernel<false, true>',
+               kernel=(tile_kernel + ' (whole call: x image + filter image + tile kernel)') if piece_form_on() else 'conv_fwd_dma_kernel<false, true>',
                achieved=round(achieved, 2), peak=round(peak, 1), frac=round(achieved / peak, 4),
                flops_per_launch=flops, us_per_launch=round(ms * 1e3, 1), traffic=None)
     # HBM-side bytes per launch of this shape from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled per

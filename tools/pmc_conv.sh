@@ -11,7 +11,7 @@ cd /tmp
 run() {  # name, counters..., env prefix handled by caller
   name=$1; shift
   rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pmc_$name -- python3 $R/tools/kernel_bench.py conv $B 5 > /tmp/pmc_$name.log 2>&1
-  python3 $R/tools/pmc_summary.py /tmp/pmc_$name conv_fwd > $OUT/pmc_$name.txt 2>&1
+  python3 $R/tools/pmc_summary.py /tmp/pmc_$name conv_fwd rows_f16 filter_amax filter_planes to_planes > $OUT/pmc_$name.txt 2>&1      # the tile kernel and the image kernels of the same call
 }
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT
 run sq2 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16

@@ -36,14 +36,14 @@ def family(name):
 
 def main():
     tag = sys.argv[1]
-    dominant = family(sys.argv[2]) if len(sys.argv) > 2 else 'conv_fwd_planes_kernel'
+    dominant = family(sys.argv[2]) if len(sys.argv) > 2 else 'conv_fwd_planes_w4_kernel'
     d = os.path.join(ROOT, 'gpurun_out', 'prof_' + tag, 'pmc')
     P = lambda n: parse(os.path.join(d, 'pmc_%s.txt' % n))
     sha_path = os.path.join(d, 'kernel_source_sha16.json')
     sha = json.load(open(sha_path)) if os.path.exists(sha_path) else {}
     sq1, sq2, sq3 = P('sq1'), P('sq2'), P('sq3')
     # the headline call is several kernels in the piece form (images + tile kernel): the figures below are the TILE kernel's
-    tile = [k for (k, c) in sq1 if 'to_planes' not in k and 'filter_planes' not in k and 'fixup' not in k]
+    tile = [k for (k, c) in sq1 if k.startswith('conv_fwd')]
     kname = norm(tile[0])
     one = lambda tab, ctr: next(v[1] for (k, c), v in tab.items() if c == ctr and norm(k) == kname)
     call_sum = lambda tab, ctr: sum(v[1] for (k, c), v in tab.items() if c == ctr)          # whole call (the launches run 1:1)
