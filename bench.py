@@ -172,6 +172,20 @@ def headline_shape_roofline(device, batch, reps=40, warm_s=0.4):
     return out
 
 
+def sustained_instruction_rate(kind):
+    """tools/mfma_rate's line for v_mfma_f32_32x32x16_<kind> (bare register loop on random operands, two waves per SIMD, in-kernel clock) from the newest
+    committed profiles/rNN_mfma_rate.txt: the clock the chip settles at under that instruction, and the rate at that clock."""
+    import re
+    path = _latest_profile('mfma_rate.txt')
+    if not path:
+        return None
+    for line in open(path):
+        m = re.match(r'mfma_f32_32x32x16_%s\s+2 waves/SIMD.*after [\d.]+ s\s+([\d.]+) TFLOP/s\s+in-kernel clock (\d+) MHz' % kind, line)
+        if m:
+            return dict(instruction='v_mfma_f32_32x32x16_%s' % kind, tflops=float(m.group(1)), clock_mhz=int(m.group(2)), source=os.path.basename(path))
+    return None
+
+
 def _latest_profile(suffix):
     """profiles/rNN_<suffix> of the highest round present (evidence files are named per round)."""
     import glob
@@ -263,6 +277,11 @@ def step_roofline(stamp, steps, shapes_file=None):
             f.write('# per family: ' + '; '.join('%s %.1f ms %.1f TFLOP/s' % (k, v[2] * 1e3, v[1] / v[2] / 1e12) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][2])) + '\n')
     out = dict(bound='mfma', **entry(name))
     out['peak_note'] = ('%s dense peak %.0f / %d piece products (fp32-equivalent)' % ('fp16' if piece_form() == 2 else 'bf16', BF16_DENSE_PEAK_TFLOPS, piece_products())) if 'planes' in name else 'f32 matrix peak (v_mfma_f32_32x32x2_f32)'
+    if 'planes' in name:        # what the piece products' matrix instruction itself sustains on this chip (committed measurement, not a live one): context for `frac`, never the `peak`
+        sus = sustained_instruction_rate('f16' if piece_form() == 2 else 'bf16')
+        if sus is not None:
+            out['matrix_instruction_sustained'] = dict(sus, fp32_equivalent_tflops=round(sus['tflops'] / piece_products(), 1),
+                                                       frac_of_sustained=round(out['achieved'] / (sus['tflops'] / piece_products()), 4))
     out['conv_family_tflops'] = round(fam_flops / max(fam_secs, 1e-12) / 1e12, 2)
     out['conv_family_ms_per_iteration'] = round(fam_secs * 1e3 / max(replays.values()), 3)
     out['timing'] = 'device stamps inside the replayed hipGraphs'

@@ -3,7 +3,7 @@
 # build whose weight-gradient kernel issues its LDS-DMA through the compiler builtin (-DIGAN_WGRAD_ASM_DMA=0: the build that was unfaithful in round 4).
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 O=gpurun_out/r5d; mkdir -p $O
-make -C inclusivegan_amd/csrc variant VARIANT=builtindma DEFS=-DIGAN_WGRAD_ASM_DMA=0 > $O/build.txt 2>&1
+[ -f inclusivegan_amd/csrc/libigan_hip_builtindma.so ] || make -C inclusivegan_amd/csrc variant VARIANT=builtindma DEFS=-DIGAN_WGRAD_ASM_DMA=0 > $O/build.txt 2>&1      # built here when the snapshot did not bring it
 run() {   # $1 label, $2 lib or ""
   for i in 1 2 3; do
     if [ -n "$2" ]; then export IGAN_LIB=$2; else unset IGAN_LIB; fi
