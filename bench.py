@@ -640,7 +640,7 @@ def main():
             out['roofline']['hbm_kernel'] = hbm_kernel_roofline(device, B)
         if world == 1 and not args.no_cpu_baseline:
             log('timing the CPU oracle baseline')
-            out['cpu_baseline'] = cpu_baseline_subprocess(args.resolution, 2 if args.resolution >= 128 else B, args.lpips_weight)
+            out["cpu_baseline"] = cpu_baseline_subprocess(args.resolution, B, args.lpips_weight)        # the GPU line's own minibatch_gpu (round 5; 2 until then)
             knn = out['cpu_baseline'].get('knn')
             if isinstance(knn, dict) and knn.get('value'):
                 knn['gpu_queries_per_s'] = knn_gpu(device, knn['num_points'], knn['dim'])
