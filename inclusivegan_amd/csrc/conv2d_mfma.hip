@@ -3147,15 +3147,17 @@ void launch_filter_image(hipStream_t stream, const float* w, unsigned short* wp,
 
 // Does this launch take the bf16-piece form (conv_fwd_planes_kernel)?  the form switched on, the 128x128 tile, Cin % 32 == 0, both
 // piece images addressable with 32-bit offsets below the out-of-range marker -- and a reduction deep enough to pay for writing
-// the piece images: 3x3 taps on at least 128 channels (taps * Cin >= 1152) over at least 1024 output rows.  Measured per layer
-// (tools/conv_layers.py): the 1x1 Skip convolutions and the 4x4 layers lose (D 128 Skip 77 -> 220 us), everything from 8x8 Conv1 at 24 samples
-// (1536 rows) up gains.  Round 5 (fp16 form, three products and a quicker filter image): the 8x8 layers at 24 samples forward 78 -> 70, data
-// gradient 78 -> 58, weight gradient 93 -> 71 us, G 16 Conv0_up forward 153 -> 92 us, 384-row layers (4x4, 8 -> 4) lose 33 -> 53 us; bench +1.2 %
-// at 1024 rows, the same at 512 (profiles/r05_small_layers.txt).  IGAN_PLANES_MIN_ROWS / IGAN_WGRAD_PLANES_MIN_ROWS move the two thresholds.
+// the piece images: 3x3 taps on at least 128 channels (taps * Cin >= 1152) over at least 2048 output rows.  Measured per layer
+// (tools/conv_layers.py): the 1x1 Skip convolutions and the 4x4 layers lose (D 128 Skip 77 -> 220 us), everything from 16x16 Conv1 up gains.
+// Round 5 tried 1024 rows (fp16 form: three products and a quicker filter image): the 8x8 layers at 24 samples forward 78 -> 70, data gradient
+// 78 -> 58, weight gradient 93 -> 71 us, G 16 Conv0_up forward 153 -> 92 us, bench +1.2 % -- and the path-length step's gradients on BASELINE
+// config 2 moved 4-15x further from the fp64 oracle (7.6e-3 against 1.9e-3 at iteration 5, the exact forms: 1.3e-3 / 2.2e-3; five steps compared,
+// profiles/r05_small_layers.txt section 5): the layers with 1024-2047 rows stay on the fp32 instruction.  IGAN_PLANES_MIN_ROWS /
+// IGAN_WGRAD_PLANES_MIN_ROWS move the two thresholds.
 // planes_shape_ok() is what the PLAN sizes the workspace by (shapes only: plans are cached per shape); the launch also needs 16 B aligned operands.
 bool planes_shape_ok(const igan_conv2d_params* p, const FwdTile& t, int Mmax) {
     if (!planes_enabled() || t.BM != 128 || t.BN != 128 || p->Cin % BK != 0) return false;
-    static const int min_rows = getenv("IGAN_PLANES_MIN_ROWS") ? atoi(getenv("IGAN_PLANES_MIN_ROWS")) : 1024;
+    static const int min_rows = getenv("IGAN_PLANES_MIN_ROWS") ? atoi(getenv("IGAN_PLANES_MIN_ROWS")) : 2048;
     if (p->KH * p->KW == 1 || (long long)p->KH * p->KW * p->Cin < 1152 || Mmax < min_rows) return false;      // 1x1: the Skip layers and the nearest-neighbour distance GEMM stay on the fp32 instruction
     if ((long long)p->N * p->OH * p->OW >= (1LL << 24)) return false;
     if ((long long)p->N * p->H * p->W * p->Cin * 6 >= 0x7FFFFF00LL || (long long)p->KH * p->KW * p->Cin * p->Cout * 6 >= 0x7FFFFF00LL) return false;
@@ -3549,7 +3551,7 @@ bool wgrad_planes_shape_ok(const igan_conv2d_wgrad_params* p) {
         if (kind && kind[0] == 'u' && p->up != 2) return false;
     }
 #endif
-    static const int wmin_rows = getenv("IGAN_WGRAD_PLANES_MIN_ROWS") ? atoi(getenv("IGAN_WGRAD_PLANES_MIN_ROWS")) : 1024;
+    static const int wmin_rows = getenv("IGAN_WGRAD_PLANES_MIN_ROWS") ? atoi(getenv("IGAN_WGRAD_PLANES_MIN_ROWS")) : 2048;
     if ((long long)p->N * p->OH * p->OW < wmin_rows * (long long)p->up * p->up) return false;
     if ((long long)p->N * p->H * p->W * p->Cin * 6 >= 0x7FFFFF00LL || (long long)p->N * p->OH * p->OW * p->Cout * 6 >= 0x7FFFFF00LL) return false;
     // fp16 form: the column-maximum pass gives every thread one channel quad (C / 4 a power of two <= 256)

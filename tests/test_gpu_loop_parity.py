@@ -256,6 +256,8 @@ def test_graphed_training_loop_matches_oracle_config2(cuda_device):
     assert graphs.graphs_enabled(True), 'this test is about the captured path'
     n_it = int(os.environ.get('IGAN_TEST_TRAJECTORY_ITERS', '20'))
     chosen = {0, 16} if os.environ.get('IGAN_TEST_TRAJECTORY_ALL', '0') != '1' else set(range(n_it))
+    if os.environ.get('IGAN_TEST_TRAJECTORY_ITS'):       # DIAGNOSTIC: the oracle on the ops of these iterations only (comma list, 0-based)
+        chosen = {int(v) for v in os.environ['IGAN_TEST_TRAJECTORY_ITS'].split(',')}
     names, firsts = [], []
 
     class Consumer(TeacherForcedOracle):

@@ -65,6 +65,7 @@ cases = [
     ('3x3 s2 33->16 C256->512', 9, 256, 33, 512, 3, 2, 1, 0, 16, dict()),
     ('3x3 up2 16->33 C512->256', 8, 512, 16, 256, 3, 1, 2, 2, 33, dict(scales=True)),
     ('3x3 24x24 C128->384 ragged', 4, 128, 24, 384, 3, 1, 1, 1, 24, dict()),
+    ('3x3 8x8 C512 at 24 samples (1536 rows: the test lowers the row threshold to 1024, the product keeps 2048)', 24, 512, 8, 512, 3, 1, 1, 1, 8, dict(scales=True)),
 ]
 # shapes the variant leaves to the fp32 kernels: 1x1 (Skip, the distance GEMM), shallow reductions, few rows
 for args in ((2, 128, 64, 256, 1, 1, 1, 0, 64), (2, 64, 32, 128, 3, 1, 1, 1, 32), (3, 512, 8, 512, 3, 1, 1, 1, 8)):
@@ -121,6 +122,7 @@ wgrad_case('3x3 24x24 C128->384', 4, 128, 24, 384, 3, 1, 1, 1, 24)
 wgrad_case('3x3 s2 33->16 C256->512', 9, 256, 33, 512, 3, 2, 1, 0, 16)
 wgrad_case('3x3 up2 16->33 C512->256', 8, 512, 16, 256, 3, 1, 2, 2, 33, scales=True)
 wgrad_case('3x3 19x19 C160->224 ragged', 6, 160, 19, 224, 3, 1, 1, 1, 19)
+wgrad_case('3x3 8x8 C512 at 24 samples (1536 summed pixels)', 24, 512, 8, 512, 3, 1, 1, 1, 8, scales=True)
 print('PLANES-VARIANT-OK')
 '''
 
@@ -129,7 +131,7 @@ print('PLANES-VARIANT-OK')
 def test_piece_forms_against_fp64(cuda_device, form):
     """IGAN_CONV_PLANES=1: three bf16 pieces, six products.  =2: two fp16 pieces under per-pixel / per-channel power-of-two scales, three products
     (the default form; channel counts that are not powers of two stay on the fp32 kernels there) -- same shapes, same tolerances."""
-    env = dict(os.environ, IGAN_CONV_PLANES=form)
+    env = dict(os.environ, IGAN_CONV_PLANES=form, IGAN_PLANES_MIN_ROWS='1024', IGAN_WGRAD_PLANES_MIN_ROWS='1024')      # the 8x8 cases run in the piece form here (product threshold: 2048 rows)
     r = subprocess.run([sys.executable, '-c', CHILD % ROOT], env=env, capture_output=True, text=True, timeout=600)
     sys.stdout.write(r.stdout[-3000:])
     assert r.returncode == 0 and 'PLANES-VARIANT-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
@@ -169,6 +171,20 @@ gx, gw, gs, gd, gb = torch.autograd.grad(y, [x, w, s, d, b], dy)
 out.append(dig(y, gx, gw, gs, gd, gb))
 print('DIGESTS ' + ' '.join(out))
 '''
+
+
+def test_four_wave_tile_is_bit_identical_to_the_eight_wave_tile(cuda_device):
+    """The fp16 form's forward / data-gradient tile runs on four waves with register-prefetched fragments by default (conv_fwd_planes_w4_kernel); IGAN_F16_W4=0
+    is the eight-wave tile (conv_fwd_planes_kernel<2, true>).  Another schedule of the same products and folds: forward outputs and every gradient of a modulated
+    layer, a fused synthesis layer and a plain layer with epilogue must agree bit for bit (profiles/r05_w4_tile.txt section 4 has the digests of five larger shapes)."""
+    digests = {}
+    for w4 in ('0', '1'):
+        env = dict(os.environ, IGAN_CONV_PLANES='2', IGAN_F16_W4=w4)
+        r = subprocess.run([sys.executable, '-c', SHARE_CHILD % ROOT], env=env, capture_output=True, text=True, timeout=600)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith('DIGESTS ')]
+        assert r.returncode == 0 and lines, r.stdout[-2000:] + r.stderr[-3000:]
+        digests[w4] = lines[-1]
+    assert digests['0'] == digests['1'], digests
 
 
 @pytest.mark.parametrize('form', ['1', '2'], ids=['bf16_x3', 'fp16_x2'])
