@@ -270,3 +270,27 @@ def test_mbstd_preserving_interleave_is_exact():
         assert sorted(perm.tolist()) == list(range(2 * n)) and torch.equal(perm[inv], torch.arange(2 * n))
         y = minibatch_stddev_layer(torch.cat([a, b]).index_select(0, perm), g).index_select(0, inv)
         assert torch.equal(y[:n], minibatch_stddev_layer(a, g)) and torch.equal(y[n:], minibatch_stddev_layer(b, g))
+
+
+def test_bench_evidence_plumbing():
+    """bench.py's roofline bookkeeping (host side only): kernel names group into families by template name, the piece families are priced against the
+    16-bit dense peak over their products and everything else against the fp32 matrix peak, the sustained rate of the piece products' instruction is read
+    from the committed tools/mfma_rate run, and a counter file is either believed (taken on the kernel sources as they are now) or refused with the command to re-run."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location('bench_under_test', os.path.join(ROOT, 'bench.py'))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.family_of('conv_fwd_planes_w4_kernel') == 'conv_fwd_planes_w4_kernel'
+    assert b.family_of('conv_wgrad_planes_kernel<2> (+ reduce)') == 'conv_wgrad_planes_kernel'
+    assert b.family_of('conv_fwd_dma_kernel<false, true, 0>') == 'conv_fwd_dma_kernel'
+    assert b.family_peak('conv_fwd_dma_kernel') == b.F32_MATRIX_PEAK_TFLOPS
+    sus = b.sustained_instruction_rate('f16')
+    assert sus is not None and sus['instruction'] == 'v_mfma_f32_32x32x16_f16' and 1000.0 < sus['tflops'] < b.BF16_DENSE_PEAK_TFLOPS and 1000 < sus['clock_mhz'] < 2500, sus
+    assert b.sustained_instruction_rate('bf16')['tflops'] > sus['tflops']       # the bf16 instruction holds a higher clock (profiles/r05_mfma_rate.txt)
+    # a counter file is believed only on the kernel sources it was taken on: either a positive figure or a refusal that says what to re-run
+    for suffix in ('pmc_dominant.json', 'pmc_conv_headline.json'):
+        traffic, source = b.pmc_traffic(suffix)
+        assert (traffic is not None and traffic > 0 and source.endswith(suffix)) or (traffic is None and 'collect_pmc' in source), (suffix, traffic, source)
+    with open(b._latest_profile('pmc_dominant.json')) as f:
+        assert b.family_of(json.load(f)['kernel']).startswith('conv_fwd_planes')
