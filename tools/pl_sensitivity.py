@@ -6,7 +6,7 @@ section 5.)  The network is config 2's generator at random initialisation with p
 pl_mean tracks the lengths, so the penalty (pl_lengths - pl_mean)^2 is a difference of nearly equal numbers); the perturbation is y -> y * (1 + eps * xi), xi ~ N(0, 1)
 fixed, applied in the forward pass of every modulated convolution whose output is `res` x `res`; reported: the largest per-variable relative deviation of the
 gradient (the quantity tests/test_gpu_loop_parity.py bounds by 5e-3) divided by eps.
-usage: python tools/pl_sensitivity.py [pl_mean fraction = 0.98] [eps = 1e-6]"""
+usage: python tools/pl_sensitivity.py [pl_mean fraction = 0.98] [eps = 1e-6] [resolution = 32] [minibatch = 6]"""
 import os
 import sys
 import time
@@ -25,7 +25,8 @@ def main():
     frac = float(sys.argv[1]) if len(sys.argv) > 1 else 0.98
     eps = float(sys.argv[2]) if len(sys.argv) > 2 else 1e-6
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
-    res, batch = 32, 6
+    res = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+    batch = int(sys.argv[4]) if len(sys.argv) > 4 else 6
     kw = dict(num_channels=3, resolution=res, label_size=0, fmap_base=8192, device='cpu')
     G = tflib.Network('G', func_name='inclusivegan_amd.training.networks_stylegan2.G_main', architecture='skip', seed=1, **kw)
     D = tflib.Network('D', func_name='inclusivegan_amd.training.networks_stylegan2.D_stylegan2_feature', architecture='resnet', seed=2, **kw)
@@ -63,7 +64,7 @@ def main():
     pm = frac * mean_len
     print('mean path length %.6g; pl_mean set to %.3f of it (%.1f s per evaluation)' % (mean_len, frac, time.time() - t0))
     _, g0, _ = greg(pm)
-    for r in (8, 16, 32):
+    for r in [x for x in (8, 16, 32, 64, 128) if x <= res]:
         target['res'] = r
         noise.clear()
         reg1, g1, _ = greg(pm)
