@@ -1,0 +1,37 @@
+#!/bin/bash
+# Round-6 GPU sessions, one parameterised runner (replaces the one-off r5_*.sh recipes): `gpurun --timeout T -- 'bash tools/r6.sh <stage> [args]'`.
+# Every stage writes under gpurun_out/r6/<stage>/ ; what is judged is copied into profiles/ by hand.
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
+export TMPDIR=/tmp
+stage=$1; shift
+O=gpurun_out/r6/$stage; mkdir -p "$O"
+run() { # label, timeout, command...
+  local label=$1 t=$2; shift 2
+  echo "=== $label: $*" | tee -a "$O/log.txt"
+  timeout "$t" "$@" > "$O/$label.txt" 2>&1; local rc=$?
+  echo "rc $rc" >> "$O/$label.txt"; tail -n 3 "$O/$label.txt" | tee -a "$O/log.txt"
+}
+case $stage in
+second_order)   # the regulariser steps per arithmetic form, from one state
+  run test_reg_forms 1500 python -m pytest tests/test_gpu_reg_forms.py -m gpu -x -q -s
+  run cfg2_init 900 python tools/reg_forms.py --res 32 --state init --pl-fracs 0,0.9,0.98 --variants "0;1;2;2:1024" --out "$O/cfg2_init.json"
+  run cfg2_loop 1500 python tools/reg_forms.py --res 32 --state loop:4,8,16 --variants "0;1;2;2:1024" --out "$O/cfg2_loop.json"
+  run bench_init 1200 python tools/reg_forms.py --res 128 --state init --pl-fracs 0.5,0.98 --variants "0;1;2" --ops G_reg --out "$O/bench_init.json"
+  for f in 0 1 2; do IGAN_CONV_PLANES=$f run audit_greg_form$f 900 python tools/conv_audit.py --op G_reg; done
+  ;;
+audit)          # per-call audit of one op under the three forms: bash tools/r6.sh audit D_reg [extra args]
+  op=${1:-G_reg}; shift
+  for f in 0 1 2; do IGAN_CONV_PLANES=$f run audit_${op}_form$f 900 python tools/conv_audit.py --op "$op" "$@"; done
+  ;;
+suite)          # the GPU suite with the tests' own prints kept (-rP)
+  run gpu_tests 3000 python -m pytest tests -m gpu -q -rP --durations=15
+  run smoke 600 python __graft_entry__.py smoke
+  ;;
+bench)          # the driver's command; extra args are passed on
+  run bench 2400 python bench.py "$@"
+  ;;
+cmd)            # anything else: bash tools/r6.sh cmd <label> <timeout> <command...>
+  run "$@"
+  ;;
+*) echo "unknown stage $stage"; exit 2;;
+esac
