@@ -2984,7 +2984,7 @@ bool eight_waves(const char* env) {
 bool is_small_dense(const igan_conv2d_params* p) {
     return p->H == 1 && p->W == 1 && p->OH == 1 && p->OW == 1 && p->KH == 1 && p->KW == 1 && p->stride == 1 && p->up == 1 &&
            p->pad_y == 0 && p->pad_x == 0 && !p->in_scale && !p->out_scale && p->act == 0 &&
-           igan::dense_small_ok(p->N, p->Cin, p->x, p->w, p->w_transposed != 0);
+           igan::dense_small_ok(p->N, p->Cin, p->Cout, p->x, p->w, p->w_transposed != 0);
 }
 bool is_small_dense_wgrad(const igan_conv2d_wgrad_params* p) {
     return p->H == 1 && p->W == 1 && p->OH == 1 && p->OW == 1 && p->KH == 1 && p->KW == 1 && p->stride == 1 && p->up == 1 &&

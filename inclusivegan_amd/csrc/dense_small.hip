@@ -19,6 +19,8 @@
 #include "igan_common.h"
 #include <cstdlib>
 
+namespace igan { bool dense_small_fits(long long M, long long K, long long N, long long ldx); }
+
 namespace {
 
 constexpr int DS_COLS = 4;                   // output channels per workgroup
@@ -90,15 +92,10 @@ __global__ __launch_bounds__(256) void dense_small_kernel(DenseGroups G) {
         for (int it = 0; it < DS_NIT; it++) {
             const int k = k0 + (it * DS_GROUPS + g) * 4;
             const bool wok = jok && k < K;
-#ifndef IGAN_DENSE_WT_B128     // Round 5: the transposed form's weights as four 4-byte loads instead of one 16-byte load -- see the note at the top of the kernel
-            if constexpr (WT) {
+            if constexpr (WT) {      // Round 5: four 4-byte loads, not one 16-byte load -- see the note at the top of the kernel (the 16-byte form returned wrong values under co-residency; its build switch is gone)
                 const unsigned o = wok ? ((unsigned)j * (unsigned)K + (unsigned)k) * 4u : OOB;
                 wv[it].x = ld1(rw, o); wv[it].y = ld1(rw, o + 4u); wv[it].z = ld1(rw, o + 8u); wv[it].w = ld1(rw, o + 12u);
-            }
-#else
-            if constexpr (WT) wv[it] = ld4(rw, wok ? ((unsigned)j * (unsigned)K + (unsigned)k) * 4u : OOB);
-#endif
-            else {
+            } else {
                 const unsigned o = wok ? ((unsigned)k * (unsigned)N + (unsigned)j) * 4u : OOB;      // OOB + 3 N * 4 stays out of range (N * K * 4 < 2^31)
                 wv[it].x = ld1(rw, o); wv[it].y = ld1(rw, o + (unsigned)N * 4u);
                 wv[it].z = ld1(rw, o + (unsigned)N * 8u); wv[it].w = ld1(rw, o + (unsigned)N * 12u);
@@ -253,6 +250,7 @@ int dense_check(const igan_dense_params* p) {
     IGAN_REQUIRE(p->M >= 1 && p->M <= IGAN_DENSE_MAX_ROWS, "dense_small: 1 <= M <= %d rows (use igan_conv2d for larger batches)", IGAN_DENSE_MAX_ROWS);
     IGAN_REQUIRE(p->K >= 4 && p->K % 4 == 0 && p->N >= 1, "dense_small: K must be a positive multiple of 4, N positive");
     IGAN_REQUIRE(p->ldx >= p->K && p->ldx % 4 == 0 && p->ldy >= p->N, "dense_small: bad row strides");
+    IGAN_REQUIRE(igan::dense_small_fits(p->M, p->K, p->N, p->ldx), "dense_small: x, x2 and w must each stay below 2 GiB (32-bit buffer offsets; use igan_conv2d for larger operands)");
     IGAN_REQUIRE((((uintptr_t)p->x) & 15) == 0 && (!p->w_transposed || (((uintptr_t)p->w) & 15) == 0), "dense_small: x (and a transposed w) must be 16-byte aligned");
     IGAN_REQUIRE(p->prologue >= IGAN_DENSE_PRO_NONE && p->prologue <= IGAN_DENSE_PRO_DEMOD_GRAD, "dense_small: unknown prologue");
     IGAN_REQUIRE(p->epilogue >= IGAN_DENSE_EPI_SCALE && p->epilogue <= IGAN_DENSE_EPI_STYLE_GRAD, "dense_small: unknown epilogue");
@@ -283,11 +281,20 @@ int taps_check(const igan_taps_params* q, bool need_v, const char* who) {
 
 namespace igan {
 
-bool dense_small_ok(int M, int K, const void* x, const void* w, bool wt) {
+// The kernel reads x, x2 and w through buffer descriptors with 32-bit byte offsets and marks a guarded-off lane by the offset 0x7FFFFFF0 (which must lie
+// OUTSIDE every descriptor's range, also after the + 3 N * 4 of the forward form's four row loads): every operand must stay below that many bytes.
+// (DCI's re-rank reaches this path with N = 8192 candidates x an unprojected dim of 196 608 = 6 GiB; such a call takes the MFMA tiles.)
+bool dense_small_fits(long long M, long long K, long long N, long long ldx) {
+    const long long lim = 0x7FFFFFF0LL;
+    return N * K * 4 < lim && ((M - 1) * ldx + K) * 4 < lim && M * K * 4 < lim && lim + 3 * N * 4 < 0xFFFFFFFFLL;
+}
+
+bool dense_small_ok(int M, int K, int N, const void* x, const void* w, bool wt) {
     // w[k][n] is streamed in 16 B pieces per k row: fine while the matrix is small and L2-resident, 4x read
     // amplification from HBM for a long reduction axis (D's 8192 -> 512 layer): that one goes to the MFMA tiles.
     static const int maxk = getenv("IGAN_DENSE_MAXK") ? atoi(getenv("IGAN_DENSE_MAXK")) : 2048;
     if (!wt && K > maxk) return false;
+    if (!dense_small_fits(M, K, N, K)) return false;
     return M >= 1 && M <= IGAN_DENSE_MAX_ROWS && (K % 4) == 0 && (((uintptr_t)x) & 15) == 0 && (!wt || (((uintptr_t)w) & 15) == 0);
 }
 

@@ -36,7 +36,8 @@ inline int check_hip(hipError_t e, const char* what) {
     } while (0)
 
 // dense_small.hip: small-batch (M <= 32 rows) dense layers, dispatched from igan_conv2d / igan_conv2d_wgrad
-bool dense_small_ok(int M, int K, const void* x, const void* w, bool wt);
+bool dense_small_ok(int M, int K, int N, const void* x, const void* w, bool wt);
+bool dense_small_fits(long long M, long long K, long long N, long long ldx);
 int dense_small_rows(int M);
 void dense_small_launch(hipStream_t stream, const igan_dense_params& a);
 void dense_small(hipStream_t stream, const float* x, const float* w, float* y, int M, int K, int N, bool wt, float alpha);

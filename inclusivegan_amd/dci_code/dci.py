@@ -35,8 +35,11 @@ class DCI(object):
         self.device = torch.device(device)
         self._data = None
         self._norms = None
-        self.cand_chunk = 8192      # candidates folded per kernel pass
-        self.query_chunk = 4096     # queries per kernel pass
+        # The kernels address an operand through 32-bit byte offsets (include/igan_hip.h: below 2 GiB each; igan_conv2d / igan_nn1_update reject more),
+        # so at large unprojected dimensions (256x256x3 = 196 608) a pass takes fewer rows instead of failing.
+        fit = max(1, 0x7FFFFFF0 // (4 * max(self._dim, 1)) - 1)
+        self.cand_chunk = min(8192, fit)      # candidates folded per kernel pass
+        self.query_chunk = min(4096, fit)     # queries per kernel pass
         self.rerank_bytes = 1 << 30 # largest fp64 block the exact re-rank of query_device_k gathers at once
 
     @property

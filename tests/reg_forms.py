@@ -127,8 +127,10 @@ def hip_ops_of_state(state, dev, ops=('G_reg', 'D_reg'), record=False):
     return out, names
 
 
-def oracle_ops_of_state(state, ops=('G_reg', 'D_reg'), trainables=None):
-    """The same ops on the fp64 oracle (oracle/loss.py).  `trainables`: dict(G=[names], D=[names]) (which variables take a gradient)."""
+def oracle_ops_of_state(state, ops=('G_reg', 'D_reg'), trainables=None, dtype=torch.float64):
+    """The same ops on the fp64 oracle (oracle/loss.py).  `trainables`: dict(G=[names], D=[names]) (which variables take a gradient).
+    dtype=torch.float32: the SAME restatement evaluated in fp32 by PyTorch's CPU kernels -- not an oracle, a second fp32 implementation (how far
+    does fp32 arithmetic as such sit from fp64 on this state?)."""
     from oracle import loss as OL
     from oracle.misc import Tape
     cfg = state['cfg']
@@ -138,28 +140,28 @@ def oracle_ops_of_state(state, ops=('G_reg', 'D_reg'), trainables=None):
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
 
     def params(vars_, names):
-        p = {n: torch.from_numpy(np.asarray(v, np.float64)) for n, v in vars_.items()}
+        p = {n: torch.from_numpy(np.asarray(v, np.float64)).to(dtype) for n, v in vars_.items()}
         for n in names:
             p[n].requires_grad_(True)
         return p
 
     out = {}
-    z = torch.zeros(B, 512, dtype=torch.float64)
+    z = torch.zeros(B, 512, dtype=dtype)
     for i, pl_mean in enumerate(state['pl_means'] if 'G_reg' in ops else []):
         gp, dp = params(state['G'], trainables['G']), params(state['D'], [])
-        st = dict(pl_mean=torch.tensor(pl_mean, dtype=torch.float64), dlatent_avg=gp['dlatent_avg'])
+        st = dict(pl_mean=torch.tensor(pl_mean, dtype=dtype), dlatent_avg=gp['dlatent_avg'])
         t0 = time.time()
-        _, reg, _ = OL.G_loss(gp, dp, {}, ocfg, Tape(state['tape_G'], torch.float64), B, None, z, None, z, 2.5, phase='reg', state=st)
+        _, reg, _ = OL.G_loss(gp, dp, {}, ocfg, Tape(state['tape_G'], dtype), B, None, z, None, z, 2.5, phase='reg', state=st)
         reg.mean().backward()
-        out['G_reg@%d' % i] = dict(value=reg.detach().numpy(), pl_mean=float(st['pl_mean']), seconds=time.time() - t0,
-                                   grads={n: gp[n].grad.numpy() for n in trainables['G'] if gp[n].grad is not None})
+        out['G_reg@%d' % i] = dict(value=reg.detach().double().numpy(), pl_mean=float(st['pl_mean']), seconds=time.time() - t0,
+                                   grads={n: gp[n].grad.double().numpy() for n in trainables['G'] if gp[n].grad is not None})
     if 'D_reg' in ops:
         gp, dp = params(state['G'], []), params(state['D'], trainables['D'])
         t0 = time.time()
-        _, reg, _ = OL.D_loss(gp, dp, ocfg, Tape(state['tape_D'], torch.float64), B, torch.from_numpy(state['reals']).double(), gamma=100, phase='reg', state={})
+        _, reg, _ = OL.D_loss(gp, dp, ocfg, Tape(state['tape_D'], dtype), B, torch.from_numpy(state['reals']).to(dtype), gamma=100, phase='reg', state={})
         reg.mean().backward()
-        out['D_reg'] = dict(value=reg.detach().numpy(), seconds=time.time() - t0,
-                            grads={n: dp[n].grad.numpy() for n in trainables['D'] if dp[n].grad is not None})
+        out['D_reg'] = dict(value=reg.detach().double().numpy(), seconds=time.time() - t0,
+                            grads={n: dp[n].grad.double().numpy() for n in trainables['D'] if dp[n].grad is not None})
     torch.set_num_threads(threads_before)
     return out
 

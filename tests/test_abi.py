@@ -118,3 +118,36 @@ def test_no_cpu_fallback():
         hip_ops.upfirdn2d_raw(torch.zeros(1, 4, 4, 4), np.ones((4, 4), np.float32), 1, 1, 1, 1, 0, 0, 0, 0)
     with pytest.raises(RuntimeError, match='no CPU path'):
         hip_ops.conv2d_raw(torch.zeros(1, 4, 4, 4), torch.zeros(3, 3, 4, 4), hip_ops.ConvGeom(3, 3, 1, 1, 1, 1), (4, 4), 4)
+
+
+def test_small_dense_path_is_bounded_by_its_32_bit_offsets():
+    """dense_small_kernel reads its operands through buffer descriptors with 32-bit byte offsets and an out-of-range marker of
+    0x7FFFFFF0, so an operand of 2 GiB or more must not reach it -- DCI's threshold re-rank (dci.py: one query row against 8192 candidates) does with
+    an unprojected dimension of 256*256*3.  The dispatcher sends such a call to the MFMA tiles; the direct entry point rejects it."""
+    from inclusivegan_amd import _abi
+    lib = _abi.get_plugin()
+
+    def kernel(M, K, N, wt):
+        p = _abi.Conv2DParams(x=1 << 20, w=1 << 20, y=1 << 20, in_scale=None, out_scale=None, workspace=None, workspace_floats=0, N=M, H=1, W=1, Cin=K, OH=1, OW=1,
+                              Cout=N, KH=1, KW=1, stride=1, up=1, pad_y=0, pad_x=0, w_transposed=wt, splits=1, alpha=1.0, bias=None, act=0, act_alpha=0.0, act_gain=1.0)
+        buf = ctypes.create_string_buffer(128)
+        _abi.check(lib.igan_conv2d_kernel_name(ctypes.byref(p), buf, 128))
+        return buf.value.decode()
+
+    assert kernel(1, 3072, 8192, 1).startswith('dense_small_kernel')             # CelebA-shaped 32x32x3: 100 MB of candidates
+    assert kernel(1, 49152, 8192, 1).startswith('dense_small_kernel')            # 128x128x3: 1.6 GB, still below the marker
+    assert kernel(64, 512, 512, 0).startswith('dense_small_kernel')
+    for K in (196608, 65536):                                                     # 256x256x3: 6.4 GB; exactly 2 GiB: refused by igan_conv2d as a whole ...
+        with pytest.raises(ValueError, match='2 GiB'):
+            kernel(1, K, 8192, 1)
+    from inclusivegan_amd.dci_code.dci import DCI                                 # ... so DCI folds fewer candidates per pass at such a dimension
+    for dim in (3072, 49152, 196608):
+        db = DCI(dim, device='cpu')
+        assert db.cand_chunk * dim * 4 < 0x7FFFFFF0 and db.query_chunk * dim * 4 < 0x7FFFFFF0
+        assert (db.cand_chunk, db.query_chunk) == ((8192, 4096) if dim <= 49152 else (2729, 2729))
+    d = _abi.DenseParams()
+    d.x = d.w = d.y = 1 << 20
+    d.M, d.K, d.N, d.ldx, d.ldy, d.w_transposed = 1, 196608, 8192, 196608, 8192, 1
+    d.prologue, d.epilogue, d.alpha = _abi.DENSE_PRO_NONE, _abi.DENSE_EPI_SCALE, 1.0
+    assert lib.igan_dense_small(None, ctypes.byref(d)) != 0
+    assert b'2 GiB' in lib.igan_last_error()

@@ -144,7 +144,7 @@ def main():
     def conv_wrapper(x, w, geom, out_hw, cout, w_transposed=False, in_scale=None, out_scale=None, bias=None, act=None, noise=None, strength=None, x_pieces=None, colmax=None):
         y = orig_conv(x, w, geom, out_hw, cout, w_transposed=w_transposed, in_scale=in_scale, out_scale=out_scale, bias=bias, act=act, noise=noise, strength=strength,
                       x_pieces=x_pieces, colmax=colmax)
-        if busy[0] or x.dim() != 4 or geom.kh * geom.kw * x.shape[1] < a.min_k:
+        if busy[0] or x.device.type != 'cuda' or x.dim() != 4 or geom.kh * geom.kw * x.shape[1] < a.min_k:
             return y
         busy[0] = True
         with torch.no_grad():
@@ -168,7 +168,7 @@ def main():
 
     def wgrad_wrapper(x, dy, geom, in_scale=None, out_scale=None, x_pieces=None, dy_pieces=None, x_colmax=None, dy_colmax=None):
         dw = orig_wgrad(x, dy, geom, in_scale=in_scale, out_scale=out_scale, x_pieces=x_pieces, dy_pieces=dy_pieces, x_colmax=x_colmax, dy_colmax=dy_colmax)
-        if busy[0] or geom.kh * geom.kw * x.shape[1] < a.min_k:
+        if busy[0] or x.device.type != 'cuda' or geom.kh * geom.kw * x.shape[1] < a.min_k:
             return dw
         busy[0] = True
         with torch.no_grad():

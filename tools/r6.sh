@@ -19,9 +19,22 @@ second_order)   # the regulariser steps per arithmetic form
   run bench_init 1200 python tools/reg_forms.py --res 128 --state init --pl-fracs 0.5,0.98 --variants "0;1;2" --ops G_reg --out "$O/bench_init.json"
   for f in 0 1 2; do IGAN_CONV_PLANES=$f run audit_greg_form$f 900 python tools/conv_audit.py --op G_reg; done
   ;;
+second_order2)  # the per-call audit of both second-order ops, the loop states with a second fp32 implementation beside them, the row thresholds on the clock
+  for op in G_reg D_reg; do for f in 0 1 2; do IGAN_CONV_PLANES=$f run audit_${op}_form$f 900 python tools/conv_audit.py --op $op; done; done
+  run cfg2_loop_cpu32 1500 python tools/reg_forms.py --res 32 --state loop:4,16 --variants "0;2;cpu32" --out "$O/cfg2_loop_cpu32.json"
+  bash tools/r6.sh ab 2 - "IGAN_PLANES_MIN_ROWS=1024 IGAN_WGRAD_PLANES_MIN_ROWS=1024"
+  ;;
 audit)          # per-call audit of one op under the three forms: bash tools/r6.sh audit D_reg [extra args]
   op=${1:-G_reg}; shift
   for f in 0 1 2; do IGAN_CONV_PLANES=$f run audit_${op}_form$f 900 python tools/conv_audit.py --op "$op" "$@"; done
+  ;;
+ab)             # alternating bench A/B of environment settings on one box: bash tools/r6.sh ab <rounds> "<env A>" "<env B>" ...  ("-" = no setting)
+  rounds=$1; shift
+  for i in $(seq 1 "$rounds"); do for e in "$@"; do
+    [ "$e" = "-" ] && ee="IGAN_NOOP=1" || ee="$e"
+    env $ee timeout 900 python bench.py --data-size 1152 --no-cpu-baseline --no-roofline --no-variant-line --op-times 2>>"$O/err.txt" | tail -1 | \
+      python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$e', d['value'], d['ms_per_step'], d.get('op_ms'), d['hip_graphs']['faithful'])" | tee -a "$O/ab.txt"
+  done; done
   ;;
 suite)          # the GPU suite with the tests' own prints kept (-rP)
   run gpu_tests 3000 python -m pytest tests -m gpu -q -rP --durations=15

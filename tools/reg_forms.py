@@ -9,7 +9,9 @@
 --state loop:i,j,...  the state training_loop() had BEFORE the path-length step of (0-based) iterations i, j, ... of a run under the default form
                       (weights, dlatent_avg, pl_mean and that op's own draws; tests/test_gpu_loop_parity.record_loop) -- every variant then
                       evaluates THAT state, unlike a comparison of separate runs, whose weights differ from the fourth iteration on (beta1 = 0)
---variants            ';'-separated "form[:min_rows[:wgrad_min_rows]]": IGAN_CONV_PLANES and the two row thresholds of the piece forms
+--variants            ';'-separated "form[:min_rows[:wgrad_min_rows]]": IGAN_CONV_PLANES and the two row thresholds of the piece forms;
+                      "cpu32" = the oracle's own restatement evaluated in fp32 by PyTorch's CPU kernels (a second, unrelated fp32 implementation:
+                      what fp32 arithmetic as such costs on this state)
 Prints per op the worst variables of every variant, SHA-1 digests of the gradient buckets (which variants are bit-identical), and writes a JSON."""
 import argparse
 import hashlib
@@ -84,6 +86,9 @@ def main():
     ops = tuple(a.ops.split(','))
     variants = []
     for v in a.variants.split(';'):
+        if v == 'cpu32':
+            variants.append((v, None))
+            continue
         f = v.split(':')
         env = dict(IGAN_CONV_PLANES=f[0])
         if len(f) > 1 and f[1]:
@@ -111,6 +116,10 @@ def main():
         RF.save_state_dict(spath, state)
         hip, digs = {}, {}
         for label, env in variants:
+            if env is None:
+                hip[label] = RF.oracle_ops_of_state(state, ops=ops, trainables=names, dtype=torch.float32)
+                digs[label] = {op: '-' for op in hip[label]}
+                continue
             opath = os.path.join(tmp, 'out.npz')
             info = RF.run_child(spath, opath, env, ops=ops)
             hip[label] = RF.load_result(opath)
