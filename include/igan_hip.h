@@ -276,7 +276,8 @@ int igan_pieces_image_ok(int N, int HW, int C);
  * channel's pixels in the weight gradient -- never a whole tensor), three products; the operand to 2^-23 (exactly in three cases of four) for every
  * element within 2^26 of the largest of its own group. */
 int igan_conv_piece_form(void);
-/* ABI v8: size in floats of an x_colmax / dy_colmax buffer for a tensor [N, HW, C]; 0 = none is taken (not the fp16 form, or a channel count outside it). */
+/* ABI v8: size in floats of an x_colmax / dy_colmax buffer for a tensor [N, HW, C]; 0 = none is taken (not the fp16 form, a channel count outside it, or fewer
+ * pixels than any weight gradient that takes the column image has: N * HW below the piece form's row threshold). */
 size_t igan_colmax_floats(int N, int HW, int C);
 /* Diagnostic for form 2 (synchronises the device): non-zero elements imaged so far BELOW the exact window (|v S| < 2^-12: more than 2^26 below the
  * largest magnitude of the element's own scale group) and elements imaged in all; reset != 0 zeroes both counters. */

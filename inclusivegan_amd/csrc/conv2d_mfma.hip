@@ -3147,17 +3147,17 @@ void launch_filter_image(hipStream_t stream, const float* w, unsigned short* wp,
 
 // Does this launch take the bf16-piece form (conv_fwd_planes_kernel)?  the form switched on, the 128x128 tile, Cin % 32 == 0, both
 // piece images addressable with 32-bit offsets below the out-of-range marker -- and a reduction deep enough to pay for writing
-// the piece images: 3x3 taps on at least 128 channels (taps * Cin >= 1152) over at least 2048 output rows.  Measured per layer
+// the piece images: 3x3 taps on at least 128 channels (taps * Cin >= 1152) over at least 1024 output rows.  Measured per layer
 // (tools/conv_layers.py): the 1x1 Skip convolutions and the 4x4 layers lose (D 128 Skip 77 -> 220 us), everything from 16x16 Conv1 up gains.
-// Round 5 tried 1024 rows (fp16 form: three products and a quicker filter image): the 8x8 layers at 24 samples forward 78 -> 70, data gradient
-// 78 -> 58, weight gradient 93 -> 71 us, G 16 Conv0_up forward 153 -> 92 us, bench +1.2 % -- and the path-length step's gradients on BASELINE
-// config 2 moved 4-15x further from the fp64 oracle (7.6e-3 against 1.9e-3 at iteration 5, the exact forms: 1.3e-3 / 2.2e-3; five steps compared,
-// profiles/r05_small_layers.txt section 5): the layers with 1024-2047 rows stay on the fp32 instruction.  IGAN_PLANES_MIN_ROWS /
+// Row threshold 1024 (round 6).  Round 5 measured it (fp16 form: three products and a quicker filter image): the 8x8 layers at 24 samples forward 78 -> 70, data gradient
+// 78 -> 58, weight gradient 93 -> 71 us, G 16 Conv0_up forward 153 -> 92 us, bench +1.2 % -- and held it back because the path-length step's gradients of two separate runs of
+// BASELINE config 2 sat 4-15x further from the fp64 oracle at 1024.  Round 6 (profiles/r06_second_order.txt): no call of that step has 1024-2047 rows (its gradient bucket is
+// bit-identical under both thresholds); the two runs' STATES differed (beta1 = 0), and on one state every form reads the same deviation.  IGAN_PLANES_MIN_ROWS /
 // IGAN_WGRAD_PLANES_MIN_ROWS move the two thresholds.
 // planes_shape_ok() is what the PLAN sizes the workspace by (shapes only: plans are cached per shape); the launch also needs 16 B aligned operands.
 bool planes_shape_ok(const igan_conv2d_params* p, const FwdTile& t, int Mmax) {
     if (!planes_enabled() || t.BM != 128 || t.BN != 128 || p->Cin % BK != 0) return false;
-    static const int min_rows = getenv("IGAN_PLANES_MIN_ROWS") ? atoi(getenv("IGAN_PLANES_MIN_ROWS")) : 2048;
+    static const int min_rows = getenv("IGAN_PLANES_MIN_ROWS") ? atoi(getenv("IGAN_PLANES_MIN_ROWS")) : 1024;
     if (p->KH * p->KW == 1 || (long long)p->KH * p->KW * p->Cin < 1152 || Mmax < min_rows) return false;      // 1x1: the Skip layers and the nearest-neighbour distance GEMM stay on the fp32 instruction
     if ((long long)p->N * p->OH * p->OW >= (1LL << 24)) return false;
     if ((long long)p->N * p->H * p->W * p->Cin * 6 >= 0x7FFFFF00LL || (long long)p->KH * p->KW * p->Cin * p->Cout * 6 >= 0x7FFFFF00LL) return false;
@@ -3536,7 +3536,11 @@ int wgrad_splits(const igan_conv2d_wgrad_params* p) {
 
 // The weight gradient's bf16-piece form (conv_wgrad_planes_kernel): same switch and the same kind of shapes as the forward one --
 // 3x3 filters between at least 128 channels on each side (the 128x128 tile), channel counts in whole 32s, a pixel axis of at least
-// 2048, both piece images below the out-of-range marker.
+// 1024 (round 6; 2048 before), both piece images below the out-of-range marker.
+int wgrad_min_rows() {
+    static const int v = getenv("IGAN_WGRAD_PLANES_MIN_ROWS") ? atoi(getenv("IGAN_WGRAD_PLANES_MIN_ROWS")) : 1024;
+    return v;
+}
 bool wgrad_planes_shape_ok(const igan_conv2d_wgrad_params* p) {
     static const bool wg = !(getenv("IGAN_WGRAD_PLANES") && atoi(getenv("IGAN_WGRAD_PLANES")) == 0);      // A/B switch inside the piece form
     if (!planes_enabled() || !wg || p->KH * p->KW == 1 || p->Cin < 128 || p->Cout < 128 || p->Cin % 32 != 0 || p->Cout % 32 != 0) return false;
@@ -3551,8 +3555,7 @@ bool wgrad_planes_shape_ok(const igan_conv2d_wgrad_params* p) {
         if (kind && kind[0] == 'u' && p->up != 2) return false;
     }
 #endif
-    static const int wmin_rows = getenv("IGAN_WGRAD_PLANES_MIN_ROWS") ? atoi(getenv("IGAN_WGRAD_PLANES_MIN_ROWS")) : 2048;
-    if ((long long)p->N * p->OH * p->OW < wmin_rows * (long long)p->up * p->up) return false;
+    if ((long long)p->N * p->OH * p->OW < wgrad_min_rows() * (long long)p->up * p->up) return false;
     if ((long long)p->N * p->H * p->W * p->Cin * 6 >= 0x7FFFFF00LL || (long long)p->N * p->OH * p->OW * p->Cout * 6 >= 0x7FFFFF00LL) return false;
     // fp16 form: the column-maximum pass gives every thread one channel quad (C / 4 a power of two <= 256)
     if (planes_mode() == 2 && (!pow2(p->Cin) || !pow2(p->Cout) || p->Cin > 1024 || p->Cout > 1024)) return false;
@@ -3735,6 +3738,9 @@ extern "C" int igan_conv_piece_form(void) { return planes_mode(); }
 extern "C" size_t igan_colmax_floats(int N, int HW, int C) {
     using namespace igan;
     if (planes_mode() != 2 || N < 1 || HW < 1 || C < 16 || C > 1024 || (C & (C - 1)) != 0) return 0;
+    // no weight gradient of a tensor with fewer pixels than the piece form's row threshold takes the column image (wgrad_planes_shape_ok: N * OH * OW >= threshold * up^2,
+    // and an up-sampling layer's input has a quarter of its output's pixels): the maxima would be two dead kernels and up to 2 MB of saved state per small layer
+    if ((long long)N * HW < wgrad_min_rows()) return 0;
     return 4 + (size_t)H_COLBLOCKS * C;
 }
 

@@ -375,28 +375,43 @@ class SubmitThread:
 
     live = set()        # submitters that have not been closed: training_loop closes them on EVERY way out (an exception used to leave the thread and the switch interval behind)
 
-    def close(self, check=True):
+    def close(self, check=True, timeout=None):
+        """timeout (seconds): give up waiting for the worker (a replay that never returns: a hung device) instead of blocking the caller's own
+        exception for ever; the daemon thread is then left behind and a RuntimeWarning says so."""
         import sys
         if self.closed:
             return
         self.closed = True
         SubmitThread.live.discard(self)
         self.q.put(None)
-        self.thread.join()
+        self.thread.join(timeout)
         sys.setswitchinterval(self._switch)
+        if self.thread.is_alive():
+            import warnings
+            warnings.warn('inclusivegan_amd: the submission thread did not exit within %.0f s (a device submission is still blocked); left behind as a daemon thread' % timeout, RuntimeWarning)
+            return
         if check:
             self._check()
 
 
 def _closing_submitters(fn):
-    """Whatever way training_loop() ends, no submission thread and no altered GIL switch interval outlive it."""
+    """Whatever way training_loop() ends, the submission threads THIS call started and its altered GIL switch interval do not outlive it (submitters of
+    another loop running in the process are not touched: ADVICE r05).  On the way out of an exception the wait for the worker is bounded, so that a hung
+    replay cannot swallow the exception that reports it."""
     @functools.wraps(fn)
     def wrapper(*args, **kwargs):
+        before = set(SubmitThread.live)
+        host_threads = torch.get_num_threads()      # the loop caps PyTorch's CPU pool while it runs (hostaffinity.limit_host_threads, IGAN_HOST_THREADS); a library caller gets its setting back
+        failed = True
         try:
-            return fn(*args, **kwargs)
+            out = fn(*args, **kwargs)
+            failed = False
+            return out
         finally:
-            for sub in list(SubmitThread.live):
-                sub.close(check=False)
+            for sub in list(SubmitThread.live - before):
+                sub.close(check=False, timeout=30.0 if failed else None)
+            if torch.get_num_threads() != host_threads:
+                torch.set_num_threads(host_threads)
     return wrapper
 
 
@@ -455,7 +470,7 @@ def training_loop(
 
     hooks = hooks or {}
     from .. import hostaffinity
-    hostaffinity.limit_host_threads()       # every entry into the loop, not only run_training / bench.py: PyTorch's CPU pool sized to the affinity mask stalls the submissions
+    hostaffinity.limit_host_threads()       # every entry into the loop, not only run_training / bench.py: PyTorch's CPU pool sized to the affinity mask stalls the submissions; for the duration of the call only (the wrapper restores the caller's pool size)
 
     # Initialize (tflib.init_tf: rnd.np_random_seed, tfutil.py:122-147).
     rank, world = _dist_info()

@@ -131,7 +131,7 @@ print('PLANES-VARIANT-OK')
 def test_piece_forms_against_fp64(cuda_device, form):
     """IGAN_CONV_PLANES=1: three bf16 pieces, six products.  =2: two fp16 pieces under per-pixel / per-channel power-of-two scales, three products
     (the default form; channel counts that are not powers of two stay on the fp32 kernels there) -- same shapes, same tolerances."""
-    env = dict(os.environ, IGAN_CONV_PLANES=form, IGAN_PLANES_MIN_ROWS='1024', IGAN_WGRAD_PLANES_MIN_ROWS='1024')      # the 8x8 cases run in the piece form here (product threshold: 2048 rows)
+    env = dict(os.environ, IGAN_CONV_PLANES=form, IGAN_PLANES_MIN_ROWS='1024', IGAN_WGRAD_PLANES_MIN_ROWS='1024')      # the 8x8 cases run in the piece form (the product's threshold since round 6, stated here so that the cases do not move with it)
     r = subprocess.run([sys.executable, '-c', CHILD % ROOT], env=env, capture_output=True, text=True, timeout=600)
     sys.stdout.write(r.stdout[-3000:])
     assert r.returncode == 0 and 'PLANES-VARIANT-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

@@ -96,7 +96,8 @@ def stats(err, ref, mag, planes):
                emag=float((err / mag.clamp_min(1e-300))[mag > 0].pow(2).mean().sqrt()) if bool((mag > 0).any()) else 0.0)
     if planes > 1:
         e = err.reshape(planes, -1)
-        zp = e.mean(1) / (e.std(1) / e.shape[1] ** 0.5 + 1e-300)
+        zp = e.mean(1) / (e.std(1) / e.shape[1] ** 0.5).clamp_min(1e-300)
+        zp = torch.where(e.std(1) > 0, zp, torch.zeros_like(zp))        # a plane of one pixel (1x1 maps) has no spread
         out['zplane_max'] = float(zp.abs().max())
         out['zplane_rms'] = float(zp.pow(2).mean().sqrt())
     return out
