@@ -37,8 +37,9 @@ extern "C" {
 /* Bumped whenever a struct layout, a signature or the set of exports changes (2: fused conv epilogue fields, fp64 nearest-neighbour state;
  * 5 / 6: piece images and their sizes; 7: igan_conv_piece_form, igan_debug_f16_window; 8: the two-piece fp16 form scales every tensor per
  * pixel (forward / data gradient) or per channel (weight gradient) and writes its own images -- caller-written images (igan_to_pieces, x_pieces,
- * dy_pieces) belong to the bf16-piece form only; igan_conv2d_params gains x_colmax, igan_conv2d_wgrad_params x_colmax / dy_colmax at their ends). */
-#define IGAN_ABI_VERSION 8
+ * dy_pieces) belong to the bf16-piece form only; igan_conv2d_params gains x_colmax, igan_conv2d_wgrad_params x_colmax / dy_colmax at their ends;
+ * 9: igan_conv2d_params gains w_pieces / w_pieces_bytes -- a caller-kept FILTER image for weights that never change (igan_filter_image_bytes, igan_filter_image)). */
+#define IGAN_ABI_VERSION 9
 
 typedef void* igan_stream_t; /* hipStream_t */
 
@@ -221,6 +222,10 @@ typedef struct igan_conv2d_params {
     float* x_colmax;        /* ABI v8, fp16 form, optional OUTPUT (igan_colmax_floats(N, H * W, Cin) floats, 16-byte aligned; NULL = none): the per-channel maxima of
                              * |x * in_scale| -- a by-product of the row image this call writes of x (a pass of its own when the call takes another path), which a later
                              * igan_conv2d_wgrad() of the SAME tensor takes as x_colmax / dy_colmax instead of a pass of its own over it */
+    const void* w_pieces;   /* ABI v9, piece forms, optional: the image of THIS call's filter (same w, KH, KW, Cin, Cout, w_transposed) written earlier by
+                             * igan_filter_image() -- for weights that are constants of the run (the LPIPS network's: 36 filter images per generator step
+                             * otherwise); the call then writes none.  NULL = the call images its filter itself.  Ignored by calls that run on the fp32 instruction */
+    size_t w_pieces_bytes;  /* its size, igan_filter_image_bytes(KH, KW, Cin, Cout): an image of any other size is rejected, never read */
 } igan_conv2d_params;
 
 int igan_conv2d_plan(const igan_conv2d_params* p, int* splits, int* sliced_tiles, size_t* workspace_floats);
@@ -276,6 +281,11 @@ int igan_pieces_image_ok(int N, int HW, int C);
  * channel's pixels in the weight gradient -- never a whole tensor), three products; the operand to 2^-23 (exactly in three cases of four) for every
  * element within 2^26 of the largest of its own group. */
 int igan_conv_piece_form(void);
+/* ABI v9: the filter image of a convolution call as a caller-kept buffer.  igan_filter_image_bytes: its size for a call with this filter geometry (Cin / Cout are the
+ * CALL's: a data-gradient call has them swapped against its forward layer), 0 = this process / filter takes none (form 0; a 1x1 or thin filter; a channel count outside
+ * the piece form).  igan_filter_image: writes it (16-byte aligned `out`; the same kernels igan_conv2d runs for its own image, so results are bit-identical). */
+size_t igan_filter_image_bytes(int KH, int KW, int Cin, int Cout);
+int igan_filter_image(igan_stream_t stream, const float* w, void* out, int KH, int KW, int Cin, int Cout, int w_transposed);
 /* ABI v8: size in floats of an x_colmax / dy_colmax buffer for a tensor [N, HW, C]; 0 = none is taken (not the fp16 form, a channel count outside it, or fewer
  * pixels than any weight gradient that takes the column image has: N * HW below the piece form's row threshold). */
 size_t igan_colmax_floats(int N, int HW, int C);

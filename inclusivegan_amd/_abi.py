@@ -61,6 +61,7 @@ class Conv2DParams(ctypes.Structure):
         ('noise', ctypes.c_void_p), ('noise_strength', ctypes.c_void_p), ('noise_bcast', ctypes.c_int),
         ('x_pieces', ctypes.c_void_p), ('x_pieces_bytes', ctypes.c_size_t),
         ('x_colmax', ctypes.c_void_p),
+        ('w_pieces', ctypes.c_void_p), ('w_pieces_bytes', ctypes.c_size_t),
     ]
 
     def __init__(self, *args, **kwargs):
@@ -116,7 +117,7 @@ class TapsParams(ctypes.Structure):
                 ('taps', ctypes.c_int), ('n', ctypes.c_int), ('scale', ctypes.c_float)]
 
 
-ABI_VERSION = 8      # include/igan_hip.h IGAN_ABI_VERSION
+ABI_VERSION = 9      # include/igan_hip.h IGAN_ABI_VERSION
 STRUCTS = (UpFirDn2DParams, FusedBiasActParams, Conv2DParams, Conv2DWgradParams, DenseParams, DenseWgradParams, TapsParams)   # igan_struct_size ids
 
 DENSE_MAX_GROUPS = 24
@@ -150,6 +151,8 @@ SIGNATURES = {
     'igan_conv2d_wgrad': (_I, [_P, ctypes.POINTER(Conv2DWgradParams)]),
     'igan_debug_f16_window_by_kind': (_I, [_P, _I]),
     'igan_colmax_floats': (ctypes.c_size_t, [_I, _I, _I]),
+    'igan_filter_image_bytes': (ctypes.c_size_t, [_I, _I, _I, _I]),
+    'igan_filter_image': (_I, [_P, _P, _P, _I, _I, _I, _I, _I]),
     'igan_to_pieces': (_I, [_P, _P, _P, _P, _I, _I, _I]),
     'igan_conv_pieces_wanted': (_I, [_I, _I, _I, _I]),
     'igan_pieces_image_ok': (_I, [_I, _I, _I]),

@@ -3409,7 +3409,11 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
         }
         // (the filter image beside the x image on a second stream, forked and joined by events -- two branches inside the captured graphs -- is correct and
         // 5.6 % SLOWER in the bench: 333.9 -> 315.1 img/s, profiles/r05_small_layers.txt section 3)
-        if (!(a.diag_mode & 1)) launch_filter_image(stream, p->w, wp, wt, p->KH * p->KW, p->KW, p->Cout, p->Cin);
+        if (p->w_pieces != nullptr) {     // ABI v9: a constant filter's image, kept by the caller (igan_filter_image): nothing to write
+            IGAN_REQUIRE(p->w_pieces_bytes == igan_filter_image_bytes(p->KH, p->KW, p->Cin, p->Cout) && (((uintptr_t)p->w_pieces) & 15) == 0,
+                         "conv2d: w_pieces is not an image igan_filter_image() wrote for this filter (size / alignment)");
+            wp = reinterpret_cast<unsigned short*>(const_cast<void*>(p->w_pieces));
+        } else if (!(a.diag_mode & 1)) launch_filter_image(stream, p->w, wp, wt, p->KH * p->KW, p->KW, p->Cout, p->Cin);
         a.xp = xp; a.wp = wp;
         a.cpt = cpp;
         if (a.diag_mode & 2) {}          // DIAGNOSTIC: image kernels only
@@ -3742,6 +3746,29 @@ extern "C" size_t igan_colmax_floats(int N, int HW, int C) {
     // and an up-sampling layer's input has a quarter of its output's pixels): the maxima would be two dead kernels and up to 2 MB of saved state per small layer
     if ((long long)N * HW < wgrad_min_rows()) return 0;
     return 4 + (size_t)H_COLBLOCKS * C;
+}
+
+// ABI v9: the filter image as a caller-kept buffer (constant weights: the LPIPS network's 13 filters are imaged 36 times per generator step otherwise).
+// The conditions are the filter's share of planes_shape_ok(); whether a given call takes the piece form also depends on its rows -- a call that does not ignores the image.
+extern "C" size_t igan_filter_image_bytes(int KH, int KW, int Cin, int Cout) {
+    using namespace igan;
+    if (!planes_enabled() || KH < 1 || KW < 1 || Cin < 1 || Cout < 1 || KH * KW == 1 || Cin % BK != 0 || (long long)KH * KW * Cin < 1152) return 0;
+    if ((long long)KH * KW * Cin * Cout * 6 >= 0x7FFFFF00LL) return 0;
+    if (planes_mode() == 2) {
+        if (!pow2(Cin / PK) || Cin / PK > 64 || KH * KW > 9 || Cout % 4 != 0) return 0;
+        return filter_part_bytes((size_t)KH * KW, (size_t)Cout, (size_t)Cin);
+    }
+    return (size_t)KH * KW * Cin * Cout * 6;
+}
+
+extern "C" int igan_filter_image(igan_stream_t stream_, const float* w, void* out, int KH, int KW, int Cin, int Cout, int w_transposed) {
+    using namespace igan;
+    IGAN_REQUIRE(w != nullptr && out != nullptr, "filter_image: null buffer");
+    IGAN_REQUIRE(igan_filter_image_bytes(KH, KW, Cin, Cout) != 0, "filter_image: igan_filter_image_bytes() says this process / filter takes none");
+    IGAN_REQUIRE(((((uintptr_t)w) | ((uintptr_t)out)) & 15) == 0, "filter_image: w and out must be 16-byte aligned");
+    launch_filter_image((hipStream_t)stream_, w, reinterpret_cast<unsigned short*>(out), w_transposed != 0, KH * KW, KW, Cout, Cin);
+    IGAN_LAUNCH_CHECK("filter_image launch");
+    return IGAN_OK;
 }
 
 extern "C" int igan_conv_pieces_wanted(int KH, int KW, int Cin, int Cout) {

@@ -32,20 +32,26 @@ struct ThinArgs {
 // instead of NV * log2(width): at offset 1, 2, 4, ... each lane keeps half of its values and sends the other half
 // to its partner (reduce-scatter), then the single remaining value is butterflied over the higher offsets.
 // On return lane l holds (in val[0]) the group total of value index  sum_k bit_k(l) * NV >> (k+1).
+// Round 6: the stages are a template recursion, so that every index into val[] is a compile-time constant.  Written as a loop over (cnt, off) the compiler
+// kept val[] dynamically indexed -- 450 compare / select pairs per call, 6 000 issue cycles per 4 KB of input: thin_out_kernel was bound by THAT (ToRGB at
+// 128x128: 1.7 TB/s), not by memory.
+template <int CNT, int OFF, int NV>
+__device__ __forceinline__ void reduce_scatter_stage(float (&val)[NV], int lane_in_group) {
+    if constexpr (CNT > 1) {
+        const bool hi = (lane_in_group & OFF) != 0;
+#pragma unroll
+        for (int i = 0; i < CNT / 2; i++) {
+            const float send = hi ? val[i] : val[i + CNT / 2];
+            const float keep = hi ? val[i + CNT / 2] : val[i];
+            val[i] = keep + __shfl_xor(send, OFF, 64);
+        }
+        reduce_scatter_stage<CNT / 2, OFF * 2, NV>(val, lane_in_group);
+    }
+}
 template <int NV>
 __device__ __forceinline__ void group_reduce_scatter(float (&val)[NV], int lane_in_group, int width) {
-    int off = 1;
-#pragma unroll
-    for (int cnt = NV; cnt > 1; cnt >>= 1, off <<= 1) {
-        const bool hi = (lane_in_group & off) != 0;
-#pragma unroll
-        for (int i = 0; i < cnt / 2; i++) {
-            const float send = hi ? val[i] : val[i + cnt / 2];
-            const float keep = hi ? val[i + cnt / 2] : val[i];
-            val[i] = keep + __shfl_xor(send, off, 64);
-        }
-    }
-    for (; off < width; off <<= 1) val[0] += __shfl_xor(val[0], off, 64);
+    reduce_scatter_stage<NV, 1, NV>(val, lane_in_group);
+    for (int off = NV; off < width; off <<= 1) val[0] += __shfl_xor(val[0], off, 64);
 }
 template <int NV>
 __device__ __forceinline__ int reduce_scatter_index(int lane_in_group) {
@@ -64,26 +70,30 @@ __global__ __launch_bounds__(256) void thin_out_kernel(ThinArgs a, int gw) {
     const int gwave = (blockIdx.x * 256 + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * 256) >> 6;
     const int npix = a.N * a.OH * a.OW;
-    // weights of this lane: W(tap, ci = 4*(lc + gw*cb) + e, co) for cb < CB, e < 4, co < 4 (zero-padded)
+    // weights of this lane: W(tap, ci = 4*(lc + gw*cb) + e, co) for cb < CB, e < 4, co < 4 (zero-padded).  Round 6: all of them are fetched by buffer loads whose
+    // out-of-range offsets return 0 (no branch per element) and are in flight together -- written as `if (ok) v = w[...]` the compiler made every element a branch
+    // with its own wait, a chain of 16 ... 144 dependent round trips per wave in front of a kernel that streams 200 MB (ToRGB at 128x128: 118 us, 1.7 TB/s).
+    constexpr int KWc = (TAPS == 9) ? 3 : 1, KHc = TAPS / KWc;      // thin_conv_kind admits 1x1 and 3x3 only
     float wr[CB][TAPS][4][4];
+    {
+        constexpr unsigned WOOB = 0x7FFFFFF0u;
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)((unsigned)TAPS * (unsigned)a.Cin * (unsigned)a.Cout * 4u), 0x00020000);
 #pragma unroll
-    for (int cb = 0; cb < CB; cb++)
+        for (int cb = 0; cb < CB; cb++)
 #pragma unroll
-        for (int t = 0; t < TAPS; t++)
+            for (int t = 0; t < TAPS; t++)
 #pragma unroll
-            for (int e = 0; e < 4; e++)
+                for (int e = 0; e < 4; e++)
 #pragma unroll
-                for (int co = 0; co < 4; co++) {
-                    float v = 0.f;
-                    const int ci = 4 * (lc + gw * cb) + e;
-                    if (co < a.Cout && ci < a.Cin) {
-                        const int ky = t / a.KW, kx = t - ky * a.KW;
-                        const int KH = TAPS / a.KW;
-                        v = a.wt ? a.w[((size_t)((KH - 1 - ky) * a.KW + (a.KW - 1 - kx)) * a.Cout + co) * a.Cin + ci]
-                                 : a.w[((size_t)t * a.Cin + ci) * a.Cout + co];
+                    for (int co = 0; co < 4; co++) {
+                        const int ci = 4 * (lc + gw * cb) + e;
+                        const int ky = t / KWc, kx = t - ky * KWc;
+                        const unsigned idx = a.wt ? (unsigned)(((KHc - 1 - ky) * KWc + (KWc - 1 - kx)) * a.Cout + co) * (unsigned)a.Cin + (unsigned)ci
+                                                  : ((unsigned)t * (unsigned)a.Cin + (unsigned)ci) * (unsigned)a.Cout + (unsigned)co;
+                        const bool ok = co < a.Cout && ci < a.Cin;
+                        wr[cb][t][e][co] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rw, ok ? idx * 4u : WOOB, 0, 0));
                     }
-                    wr[cb][t][e][co] = v;
-                }
+    }
     // U pixel steps per iteration with all their loads in flight together (one load per iteration is a latency chain)
     constexpr int U = (TAPS == 1) ? 4 : 1;
     for (int p0 = gwave * ppw * U; p0 < npix; p0 += nwaves * ppw * U) {      // wave-uniform trip count
@@ -109,7 +119,7 @@ __global__ __launch_bounds__(256) void thin_out_kernel(ThinArgs a, int gw) {
                 sc[u][cb] = a.in_scale ? *reinterpret_cast<const float4*>(a.in_scale + (size_t)n * a.Cin + ci) : make_float4(1.f, 1.f, 1.f, 1.f);
 #pragma unroll
                 for (int t = 0; t < TAPS; t++) {
-                    const int ky = t / a.KW, kx = t - ky * a.KW;
+                    const int ky = t / KWc, kx = t - ky * KWc;
                     const int iy = oy + ky - a.pad_y, ix = ox + kx - a.pad_x;
                     // 1x1 (pad 0, same size: thin_conv_kind): the input pixel is the output pixel
                     const bool in = (TAPS == 1) ? okp[u] : (okp[u] && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W);

@@ -638,6 +638,42 @@ def colmax_buffer(x, want=True):
     return torch.empty((fl,), device=x.device, dtype=torch.float32)
 
 
+_filter_bytes = {}
+FILTER_CACHE = os.environ.get('IGAN_FILTER_CACHE', '1') != '0'      # A/B switch: 0 = every call images its filter itself, constant or not
+
+
+def mark_constant(w):
+    """Declare a weight tensor a constant of the run (the LPIPS network's filters): the convolution calls on it keep ONE filter image per orientation on the
+    tensor object instead of writing one per call (ABI v9 w_pieces).  An in-place change of the tensor (its version counter) drops the images."""
+    w._igan_constant = True
+    return w
+
+
+def _constant_filter_image(lib, w, geom, cin, cout, w_transposed):
+    """The cached image of a constant filter for a call with this (Cin, Cout, orientation), or None (not a constant, no piece form for this filter, or the
+    first use falls inside a stream capture: an allocation made there belongs to the graph's pool and cannot be kept)."""
+    if not (FILTER_CACHE and getattr(w, '_igan_constant', False)):
+        return None
+    key = (geom.kh, geom.kw, int(cin), int(cout))
+    nbytes = _filter_bytes.get(key)
+    if nbytes is None:
+        nbytes = _filter_bytes[key] = int(lib.igan_filter_image_bytes(*key))
+    if nbytes == 0 or (w.data_ptr() & 15):
+        return None
+    cache = getattr(w, '_igan_filter_images', None)
+    if cache is None or cache[0] != w._version:
+        cache = (w._version, {})
+        w._igan_filter_images = cache
+    img = cache[1].get((key, bool(w_transposed)))
+    if img is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        img = torch.empty(((nbytes + 3) // 4,), device=w.device, dtype=torch.float32)
+        _abi.check(lib.igan_filter_image(_stream(), _ptr(w), _ptr(img), geom.kh, geom.kw, int(cin), int(cout), 1 if w_transposed else 0))
+        cache[1][(key, bool(w_transposed))] = img
+    return PieceImage(img, nbytes)
+
+
 def conv2d_raw(x, w, geom, out_hw, cout, w_transposed=False, in_scale=None, out_scale=None, bias=None, act=None, noise=None, strength=None, x_pieces=None, colmax=None):
     """x: logical [N,Cin,H,W] (channels_last).  w: HWIO [KH,KW,Cin,Cout] (or the forward layer's
     [KH,KW,Cout,Cin] when w_transposed).  Returns logical [N,Cout,OH,OW] channels_last.
@@ -673,6 +709,10 @@ def conv2d_raw(x, w, geom, out_hw, cout, w_transposed=False, in_scale=None, out_
         p.x_pieces_bytes = x_pieces.nbytes
     if colmax is not None:      # fp16 form: the channel maxima of x * in_scale as a by-product (colmax_buffer)
         p.x_colmax = colmax.data_ptr()
+    wimg = _constant_filter_image(lib, w, geom, cin, cout, w_transposed)
+    if wimg is not None:        # a constant filter's image, written once (mark_constant)
+        p.w_pieces = wimg.data_ptr()
+        p.w_pieces_bytes = wimg.nbytes
     if noise is not None:       # epilogue noise: [N or 1, 1, OH, OW] contiguous + device scalar strength (needs act)
         noise = noise.contiguous()
         _require_cuda_f32(noise, strength)

@@ -46,6 +46,8 @@ def _conv_relu(x, fmaps, name):
         cin = int(x.shape[1])
         std = float(np.sqrt(2.0 / (9 * cin)))
         w = get_variable('weight', shape=[3, 3, cin, fmaps], initializer=('normal', std), trainable=False)
+        if w.device.type == 'cuda':
+            hip_ops.mark_constant(w)        # the perceptual network's weights never change: its filter images are written once, not 36 times per generator step
         b = get_variable('bias', shape=[fmaps], initializer=('zeros',), trainable=False)
         geom, out_hw = hip_ops.ConvGeom(3, 3, 1, 1, 1, 1), (int(x.shape[2]), int(x.shape[3]))
         if hip_ops.conv_bias_act_fusable(x, fmaps, 2):

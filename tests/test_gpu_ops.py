@@ -843,3 +843,46 @@ def test_fir_with_fused_epilogue_matches_two_step_form(case, cuda_device):
     assert tuple(y1.shape) == (N, C, H - 1, W - 1) and torch.equal(y1, y0)
     for a, r in zip(g1, g0):
         assert torch.equal(a, r)
+
+
+def test_constant_filter_image_is_written_once_and_bit_identical(cuda_device):
+    """ABI v9 (w_pieces): a weight marked as a constant of the run (the LPIPS network's filters, metrics/lpips.py) keeps ONE filter image per orientation on
+    the tensor; the calls that use it return bit for bit what a call that images its filter itself returns (forward with the fused epilogue, data gradient),
+    an in-place change of the weight drops the image, and a filter the piece form does not take gets none."""
+    from inclusivegan_amd import hip_ops, _abi
+    lib = _abi.get_plugin()
+    dev = cuda_device
+    g = torch.Generator().manual_seed(3)
+    N, C, H = 8, 256, 16           # 2048 rows: the piece form
+    x = to_nhwc_cuda(torch.randn(N, C, H, H, generator=g), dev)
+    dy = to_nhwc_cuda(torch.randn(N, C, H, H, generator=g), dev)
+    w = (torch.randn(3, 3, C, C, generator=g) / 48.0).to(dev)
+    b = torch.randn(C, generator=g).to(dev)
+    geom = hip_ops.ConvGeom(3, 3, 1, 1, 1, 1)
+    plain = (hip_ops.conv2d_raw(x, w, geom, (H, H), C, bias=b, act=(2, 0.0, 1.0)), hip_ops.conv2d_raw(dy, w, hip_ops.dgrad_geom(geom), (H, H), C, w_transposed=True))
+    assert getattr(w, '_igan_filter_images', None) is None
+    wc = hip_ops.mark_constant(w.clone())
+    for _ in range(2):
+        got = (hip_ops.conv2d_raw(x, wc, geom, (H, H), C, bias=b, act=(2, 0.0, 1.0)), hip_ops.conv2d_raw(dy, wc, hip_ops.dgrad_geom(geom), (H, H), C, w_transposed=True))
+        assert torch.equal(got[0], plain[0]) and torch.equal(got[1], plain[1])
+    form = lib.igan_conv_piece_form()
+    images = wc._igan_filter_images[1]
+    assert len(images) == (2 if form != 0 else 0), (form, list(images))
+    if form != 0:
+        assert lib.igan_filter_image_bytes(3, 3, C, C) > 0 and lib.igan_filter_image_bytes(1, 1, C, C) == 0 and lib.igan_filter_image_bytes(3, 3, 3, 64) == 0
+        first = next(iter(images.values()))
+        with torch.no_grad():
+            wc.mul_(2.0)                 # a new version of the weight: the images are rebuilt, the result follows the weight
+        got = hip_ops.conv2d_raw(dy, wc, hip_ops.dgrad_geom(geom), (H, H), C, w_transposed=True)
+        assert next(iter(wc._igan_filter_images[1].values())) is not first
+        assert rel_err(got, plain[1] * 2.0) < 1e-6
+        # a wrong-sized image is rejected by the library, never read
+        p = _abi.Conv2DParams(x=x.data_ptr(), w=w.data_ptr(), y=plain[0].data_ptr(), in_scale=None, out_scale=None, workspace=None, workspace_floats=0, N=N, H=H, W=H, Cin=C, OH=H, OW=H,
+                              Cout=C, KH=3, KW=3, stride=1, up=1, pad_y=1, pad_x=1, w_transposed=0, splits=1, alpha=1.0, bias=None, act=0, act_alpha=0.0, act_gain=1.0)
+        import ctypes
+        splits, sliced, wsf = ctypes.c_int(1), ctypes.c_int(0), ctypes.c_size_t(0)
+        _abi.check(lib.igan_conv2d_plan(ctypes.byref(p), ctypes.byref(splits), ctypes.byref(sliced), ctypes.byref(wsf)))
+        ws = torch.empty((wsf.value,), device=dev)
+        p.workspace, p.workspace_floats, p.splits, p.sliced_tiles = ws.data_ptr(), wsf.value, splits.value, sliced.value
+        p.w_pieces, p.w_pieces_bytes = first.data_ptr(), 12345
+        assert lib.igan_conv2d(None, ctypes.byref(p)) != 0 and b'w_pieces' in lib.igan_last_error()

@@ -3,6 +3,7 @@
   python tools/kernel_bench.py conv     [batch] [reps]   modulated conv 128x128 (north-star GEMM shape) -> TFLOP/s vs the form's peak (833.3 fp32-equivalent for the default two-piece fp16 form, 416.7 with IGAN_CONV_PLANES=1, 157.3 with =0)
   python tools/kernel_bench.py upfirdn  [batch] [reps]   the three upfirdn2d call sites at 128x128     -> GB/s vs 8 TB/s
   python tools/kernel_bench.py epilogue [batch] [reps]   fused noise+bias+lrelu forward / backward      -> GB/s
+  python tools/kernel_bench.py thin     [batch] [reps]   the 3-channel layers (ToRGB, FromRGB, VGG conv1_1 and their data gradients) at the bench's shapes -> GB/s
 Algorithmic bytes = (numel_in + numel_out) * 4."""
 import os
 import sys
@@ -77,6 +78,29 @@ def main():
         print('scale_dot     [B,128,128,128] %7.1f us  %7.1f GB/s  (2 reads + 1 write)' % (ms * 1e3, 3 * x.numel() * 4 / ms / 1e6))
         ms = time_ms(lambda: hip_ops.scale_dot_raw(x, dxs), reps)
         print('channel dot   [B,128,128,128] %7.1f us  %7.1f GB/s  (2 reads)' % (ms * 1e3, 2 * x.numel() * 4 / ms / 1e6))
+    elif mode == 'thin':
+        # thin-channel layers (csrc/thin_conv.hip) at the bench configuration's shapes: batch = 4 x minibatch_gpu generator samples; bytes = the wide tensor + the thin one
+        g1 = hip_ops.ConvGeom(1, 1, 1, 1, 0, 0)
+        g3 = hip_ops.ConvGeom(3, 3, 1, 1, 1, 1)
+        N = 4 * B
+        cases = [('ToRGB 128x128 C128 -> 3 (modulated)', N, 128, 128, 3, g1, False, True),
+                 ('ToRGB 64x64 C256 -> 3 (modulated)', N, 64, 256, 3, g1, False, True),
+                 ('ToRGB 32x32 C512 -> 3 (modulated)', N, 32, 512, 3, g1, False, True),
+                 ('FromRGB dgrad 128x128 C128 -> 3', N, 128, 128, 3, g1, True, False),
+                 ('VGG conv1_1 dgrad 3x3 C64 -> 3', 5 * B, 128, 64, 3, g3, True, False),
+                 ('FromRGB 128x128 3 -> C128', N, 128, 3, 128, g1, False, False),
+                 ('ToRGB dgrad 128x128 3 -> C128 (modulated)', N, 128, 3, 128, g1, True, True),
+                 ('VGG conv1_1 3x3 3 -> C64', 5 * B, 128, 3, 64, g3, False, False)]
+        for name, n, r, cin, cout, g, wt, mod in cases:
+            x = torch.randn(n, cin, r, r, device=dev).contiguous(memory_format=torch.channels_last)
+            w = torch.randn(*((g.kh, g.kw, cout, cin) if wt else (g.kh, g.kw, cin, cout)), device=dev)
+            sc = (torch.rand(n, cin, device=dev) + 0.5) if (mod and cin > 4) else None
+            osc = (torch.rand(n, cout, device=dev) + 0.5) if (mod and cin <= 4) else None
+            fn = lambda: hip_ops.conv2d_raw(x, w, g, (r, r), cout, w_transposed=wt, in_scale=sc, out_scale=osc)
+            y = fn()
+            ms = time_ms(fn, reps)
+            by = (x.numel() + y.numel()) * 4.0
+            print('%-44s N%-3d %7.1f us  %7.1f GB/s = %.1f %% of 8 TB/s' % (name, n, ms * 1e3, by / ms / 1e6, by / ms / 1e6 / HBM_PEAK * 100))
     else:
         raise SystemExit(__doc__)
 

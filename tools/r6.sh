@@ -24,6 +24,15 @@ second_order2)  # the per-call audit of both second-order ops, the loop states w
   run cfg2_loop_cpu32 1500 python tools/reg_forms.py --res 32 --state loop:4,16 --variants "0;2;cpu32" --out "$O/cfg2_loop_cpu32.json"
   bash tools/r6.sh ab 2 - "IGAN_PLANES_MIN_ROWS=1024 IGAN_WGRAD_PLANES_MIN_ROWS=1024"
   ;;
+thin_cache)     # round 6: thin_out rewrite + constant filter images: parity subset, microbench old / new library, bench A/B, the co-residency probe over every small kernel family
+  run tests 1500 python -m pytest tests/test_gpu_ops.py tests/test_gpu_planes_variant.py tests/test_gpu_networks.py tests/test_gpu_fullsize.py -m gpu -x -q
+  IGAN_LIB=inclusivegan_amd/csrc/libigan_hip_oldthin.so run thin_old 300 python tools/kernel_bench.py thin 6 50
+  run thin_new 300 python tools/kernel_bench.py thin 6 50
+  bash tools/r6.sh ab 2 "IGAN_LIB=inclusivegan_amd/csrc/libigan_hip_oldthin.so IGAN_FILTER_CACHE=0" "IGAN_FILTER_CACHE=0" "-"
+  PROBE_VICTIMS=dense,thin,lpips,nn1,scale_dot,smallconv,stream run probe_none 300 python tools/coresidency_probe.py none 4 0 15
+  PROBE_VICTIMS=dense,thin,lpips,nn1,scale_dot,smallconv,stream run probe_fwd2 300 python tools/coresidency_probe.py fwd2 4 4 25
+  PROBE_VICTIMS=dense,thin,lpips,nn1,scale_dot,smallconv,stream run probe_wgrad2 300 python tools/coresidency_probe.py wgrad2 4 4 25
+  ;;
 audit)          # per-call audit of one op under the three forms: bash tools/r6.sh audit D_reg [extra args]
   op=${1:-G_reg}; shift
   for f in 0 1 2; do IGAN_CONV_PLANES=$f run audit_${op}_form$f 900 python tools/conv_audit.py --op "$op" "$@"; done
