@@ -568,15 +568,25 @@ def training_loop(
     B = sched.minibatch_gpu
     C, R = training_set.shape[0], training_set.shape[1]
     LS = training_set.label_size
-    feed = dict(
-        reals_rec_1=torch.zeros((B, C, R, R), device=device), labels_rec_1=torch.zeros((B, LS), device=device),
-        latents_rec_1=torch.zeros([B] + G.input_shapes[0][1:], device=device),
-        reals_rec_2=torch.zeros((B, C, R, R), device=device), labels_rec_2=torch.zeros((B, LS), device=device),
-        latents_rec_2=torch.zeros([B] + G.input_shapes[0][1:], device=device),
-        reals=torch.zeros((2 * B, C, R, R), device=device, dtype=torch.uint8), labels=torch.zeros((2 * B, LS), device=device))
-    staging = [dict({k: torch.empty(v.shape, dtype=torch.float32).pin_memory() for k, v in feed.items() if '_rec_' in k},
-                    event=torch.cuda.Event()) for _ in range(3)]
-    stage_np = [{k: v.numpy() for k, v in st.items() if k != 'event'} for st in staging]       # views of the pinned buffers (same memory)
+    # The six per-iteration inputs of the G ops live in ONE device buffer and each staging set in ONE pinned host buffer (views per tensor, 256-byte aligned):
+    # an iteration uploads them with a single asynchronous copy.  (Round 6: as six copies the device sat idle between them -- 0.8 ms per iteration in
+    # profiles/r05_bench_steady_state.txt, "copyBuffer -> copyBuffer" -- because every copy is a host submission of its own.)
+    rec_shapes = dict(reals_rec_1=(B, C, R, R), labels_rec_1=(B, LS), latents_rec_1=tuple([B] + G.input_shapes[0][1:]),
+                      reals_rec_2=(B, C, R, R), labels_rec_2=(B, LS), latents_rec_2=tuple([B] + G.input_shapes[0][1:]))
+    rec_offsets, rec_total = {}, 0
+    for k, shp in rec_shapes.items():
+        rec_offsets[k] = rec_total
+        rec_total += (int(np.prod(shp)) + 63) // 64 * 64
+    rec_total = max(rec_total, 64)
+    rec_views = lambda flat: {k: flat[rec_offsets[k]:rec_offsets[k] + int(np.prod(shp))].view(shp) for k, shp in rec_shapes.items()}
+    feed_flat = torch.zeros((rec_total,), device=device)
+    feed = dict(rec_views(feed_flat),
+                reals=torch.zeros((2 * B, C, R, R), device=device, dtype=torch.uint8), labels=torch.zeros((2 * B, LS), device=device))
+    staging = []
+    for _ in range(3):
+        flat = torch.zeros((rec_total,), dtype=torch.float32).pin_memory()
+        staging.append(dict(rec_views(flat), flat=flat, event=torch.cuda.Event()))
+    stage_np = [{k: v.numpy() for k, v in st.items() if k not in ('event', 'flat')} for st in staging]       # views of the pinned buffers (same memory)
     use_graphs = graphs.graphs_enabled(hip_graphs)
     # Gradient exchange: chunk by chunk DURING backward (tflib/optimizer.py GradientExchange), inside the captured graph
     # when the process group's collectives can be captured (RCCL); otherwise (gloo) one all-reduce after each replay.
@@ -814,9 +824,7 @@ def training_loop(
                     np.copyto(stage_np[running_mb_counter % len(staging)][key % (h + 1)], arr[rs], casting='same_kind')
 
             def upload(stage=stage):
-                for key in stage:
-                    if key != 'event':
-                        feed[key].copy_(stage[key], non_blocking=True)
+                feed_flat.copy_(stage['flat'], non_blocking=True)      # all six inputs: one copy
                 stage['event'].record()
 
             # Run training ops (:474-479) -- handed to the submission thread in program order (or executed here when it is off).

@@ -49,7 +49,7 @@ def scan(path):
 
 def demangle(names):
     try:
-        r = subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-cxxfilt'], input='\n'.join(names), capture_output=True, text=True, check=True)
+        r = subprocess.run(['c++filt'], input='\n'.join(names), capture_output=True, text=True, check=True)
         return dict(zip(names, r.stdout.splitlines()))
     except Exception:
         return {n: n for n in names}

@@ -45,6 +45,18 @@ ab)             # alternating bench A/B of environment settings on one box: bash
       python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$e', d['value'], d['ms_per_step'], d.get('op_ms'), d['hip_graphs']['faithful'])" | tee -a "$O/ab.txt"
   done; done
   ;;
+evidence)       # the round's evidence set on the FINAL kernel sources: counter passes first (so that the bench line of the set carries roofline.traffic from passes
+                # on these very sources), then bench line / kernel tables / per-layer tables / microbenchmarks (tools/collect_pmc.sh, tools/collect_profiles.sh)
+  bash tools/collect_pmc.sh r06 > "$O/collect_pmc.log" 2>&1
+  python tools/pmc_to_json.py r06 conv_fwd_planes_w4_kernel > "$O/pmc_to_json.log" 2>&1
+  mkdir -p gpurun_out/prof_r06/pmc_json; cp profiles/r06_pmc* gpurun_out/prof_r06/pmc_json/ 2>/dev/null
+  bash tools/collect_profiles.sh r06 > "$O/collect_profiles.log" 2>&1
+  python tools/kernel_bench.py thin 6 50 >> gpurun_out/prof_r06/kernel_bench.txt 2>/dev/null
+  tail -3 "$O/collect_pmc.log" "$O/pmc_to_json.log"
+  ;;
+driver)         # the driver's own command, twice in a row
+  for i in 1 2; do run driver$i 1500 python bench.py --gpus 1 --steps 20 --warmup 5; done
+  ;;
 suite)          # the GPU suite with the tests' own prints kept (-rP)
   run gpu_tests 3000 python -m pytest tests -m gpu -q -rP --durations=15
   run smoke 600 python __graft_entry__.py smoke
