@@ -3693,7 +3693,9 @@ extern "C" int igan_conv2d_wgrad(igan_stream_t stream_, const igan_conv2d_wgrad_
     const int scm = (a.in_scale && a.out_scale) ? 1 : ((a.in_scale || a.out_scale) ? 2 : 0);
     // 8 waves pay on the short pixel axes (32x32 and below: +1.5 %), 4 waves on the 128x128 layers (+3-4 %): measured, tools/conv_bench.py
     const bool long_axis = (long long)p->OH * p->OW >= 128LL * 128LL;
-    if (t.BM == 128 && t.BN == 128 && eight_waves("IGAN_WGRAD_8WAVE") && !long_axis) launch_wgrad<128, 128, 2, 4>(stream, a, grid, vec, scm);
+    // (round 6) the scaled forms (scm != 0: the modulated layers below the piece form's row threshold) take the four-wave tile: at the 128 registers of eight waves they
+    // spill ten registers to scratch inside the loop (tools/asm_scan.py), at 256 they do not
+    if (t.BM == 128 && t.BN == 128 && eight_waves("IGAN_WGRAD_8WAVE") && !long_axis && scm == 0) launch_wgrad<128, 128, 2, 4>(stream, a, grid, vec, scm);
     else if (t.BM == 128 && t.BN == 128) launch_wgrad<128, 128, 2, 2>(stream, a, grid, vec, scm);
     else if (t.BM == 128 && t.BN == 32) launch_wgrad<128, 32, 4, 1>(stream, a, grid, vec, scm);
     else launch_wgrad<32, 128, 1, 4>(stream, a, grid, vec, scm);
