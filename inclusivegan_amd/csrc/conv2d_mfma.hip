@@ -3291,9 +3291,7 @@ extern "C" int igan_conv2d_kernel_name(const igan_conv2d_params* p, char* buf, i
         return IGAN_OK;
     }
     if (use_dma_kernel(p, t, walk_ok(p))) {
-        const int split = getenv("IGAN_CONV_BF16X3") ? atoi(getenv("IGAN_CONV_BF16X3")) : 0;
-        snprintf(buf, (size_t)buflen, split == 6 ? "conv_fwd_dma_kernel<%s, %s, 3>" : split ? "conv_fwd_dma_kernel<%s, %s, 2>" : "conv_fwd_dma_kernel<%s, %s>",
-                 wt ? "true" : "false", p->in_scale ? "true" : "false");
+        snprintf(buf, (size_t)buflen, "conv_fwd_dma_kernel<%s, %s>", wt ? "true" : "false", p->in_scale ? "true" : "false");
         return IGAN_OK;
     }
     int wm = 2, wn = 2;
@@ -3430,26 +3428,9 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
         launched = true;
     } else
     if (use_dma_kernel(p, t, a.walk != 0)) {       // LDS-DMA form of the 128x128 tile
-        // measure-only: IGAN_CONV_BF16X3=1 (two bf16 pieces per operand, three products) / IGAN_CONV_BF16X3=6 (three pieces, six
-        // products) run these launches on the bf16 matrix pipe; not fp32-exact
-        static const int split = getenv("IGAN_CONV_BF16X3") ? atoi(getenv("IGAN_CONV_BF16X3")) : 0;
-        if (split == 6) {
-            if (wt) {
-                if (a.in_scale) hipLaunchKernelGGL((conv_fwd_dma_kernel<true, true, 3>), grid, dim3(512), 0, stream, a);
-                else hipLaunchKernelGGL((conv_fwd_dma_kernel<true, false, 3>), grid, dim3(512), 0, stream, a);
-            } else {
-                if (a.in_scale) hipLaunchKernelGGL((conv_fwd_dma_kernel<false, true, 3>), grid, dim3(512), 0, stream, a);
-                else hipLaunchKernelGGL((conv_fwd_dma_kernel<false, false, 3>), grid, dim3(512), 0, stream, a);
-            }
-        } else if (split != 0) {
-            if (wt) {
-                if (a.in_scale) hipLaunchKernelGGL((conv_fwd_dma_kernel<true, true, 2>), grid, dim3(512), 0, stream, a);
-                else hipLaunchKernelGGL((conv_fwd_dma_kernel<true, false, 2>), grid, dim3(512), 0, stream, a);
-            } else {
-                if (a.in_scale) hipLaunchKernelGGL((conv_fwd_dma_kernel<false, true, 2>), grid, dim3(512), 0, stream, a);
-                else hipLaunchKernelGGL((conv_fwd_dma_kernel<false, false, 2>), grid, dim3(512), 0, stream, a);
-            }
-        } else if (wt) {
+        // (the in-register bf16 split forms of round 2 -- IGAN_CONV_BF16X3, PIECES = 2 / 3 of this kernel -- are no longer instantiated: measure-only, superseded by the
+        // piece kernels, and the only kernels of the library beside the 16-wave experiment that spilled to scratch: tools/asm_scan.py, HISTORY.md section 8)
+        if (wt) {
             if (a.in_scale) hipLaunchKernelGGL((conv_fwd_dma_kernel<true, true>), grid, dim3(512), 0, stream, a);
             else hipLaunchKernelGGL((conv_fwd_dma_kernel<true, false>), grid, dim3(512), 0, stream, a);
         } else {
@@ -3459,9 +3440,7 @@ extern "C" int igan_conv2d(igan_stream_t stream_, const igan_conv2d_params* p) {
         IGAN_LAUNCH_CHECK("conv2d (LDS-DMA) launch");
         launched = true;
     }
-    static const bool sixteen = getenv("IGAN_CONV_16WAVE") && atoi(getenv("IGAN_CONV_16WAVE")) == 1;     // experiment
     if (launched) {}
-    else if (t.BM == 128 && t.BN == 128 && sixteen) launch_fwd<128, 128, 4, 4>(stream, a, grid, wt, vec);
     else if (t.BM == 128 && t.BN == 128 && eight_waves("IGAN_CONV_8WAVE")) launch_fwd<128, 128, 2, 4>(stream, a, grid, wt, vec);
     else if (t.BM == 128 && t.BN == 128) launch_fwd<128, 128, 2, 2>(stream, a, grid, wt, vec);
     else if (t.BM == 128 && t.BN == 64 && eight_waves("IGAN_CONV_8WAVE")) launch_fwd<128, 64, 4, 2>(stream, a, grid, wt, vec);
@@ -3497,9 +3476,13 @@ int wgrad_geometry_check(const igan_conv2d_wgrad_params* p) {
 
 template <int BM, int BN, int WM, int WN, bool VEC>
 void launch_wgrad2(hipStream_t stream, const WgradArgs& a, dim3 grid, int scm) {
-    if (scm == 0) hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, VEC, 0>), grid, dim3(WM * WN * 64), 0, stream, a);
-    else if (scm == 1) hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, VEC, 1>), grid, dim3(WM * WN * 64), 0, stream, a);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, VEC, 2>), grid, dim3(WM * WN * 64), 0, stream, a);
+    if constexpr (BM == 128 && BN == 128 && WM * WN == 8) {      // the eight-wave 128x128 tile exists unscaled only (its scaled forms spilled: the dispatcher sends them to four waves)
+        hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, VEC, 0>), grid, dim3(WM * WN * 64), 0, stream, a);
+    } else {
+        if (scm == 0) hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, VEC, 0>), grid, dim3(WM * WN * 64), 0, stream, a);
+        else if (scm == 1) hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, VEC, 1>), grid, dim3(WM * WN * 64), 0, stream, a);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, VEC, 2>), grid, dim3(WM * WN * 64), 0, stream, a);
+    }
 }
 template <int BM, int BN, int WM, int WN>
 void launch_wgrad(hipStream_t stream, const WgradArgs& a, dim3 grid, bool vec, int scm) {
