@@ -1282,14 +1282,47 @@ def bcast_mul_taps_raw(w, v, scale):
     return out
 
 
-def style_mod_composite(y, a_w, a_b, w, c_a, c_w, demodulate):
-    """The same (s, d) from differentiable pieces (any order of differentiation; any sizes)."""
-    s = matmul(y, a_w, alpha=c_a) + a_b + 1.0
+class SumsqTapsFn(torch.autograd.Function):
+    """wsq[Cin, Cout] = sum over the taps of w^2 (the weights-only factor of the demodulation, networks_stylegan2.py:105-107) as ONE kernel with ONE kernel
+    for its gradient (2 w g, spread over the taps) -- as `(w * w).sum((0, 1))` the second-order path paid two passes over every [3, 3, Cin, Cout] filter
+    forward and three more backward, per layer and path-length step (the largest torch kernels of that step).  The gradient is linear in g and w: when the
+    backward is itself being recorded (create_graph) it is taken through differentiable torch operations."""
+
+    @staticmethod
+    def forward(ctx, w):
+        ctx.save_for_backward(w)
+        return sumsq_taps_raw(w)
+
+    @staticmethod
+    def backward(ctx, g):
+        w, = ctx.saved_tensors
+        if torch.is_grad_enabled():
+            return 2.0 * w * g[None, None]
+        return bcast_mul_taps_raw(w, g.contiguous(), 2.0)
+
+
+_SUMSQ_FN = os.environ.get('IGAN_SUMSQ_FN', '1') != '0'      # A/B switch: 0 = the torch composite (w * w).sum((0, 1))
+
+
+def _sumsq_taps(w):
+    if _SUMSQ_FN and w.is_cuda and w.dim() == 4 and (w.shape[2] * w.shape[3]) % 4 == 0 and not (w.data_ptr() & 15):
+        return SumsqTapsFn.apply(w)
+    return (w * w).sum(dim=(0, 1))
+
+
+def style_mod_composite(y, a_w, a_b, w, c_a, c_w, demodulate, b1=None):
+    """The same (s, d) from differentiable pieces (any order of differentiation; any sizes).  b1: a_b + 1 when the caller has it (style_bias_plus_one)."""
+    s = matmul(y, a_w, alpha=c_a) + (b1 if b1 is not None else a_b + 1.0)
     d = None
     if demodulate:
-        wsq = (w * w).sum(dim=(0, 1))
-        d = torch.rsqrt(matmul(s * s, wsq, alpha=c_w * c_w) + 1e-8)
+        d = torch.rsqrt(matmul(s * s, _sumsq_taps(w), alpha=c_w * c_w) + 1e-8)
     return s, d
+
+
+def style_bias_plus_one(biases):
+    """[a_b + 1 for every layer] from ONE concatenation and ONE add (views of the result): the second-order path's per-layer `+ a_b + 1` pairs."""
+    flat = torch.cat([b.reshape(-1) for b in biases]) + 1.0
+    return list(flat.split([b.numel() for b in biases]))
 
 
 _STYLE_FUSION = os.environ.get('IGAN_STYLE_FUSION', '1') != '0'      # A/B switch for profiling

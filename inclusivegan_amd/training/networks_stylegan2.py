@@ -162,7 +162,11 @@ def _precompute_styles(specs, dlatents, init_mul):
             l['wsq'] = v
     res = hip_ops.style_mod_all(layers)
     if res is None:
-        return None
+        if hip_ops._second_order_depth > 0:       # path-length step: the differentiable composites, with what is common to the layers done once
+            b1 = hip_ops.style_bias_plus_one([l['a_b'] for l in layers])
+            res = [hip_ops.style_mod_composite(l['y'], l['a_w'], l['a_b'], l['w'], l['c_a'], l['c_w'], l['demodulate'], b1=b1[i]) for i, l in enumerate(layers)]
+        else:
+            return None
     return {l['scope']: sd for l, sd in zip(layers, res)}
 
 #----------------------------------------------------------------------------

@@ -6,12 +6,22 @@ import shutil
 
 import pytest
 
-from tools import ds_read_check
+from tools import asm_scan, ds_read_check
+
+needs_hipcc = pytest.mark.skipif(not (os.path.exists('/opt/rocm/bin/hipcc') or shutil.which('hipcc')), reason='needs hipcc')
 
 
-@pytest.mark.skipif(not (os.path.exists('/opt/rocm/bin/hipcc') or shutil.which('hipcc')), reason='needs hipcc')
-def test_w4_tile_fragment_reads_are_untouched_until_their_wait():
-    r = ds_read_check.check(ds_read_check.assembly())
+@pytest.fixture(scope='module')
+def conv_asm(tmp_path_factory):
+    """gfx950 assembly of csrc/conv2d_mfma.hip (one 40 s compile for the checks below)."""
+    path = tmp_path_factory.mktemp('asm') / 'conv2d_mfma.s'
+    path.write_text(ds_read_check.assembly())
+    return str(path)
+
+
+@needs_hipcc
+def test_w4_tile_fragment_reads_are_untouched_until_their_wait(conv_asm):
+    r = ds_read_check.check(open(conv_asm).read())
     assert r['reads'] >= 16 and r['waits'] >= 2, r
     assert r['meta'].get('vgpr_spill_count', 0) == 0 and r['meta'].get('vgpr_count', 999) <= 256, r['meta']
     assert not r['problems'], '\n'.join(r['problems'])
@@ -30,3 +40,18 @@ _Z25conv_fwd_planes_w4_kernelN4igan8ConvArgsE:
 '''
     r = ds_read_check.check(asm)
     assert r['reads'] == 2 and len(r['problems']) == 1 and 'v[99]' in r['problems'][0], r
+
+
+@needs_hipcc
+def test_convolution_kernels_have_no_flat_access_and_no_scratch_on_any_configured_path(conv_asm):
+    """Round 6 (profiles/r06_coresidency.txt): under co-residency with another process's tile kernel it was a kernel's flat / scratch accesses that returned
+    wrong data, and spills inside a loop cost time in any case.  No kernel of conv2d_mfma.hip may have a flat instruction; scratch is tolerated only in the two
+    instantiations no BASELINE configuration reaches (the four-wave scaled weight gradient on RAGGED channel counts)."""
+    kernels = {k: v for k, v in asm_scan.scan(conv_asm).items() if 'vgpr_count' in v}
+    assert len(kernels) > 30
+    names = asm_scan.demangle(list(kernels))
+    flat = [names[k] for k, v in kernels.items() if v['flat']]
+    assert not flat, flat
+    scratch = sorted(names[k].replace('(anonymous namespace)::', '').split('(')[0] for k, v in kernels.items()
+                     if v.get('private_segment_fixed_size', 0) or v['scratch'] or v.get('vgpr_spill_count', 0))
+    assert scratch == ['void conv_wgrad_kernel<128, 128, 2, 2, false, 1>', 'void conv_wgrad_kernel<128, 128, 2, 2, false, 2>'], scratch
