@@ -33,6 +33,12 @@ thin_cache)     # round 6: thin_out rewrite + constant filter images: parity sub
   PROBE_VICTIMS=dense,thin,lpips,nn1,scale_dot,smallconv,stream run probe_fwd2 300 python tools/coresidency_probe.py fwd2 4 4 25
   PROBE_VICTIMS=dense,thin,lpips,nn1,scale_dot,smallconv,stream run probe_wgrad2 300 python tools/coresidency_probe.py wgrad2 4 4 25
   ;;
+glue)           # torch glue of the path-length step by source line, with and without SumsqTapsFn; parity of the step; bench A/B
+  IGAN_SUMSQ_FN=0 run glue_G_reg_composite 600 python tools/glue_attrib.py G_reg 60
+  run glue_G_reg 600 python tools/glue_attrib.py G_reg 60
+  run tests 1500 python -m pytest tests/test_gpu_networks.py tests/test_gpu_reg_forms.py "tests/test_gpu_loop_parity.py::test_graphed_training_loop_every_op_small_width" "tests/test_gpu_loop_parity.py::test_graph_replay_equals_eager_bitwise" -m gpu -x -q -rP
+  bash tools/r6.sh ab 2 "IGAN_SUMSQ_FN=0" "-"
+  ;;
 audit)          # per-call audit of one op under the three forms: bash tools/r6.sh audit D_reg [extra args]
   op=${1:-G_reg}; shift
   for f in 0 1 2; do IGAN_CONV_PLANES=$f run audit_${op}_form$f 900 python tools/conv_audit.py --op "$op" "$@"; done
