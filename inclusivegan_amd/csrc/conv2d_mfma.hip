@@ -2729,13 +2729,28 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_planes_kernel(WgradArgs a) 
     typedef __attribute__((address_space(3))) void lds_void;
     unsigned offA = OOB, offB = OOB;
     unsigned char* dA = nullptr;
+    // Round 6: the lane's byte offsets into the two images WALK with its pixel (modulo 2^32: exact whenever the pixel is valid): a step adds a wave-uniform delta and
+    // one correction per carry.  Decoded anew every step -- ((n H + iy) W + ix) rowA and its twin -- they cost six quarter-rate integer multiplies (v_mul_lo_u32,
+    // v_mad_u64_u32) per wave and step, in a loop whose vector work (10 instructions per matrix instruction) already outweighed its six products.  Same addresses, bit-identical results.
+    unsigned linA, linB;
+    {
+        const int iy0 = wqy * s_in + cy, ix0 = wqx * s_in + cx;
+        linA = (unsigned)((wn_ * a.H + iy0) * a.W + ix0) * rowA + constA;
+        const int oy0 = (wqy << a.up_shift) + py, ox0 = (wqx << a.up_shift) + px;
+        linB = (unsigned)((wn_ * a.OH + oy0) * a.OW + ox0) * rowB + constB;
+    }
+    const unsigned dA0 = (unsigned)((st_a1 * a.H + s_in * st_a2) * a.W + s_in * st_b) * rowA;       // st_a1 samples + st_a2 rows + st_b columns further
+    const unsigned dA1 = (unsigned)(s_in * a.W - s_in * QW) * rowA;                                 // the column carry: one row down, QW columns back
+    const unsigned dA2 = (unsigned)((a.H - s_in * QH) * a.W) * rowA;                                // the row carry: the next sample, QH rows back
+    const unsigned dB0 = (unsigned)((st_a1 * a.OH + up * st_a2) * a.OW + up * st_b) * rowB;
+    const unsigned dB1 = (unsigned)(up * a.OW - up * QW) * rowB;
+    const unsigned dB2 = (unsigned)((a.OH - up * QH) * a.OW) * rowB;
     auto dma_prep = [&](int stage) {
         const int iy = __mul24(wqy, s_in) + cy, ix = __mul24(wqx, s_in) + cx;
         const bool live = kp < Kpix;
         const bool okA = live & chA & ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);
-        offA = okA ? (unsigned)((wn_ * a.H + iy) * a.W + ix) * rowA + constA : OOB;
-        const int oy = (wqy << a.up_shift) + py, ox = (wqx << a.up_shift) + px;
-        offB = (live & chB) ? (unsigned)((wn_ * a.OH + oy) * a.OW + ox) * rowB + constB : OOB;
+        offA = okA ? linA : OOB;
+        offB = (live & chB) ? linB : OOB;
         dA = smem + stage * STAGE + (wave & 3) * 1024;
         kp += PK;                                   // walk to the same row of the next chunk
         wqx += st_b;
@@ -2744,7 +2759,8 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_planes_kernel(WgradArgs a) 
         wqy += st_a2 + (c1 ? 1 : 0);
         const bool c2 = wqy >= QH;
         wqy -= c2 ? QH : 0;
-        wn_ += st_a1 + (c2 ? 1 : 0);
+        linA += dA0 + (c1 ? dA1 : 0u) + (c2 ? dA2 : 0u);
+        linB += dB0 + (c1 ? dB1 : 0u) + (c2 ? dB2 : 0u);
     };
 #if IGAN_WGRAD_ASM_DMA
     const u32x4 wx = raw_rsrc_words(a.xp, xbytes), wdy = raw_rsrc_words(a.dyp, dybytes);

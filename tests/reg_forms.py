@@ -66,6 +66,10 @@ def save_state(path, cfg, G_vars, D_vars, pl_means, tape_G, tape_D, reals):
 
 def save_state_dict(path, state):
     save_state(path, state['cfg'], state['G'], state['D'], state['pl_means'], state['tape_G'], state['tape_D'], state['reals'])
+    if state.get('tape_Dloss'):          # the first-order D step (op 'D_loss'): its own draws; it reads the same `reals`
+        z = dict(np.load(path, allow_pickle=False))
+        z.update(_tape_arrays('tapeDloss', state['tape_Dloss']))
+        np.savez(path, **z)
 
 
 def load_state(path):
@@ -73,7 +77,10 @@ def load_state(path):
     cfg = json.loads(str(z['cfg']))
     G_vars = {k[2:]: z[k] for k in z.files if k.startswith('G/')}
     D_vars = {k[2:]: z[k] for k in z.files if k.startswith('D/')}
-    return dict(cfg=cfg, G=G_vars, D=D_vars, pl_means=[float(v) for v in z['pl_means']], tape_G=_tape_from(z, 'tapeG'), tape_D=_tape_from(z, 'tapeD'), reals=z['reals'])
+    st = dict(cfg=cfg, G=G_vars, D=D_vars, pl_means=[float(v) for v in z['pl_means']], tape_G=_tape_from(z, 'tapeG'), tape_D=_tape_from(z, 'tapeD'), reals=z['reals'])
+    if 'tapeDloss_kinds' in z.files:
+        st['tape_Dloss'] = _tape_from(z, 'tapeDloss')
+    return st
 
 
 def _assign(net, vars_):
@@ -123,6 +130,20 @@ def hip_ops_of_state(state, dev, ops=('G_reg', 'D_reg'), record=False):
             state['tape_D'] = list(src.entries)
         out['D_reg'] = dict(value=reg.detach().double().cpu().numpy(),
                             grads={n: v.grad.detach().cpu().numpy().copy() for n, v in D.trainables.items() if v.grad is not None})
+    if 'D_loss' in ops:          # the first-order D step (training/loss.py:93-105): G forward without gradients, D(fakes) and D(reals), softplus
+        _assign(G, state['G'])
+        G.zero_grad(); D.zero_grad()
+        reals = torch.from_numpy(state['reals']).to(dev).contiguous(memory_format=torch.channels_last)
+        lab2 = torch.zeros(reals.shape[0], 0, device=dev)
+        G.requires_grad_(False)
+        with tfutil.use_random(tfutil.RandomTape(state['tape_Dloss'])):
+            loss, _ = PL.D_logistic_r1(G, D, ts, B, reals, lab2, gamma=100, phase='loss')
+        G.requires_grad_(True)
+        torch.autograd.backward(loss.mean(), inputs=list(D.trainables.values()))
+        torch.cuda.synchronize()
+        out['D_loss'] = dict(value=loss.detach().double().cpu().numpy(),
+                             grads={n: v.grad.detach().cpu().numpy().copy() for n, v in D.trainables.items() if v.grad is not None})
+        _assign(G, state['G'])
     names = dict(G=list(G.trainables), D=list(D.trainables))
     return out, names
 
@@ -162,6 +183,14 @@ def oracle_ops_of_state(state, ops=('G_reg', 'D_reg'), trainables=None, dtype=to
         reg.mean().backward()
         out['D_reg'] = dict(value=reg.detach().double().numpy(), seconds=time.time() - t0,
                             grads={n: dp[n].grad.double().numpy() for n in trainables['D'] if dp[n].grad is not None})
+    if 'D_loss' in ops:
+        gp, dp = params(state['G'], []), params(state['D'], trainables['D'])
+        t0 = time.time()
+        loss, _, _ = OL.D_loss(gp, dp, ocfg, Tape(state['tape_Dloss'], dtype), B, torch.from_numpy(state['reals']).to(dtype), gamma=100, phase='loss',
+                               state=dict(dlatent_avg=gp['dlatent_avg']))
+        loss.mean().backward()
+        out['D_loss'] = dict(value=loss.detach().double().numpy(), seconds=time.time() - t0,
+                             grads={n: dp[n].grad.double().numpy() for n in trainables['D'] if dp[n].grad is not None})
     torch.set_num_threads(threads_before)
     return out
 

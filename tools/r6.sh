@@ -39,6 +39,14 @@ glue)           # torch glue of the path-length step by source line, with and wi
   run tests 1500 python -m pytest tests/test_gpu_networks.py tests/test_gpu_reg_forms.py "tests/test_gpu_loop_parity.py::test_graphed_training_loop_every_op_small_width" "tests/test_gpu_loop_parity.py::test_graph_replay_equals_eager_bitwise" -m gpu -x -q -rP
   bash tools/r6.sh ab 2 "IGAN_SUMSQ_FN=0" "-"
   ;;
+wgrad_walk)     # the weight gradient's walking addresses: bit-identity with the previous library, per-layer times alternating, parity, bench A/B
+  run digest_ab 1500 bash tools/planes_sched_ab.sh inclusivegan_amd/csrc/libigan_hip_oldwgrad.so 0.3
+  run tests 1500 python -m pytest tests/test_gpu_planes_variant.py tests/test_gpu_fullsize.py tests/test_gpu_ops.py tests/test_gpu_f16_dynamic_range.py -m gpu -x -q
+  bash tools/r6.sh ab 3 "IGAN_LIB=inclusivegan_amd/csrc/libigan_hip_oldwgrad.so" "-" "IGAN_LIB=inclusivegan_amd/csrc/libigan_hip_noslp.so"
+  ;;
+dstep)          # the first-order D step of early iterations of config 2 on ONE state under forms / thresholds / a second fp32 implementation (the all-ops run stops there at 1024 rows)
+  run cfg2_D_loop 2400 python tools/reg_forms.py --res 32 --state loop:1,2,5 --loop-op D --variants "0;1;2;2:2048;cpu32" --out "$O/cfg2_D_loop.json"
+  ;;
 audit)          # per-call audit of one op under the three forms: bash tools/r6.sh audit D_reg [extra args]
   op=${1:-G_reg}; shift
   for f in 0 1 2; do IGAN_CONV_PLANES=$f run audit_${op}_form$f 900 python tools/conv_audit.py --op "$op" "$@"; done

@@ -29,8 +29,8 @@ import inclusivegan_amd  # noqa: E402,F401
 from tests import reg_forms as RF  # noqa: E402
 
 
-def loop_states(res, fmap, B, iterations):
-    """Pre-op states of the G_reg ops of the given iterations from one run of the real loop (graphs on, default form)."""
+def loop_states(res, fmap, B, iterations, op='G_reg'):
+    """Pre-op states of the `op` ops ('G_reg' or 'D': the first-order D step) of the given iterations from one run of the real loop (graphs on, default form)."""
     from tests.test_gpu_loop_parity import record_loop, loop_kwargs, flat_of
     want = set(iterations)
     states = {}
@@ -45,7 +45,7 @@ def loop_states(res, fmap, B, iterations):
 
         def __call__(self, rec):
             init = box['init']
-            if rec['name'] == 'G_reg' and rec['it'] in want:
+            if rec['name'] == op and rec['it'] in want:
                 def named(which, flat):
                     out = {n: np.asarray(v).copy() for n, v in init[which].items()}
                     for n, (o, c, shape) in init[which + '_layout'].items():
@@ -53,8 +53,14 @@ def loop_states(res, fmap, B, iterations):
                     return out
                 Gv = named('G', box['pre']['G'])
                 Gv['dlatent_avg'] = box['dlatent_avg'].copy()
-                states[rec['it']] = dict(cfg=dict(res=res, fmap=fmap, B=B), G=Gv, D=named('D', box['pre']['D']), pl_means=[box['pl_mean']],
-                                         tape_G=rec['tape'], tape_D=[], reals=np.zeros((2 * B, 3, res, res), np.float32), hip_value=rec['value'])
+                if op == 'G_reg':
+                    states[rec['it']] = dict(cfg=dict(res=res, fmap=fmap, B=B), G=Gv, D=named('D', box['pre']['D']), pl_means=[box['pl_mean']],
+                                             tape_G=rec['tape'], tape_D=[], reals=np.zeros((2 * B, 3, res, res), np.float32), hip_value=rec['value'])
+                else:       # 'D': reals as the loop fed them (dataset range 0..255 -> [-1, 1], process_reals at lod 0 without mirroring)
+                    from oracle.misc import adjust_dynamic_range
+                    reals = np.ascontiguousarray(adjust_dynamic_range(rec['reals'].astype(np.float32), [0, 255], [-1, 1]), dtype=np.float32)
+                    states[rec['it']] = dict(cfg=dict(res=res, fmap=fmap, B=B), G=Gv, D=named('D', box['pre']['D']), pl_means=[box['pl_mean']],
+                                             tape_G=[], tape_D=[], tape_Dloss=rec['tape'], reals=reals, hip_value=rec['value'])
             key = 'G' if rec['name'].startswith('G') else 'D'
             box['pre'][key] = rec['post']['w' + key][:box['pre'][key].size].copy()
             box['pl_mean'] = rec['pl_mean']
@@ -81,6 +87,7 @@ def main():
     ap.add_argument('--variants', default='0;1;2')
     ap.add_argument('--ops', default='G_reg,D_reg')
     ap.add_argument('--out', default=None)
+    ap.add_argument('--loop-op', default='G_reg', help="with --state loop: which op's pre-state to take: G_reg or D (the first-order D step)")
     a = ap.parse_args()
     dev = torch.device('cuda', 0)
     ops = tuple(a.ops.split(','))
@@ -103,11 +110,11 @@ def main():
         todo = [('init (pl_mean fractions %s of the mean path length %.5g)' % (a.pl_fracs, state['mean_path_length']), state)]
     else:
         its = [int(x) for x in a.state.split(':')[1].split(',')]
-        st = loop_states(a.res, a.fmap, a.B, its)
+        st = loop_states(a.res, a.fmap, a.B, its, op=a.loop_op)
         G, D = RF.make_nets('cpu', a.res, a.fmap)
         names = dict(G=list(G.trainables), D=list(D.trainables))
-        todo = [('loop state before G_reg of iteration %d (0-based), pl_mean %.6g' % (it, st[it]['pl_means'][0]), st[it]) for it in its]
-        ops = ('G_reg',)
+        todo = [('loop state before %s of iteration %d (0-based), pl_mean %.6g' % (a.loop_op, it, st[it]['pl_means'][0]), st[it]) for it in its]
+        ops = ('G_reg',) if a.loop_op == 'G_reg' else ('D_loss',)
     torch.cuda.empty_cache()
     record = []
     tmp = tempfile.mkdtemp(prefix='reg_forms_')
