@@ -12,7 +12,7 @@ gathers on the device; tests/test_conv_audit_reference.py holds it to oracle/con
     emag    rms of err / sum_k |a_k b_k|                against the element's own magnitude sum
 
 The arithmetic form is the process's (IGAN_CONV_PLANES = 0 / 1 / 2 ...): run once per form.
-usage: python tools/conv_audit.py [--res 128] [--fmap 8192] [--B 6] [--op G_reg|D_reg] [--samples 1024] [--planes 8]"""
+usage: python tools/conv_audit.py [--res 128] [--fmap 8192] [--B 6] [--op G_reg|D_reg|D_loss] [--state file.npz] [--samples 1024] [--planes 8] [--min-k 1152]"""
 import argparse
 import ctypes
 import os
@@ -111,6 +111,7 @@ def main():
     ap.add_argument('--op', default='G_reg')
     ap.add_argument('--samples', type=int, default=1024)
     ap.add_argument('--planes', type=int, default=8)
+    ap.add_argument('--state', default=None, help='a state file of tests/reg_forms.py (tools/reg_forms.py --keep-state) instead of the initialisation state')
     ap.add_argument('--min-k', type=int, default=1152, help='audit calls with taps * Cin >= this (the piece forms start at 1152)')
     a = ap.parse_args()
     import inclusivegan_amd  # noqa: F401
@@ -188,19 +189,51 @@ def main():
         busy[0] = False
         return dw
 
-    state, _ = RF.init_state(dev, a.res, a.fmap, a.B, (0.0,))       # records the draws (unpatched), pl_mean = 0
+    if a.state:
+        state = RF.load_state(a.state)
+    else:
+        state, _ = RF.init_state(dev, a.res, a.fmap, a.B, (0.0,))       # records the draws (unpatched), pl_mean = 0
+    other = []
+    orig_ban_bwd, orig_mb_bwd = hip_ops.bias_act_noise_bwd_raw, hip_ops.mbstd_bwd_raw
+
+    def ban_bwd_wrapper(dy, y, noise, act_idx, alpha, gain, want_db):
+        out = orig_ban_bwd(dy, y, noise, act_idx, alpha, gain, want_db)
+        if y.device.type == 'cuda' and act_idx in (1, 2, 3):
+            with torch.no_grad():
+                d64, y64 = dy.double().reshape(y.shape), y.double()
+                slope = {1: torch.ones_like(y64), 2: (y64 > 0).double(), 3: torch.where(y64 > 0, torch.ones_like(y64), torch.full_like(y64, float(alpha)))}[act_idx]
+                ref = d64 * slope * float(gain)
+                e = float((out[0].double() - ref).norm() / ref.norm().clamp_min(1e-300))
+                eb = float((out[1].double() - ref.sum(dim=(0, 2, 3) if y.dim() == 4 else 0)).norm() / ref.sum(dim=(0, 2, 3) if y.dim() == 4 else 0).norm().clamp_min(1e-300)) if out[1] is not None else 0.0
+                other.append('ban_bwd   %-22s act %d  dx rel %.2e  db rel %.2e  zeros in y %d' % (tuple(y.shape), act_idx, e, eb, int((y == 0).sum())))
+        return out
+
+    def mb_bwd_wrapper(x, dy, g):
+        out = orig_mb_bwd(x, dy, g)
+        with torch.no_grad():
+            x64 = x.double().detach().requires_grad_(True)
+            with torch.enable_grad():
+                yc = hip_ops.mbstd_composite(x64, g)
+            ref, = torch.autograd.grad(yc, [x64], dy.double())
+            other.append('mbstd_bwd %-22s G %d  dx rel %.2e' % (tuple(x.shape), g, float((out.double() - ref).norm() / ref.norm())))
+        return out
+
     hip_ops.conv2d_raw, hip_ops.conv2d_wgrad_raw = conv_wrapper, wgrad_wrapper
+    hip_ops.bias_act_noise_bwd_raw, hip_ops.mbstd_bwd_raw = ban_bwd_wrapper, mb_bwd_wrapper
     try:
         RF.hip_ops_of_state(state, dev, ops=(a.op,))
     finally:
         hip_ops.conv2d_raw, hip_ops.conv2d_wgrad_raw = orig_conv, orig_wgrad
+        hip_ops.bias_act_noise_bwd_raw, hip_ops.mbstd_bwd_raw = orig_ban_bwd, orig_mb_bwd
     form = int(lib.igan_conv_piece_form())
     print('# conv calls of one %s step at %dx%d, fmap %d, minibatch_gpu %d; arithmetic form %d (IGAN_CONV_PLANES); %d samples per call in %d (sample, channel) planes'
-          % (a.op, a.res, a.res, a.fmap, a.B, form, a.samples, a.planes))
+          % (a.op, state['cfg']['res'], state['cfg']['res'], state['cfg']['fmap'], state['cfg']['B'], form, a.samples, a.planes))
     print('%-3s %-12s %-44s %-28s %9s %10s %7s %11s %9s' % ('#', 'kind', 'shape', 'kernel', 'rel', 'bias', 'z', 'zplane max/rms', 'emag'))
     for i, s in enumerate(rows):
         print('%-3d %-12s %-44s %-28s %9.2e %10.2e %7.2f %5.1f /%5.2f %9.2e' % (i, s['kind'], s['shape'], s['kernel'], s['rel'], s['bias'], s['z'],
                                                                               s.get('zplane_max', 0.0), s.get('zplane_rms', 0.0), s['emag']))
+    for line in other:
+        print('# other: ' + line)
     by = {}
     for s in rows:
         by.setdefault(s['kernel'], []).append(s)

@@ -47,6 +47,10 @@ wgrad_walk)     # the weight gradient's walking addresses: bit-identity with the
 dstep)          # the first-order D step of early iterations of config 2 on ONE state under forms / thresholds / a second fp32 implementation (the all-ops run stops there at 1024 rows)
   run cfg2_D_loop 2400 python tools/reg_forms.py --res 32 --state loop:1,2,5 --loop-op D --variants "0;1;2;2:2048;cpu32" --out "$O/cfg2_D_loop.json"
   ;;
+dstep_audit)    # the state before the D step of iteration 2 of config 2 (where every form sits 7e-3 from fp64 and PyTorch's CPU fp32 does not): every conv / dense call of that step against fp64
+  run capture 1500 python tools/reg_forms.py --res 32 --state loop:1 --loop-op D --variants "2" --keep-state /tmp/dstep_state
+  run audit_D_loss 900 python tools/conv_audit.py --op D_loss --state /tmp/dstep_state/state_0.npz --min-k 256 --samples 2048
+  ;;
 audit)          # per-call audit of one op under the three forms: bash tools/r6.sh audit D_reg [extra args]
   op=${1:-G_reg}; shift
   for f in 0 1 2; do IGAN_CONV_PLANES=$f run audit_${op}_form$f 900 python tools/conv_audit.py --op "$op" "$@"; done

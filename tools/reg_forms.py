@@ -87,6 +87,7 @@ def main():
     ap.add_argument('--variants', default='0;1;2')
     ap.add_argument('--ops', default='G_reg,D_reg')
     ap.add_argument('--out', default=None)
+    ap.add_argument('--keep-state', default=None, help='directory: keep every evaluated state file there as state_<k>.npz (for tools/conv_audit.py --state)')
     ap.add_argument('--loop-op', default='G_reg', help="with --state loop: which op's pre-state to take: G_reg or D (the first-order D step)")
     a = ap.parse_args()
     dev = torch.device('cuda', 0)
@@ -118,9 +119,12 @@ def main():
     torch.cuda.empty_cache()
     record = []
     tmp = tempfile.mkdtemp(prefix='reg_forms_')
-    for title, state in todo:
+    for k, (title, state) in enumerate(todo):
         spath = os.path.join(tmp, 'state.npz')
         RF.save_state_dict(spath, state)
+        if a.keep_state:
+            os.makedirs(a.keep_state, exist_ok=True)
+            RF.save_state_dict(os.path.join(a.keep_state, 'state_%d.npz' % k), state)
         hip, digs = {}, {}
         for label, env in variants:
             if env is None:
