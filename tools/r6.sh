@@ -50,6 +50,7 @@ dstep)          # the first-order D step of early iterations of config 2 on ONE 
 dstep_audit)    # the state before the D step of iteration 2 of config 2 (where every form sits 7e-3 from fp64 and PyTorch's CPU fp32 does not): every conv / dense call of that step against fp64
   run capture 1500 python tools/reg_forms.py --res 32 --state loop:1 --loop-op D --variants "2" --keep-state /tmp/dstep_state
   run audit_D_loss 900 python tools/conv_audit.py --op D_loss --state /tmp/dstep_state/state_0.npz --min-k 256 --samples 2048
+  run kink_flips 900 python tools/kink_flips.py /tmp/dstep_state/state_0.npz
   ;;
 audit)          # per-call audit of one op under the three forms: bash tools/r6.sh audit D_reg [extra args]
   op=${1:-G_reg}; shift
