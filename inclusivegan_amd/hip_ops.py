@@ -662,6 +662,8 @@ def _constant_filter_image(lib, w, geom, cin, cout, w_transposed):
         return None
     cache = getattr(w, '_igan_filter_images', None)
     if cache is None or cache[0] != w._version:
+        if cache is not None:        # a captured hipGraph may still read the old images: they stay allocated (a constant changes a handful of times per run at most)
+            w._igan_filter_keepalive = getattr(w, '_igan_filter_keepalive', []) + list(cache[1].values())
         cache = (w._version, {})
         w._igan_filter_images = cache
     img = cache[1].get((key, bool(w_transposed)))
